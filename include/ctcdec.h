@@ -1,0 +1,171 @@
+/*
+ * ctcdec.h -- C ABI of libctcdec.so, the MI355X-native CTC prefix-beam-search decoder.
+ *
+ * The reference (kensho-technologies/pyctcdecode) is pure Python and has NO FFI: its boundary for
+ * this path is the Python surface BeamSearchDecoderCTC.decode / decode_beams / decode_batch /
+ * decode_beams_batch (pyctcdecode/decoder.py:730-945) built by build_ctcdecoder
+ * (decoder.py:1051-1099).  This header is the C ABI a maintainer would bind underneath that
+ * surface (ctypes stub: INTEGRATION.md); every entry point cites the reference code it replaces.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * negative ctcdec_status otherwise (never throws); ctcdec_last_error() returns a thread-local
+ * message.  The caller owns all input buffers; the library owns result objects until
+ * ctcdec_result_free().  One decoder handle may be used from one host thread at a time.
+ */
+#ifndef CTCDEC_H
+#define CTCDEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ctcdec_decoder ctcdec_decoder; /* opaque */
+typedef struct ctcdec_result ctcdec_result;   /* opaque */
+
+enum ctcdec_status {
+  CTCDEC_OK = 0,
+  CTCDEC_ERR_ARG = -1,     /* bad argument (ValueError on the Python side)            */
+  CTCDEC_ERR_IO = -2,      /* cannot read / parse the LM file                          */
+  CTCDEC_ERR_DEVICE = -3,  /* HIP runtime failure or no gfx950 device                  */
+  CTCDEC_ERR_LIMIT = -4,   /* request exceeds a documented limit (beam width, order..) */
+  CTCDEC_ERR_INTERNAL = -5
+};
+
+enum ctcdec_dtype { CTCDEC_F32 = 0, CTCDEC_F64 = 1 };
+
+/* Maximum supported values (checked; CTCDEC_ERR_LIMIT otherwise). */
+#define CTCDEC_MAX_BEAM_WIDTH 256
+#define CTCDEC_MAX_LM_ORDER 6
+#define CTCDEC_MAX_VOCAB 65535
+
+/* Decode-time parameters: the keyword arguments of decode_beams (decoder.py:730-740) plus the
+ * LM parameters that reset_params may change between calls (decoder.py:292-313,
+ * language_model.py:271-301), which is why they are per-call kernel arguments. */
+typedef struct ctcdec_params {
+  int32_t beam_width;        /* DEFAULT_BEAM_WIDTH 100       constants.py:8  */
+  int32_t prune_history;     /* 0/1; decode() forces 1       decoder.py:888  */
+  int32_t n_best;            /* beams to return per utterance (<=0: all, 1 for decode()) */
+  int32_t want_lm_state;     /* 0/1: also return last_lm_state per beam      */
+  double beam_prune_logp;    /* DEFAULT_PRUNE_LOGP -10       constants.py:10 */
+  double token_min_logp;     /* DEFAULT_MIN_TOKEN_LOGP -5    constants.py:12 */
+  double hotword_weight;     /* DEFAULT_HOTWORD_WEIGHT 10    constants.py:9  */
+  double alpha;              /* language_model.py:266        */
+  double beta;               /* language_model.py:267        */
+  double unk_score_offset;   /* language_model.py:268        */
+  double log_base_change;    /* LOG_BASE_CHANGE_FACTOR       constants.py:18 */
+  int32_t lm_score_boundary; /* language_model.py:269        */
+  int32_t first_frame;       /* processed_frames offset      decoder.py:443  */
+} ctcdec_params;
+
+/* LM start state for one utterance (decode_beams(lm_start_state=...), decoder.py:621-625):
+ * context words newest first, as vocabulary indices of THIS decoder's LM, with the back-off
+ * weight of each context length. length == -1 means "use the LM's own start state". */
+typedef struct ctcdec_lm_state {
+  int32_t length;
+  uint32_t words[CTCDEC_MAX_LM_ORDER - 1];
+  float backoff[CTCDEC_MAX_LM_ORDER - 1];
+} ctcdec_lm_state;
+
+/* ---- construction: replaces BeamSearchDecoderCTC.__init__ / build_ctcdecoder ------------------
+ * labels_blob/labels_off: the NORMALISED alphabet (Alphabet.labels, alphabet.py:139-148) as one
+ * UTF-8 blob with n_labels+1 byte offsets; is_bpe = Alphabet.is_bpe.  device: HIP device index. */
+int ctcdec_create(const char* labels_blob, const int64_t* labels_off, int32_t n_labels,
+                  int32_t is_bpe, int32_t device, ctcdec_decoder** out);
+void ctcdec_destroy(ctcdec_decoder* dec);
+
+/* Replaces kenlm.Model(path) (decoder.py:1074): parse an ARPA file into the flat hashed n-gram
+ * trie and upload it.  order_out receives the n-gram order (LanguageModel.order). */
+int ctcdec_lm_load_arpa(ctcdec_decoder* dec, const char* path, int32_t* order_out);
+
+/* Replaces LanguageModel.__init__'s unigram handling (language_model.py:257-265, :87-103):
+ * unigrams given as a UTF-8 blob + offsets; has_unigrams=0 means "unigrams is None" (no trie).
+ * Words not in the LM vocabulary are dropped (language_model.py:95).  n_kept_out: |unigram_set|. */
+int ctcdec_lm_set_unigrams(ctcdec_decoder* dec, int32_t has_unigrams, const char* blob,
+                           const int64_t* off, int64_t n_unigrams, int64_t* n_kept_out);
+
+/* Let `dst` use the language model already loaded into `src` (shared, reference counted): a
+ * LanguageModel object constructed on its own (language_model.py:237-269) and later handed to
+ * BeamSearchDecoderCTC(alphabet, language_model) (decoder.py:275-290) is parsed only once. */
+int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src);
+
+/* Unigram char-trie query: CharTrie.has_node (language_model.py:331) and set membership
+ * (language_model.py:351).  flags_out: bit0 prefix of a unigram, bit1 LM vocabulary word,
+ * bit2 member of the unigram set. */
+int ctcdec_lm_prefix_flags(const ctcdec_decoder* dec, const char* str_utf8, int64_t len,
+                           uint32_t* flags_out);
+
+/* kenlm vocabulary queries used by the Python shell: Model.__contains__ (language_model.py:95,
+ * 352) and word index / word string for exporting and importing LM states. */
+int ctcdec_lm_word_index(const ctcdec_decoder* dec, const char* word_utf8, int64_t len,
+                         uint32_t* index_out);
+int ctcdec_lm_word_string(const ctcdec_decoder* dec, uint32_t index, const char** str_out,
+                          int64_t* len_out);
+
+/* Host-side single-word query = kenlm.Model.BaseScore (language_model.py:347) and the start
+ * states BeginSentenceWrite / NullContextWrite (language_model.py:311-314).  Used by the public
+ * LanguageModel.score()/get_start_state() methods, NOT by the decode path (which runs on device). */
+int ctcdec_lm_start_state(const ctcdec_decoder* dec, int32_t begin_sentence, ctcdec_lm_state* out);
+int ctcdec_lm_base_score(const ctcdec_decoder* dec, const ctcdec_lm_state* in, uint32_t word_index,
+                         ctcdec_lm_state* out, float* log10_prob_out);
+
+/* Replaces HotwordScorer.build_scorer (language_model.py:152-189) for the next decode calls:
+ * hot-word UNIGRAMS (already stripped and split by the caller) as UTF-8 blob + offsets. */
+int ctcdec_set_hotwords(ctcdec_decoder* dec, const char* blob, const int64_t* off, int64_t n_words);
+
+/* ---- the hot path: replaces decode_beams / decode_batch / decode_beams_batch ------------------
+ * utt_logits[i] points to a row-major [utt_frames[i], n_labels] matrix of `dtype`; pointers may
+ * be device (HBM-resident, no copy) or host memory (copied H2D first), is_device tells which.
+ * start_states may be NULL. The call returns when results are on the host. */
+int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits,
+                        const int32_t* utt_frames, int32_t n_utts, int32_t dtype, int32_t is_device,
+                        const ctcdec_params* params, const ctcdec_lm_state* start_states,
+                        ctcdec_result** out);
+
+/* ---- results (OutputBeam fields, decoder.py:102-110, assembled as decoder.py:653-667) --------- */
+int32_t ctcdec_result_num_utts(const ctcdec_result* r);
+int32_t ctcdec_result_num_beams(const ctcdec_result* r, int32_t utt);
+/* text of beam b of utterance u (UTF-8, not NUL-terminated) */
+int ctcdec_result_text(const ctcdec_result* r, int32_t utt, int32_t beam, const char** str_out,
+                       int64_t* len_out);
+int ctcdec_result_scores(const ctcdec_result* r, int32_t utt, int32_t beam, double* logit_score,
+                         double* lm_score);
+/* word frames: n words; word k spans bytes [word_off[k], word_off[k+1]) of the text and frames
+ * [start[k], end[k]). Pointers stay valid until ctcdec_result_free. */
+int ctcdec_result_frames(const ctcdec_result* r, int32_t utt, int32_t beam, int32_t* n_words,
+                         const int32_t** word_off, const int32_t** start, const int32_t** end);
+int ctcdec_result_lm_state(const ctcdec_result* r, int32_t utt, int32_t beam, ctcdec_lm_state* out);
+/* Bulk view of a whole result (one call instead of four per beam): beams of utterance u are
+ * [beam_off[u], beam_off[u+1]); beam k's text is text_blob[text_off[k] .. text_off[k+1]); its words
+ * are [word_cnt_off[k], word_cnt_off[k+1]) in word_byte_off / word_start / word_end, where
+ * word_byte_off is relative to the beam's text and word j ends where word j+1 starts minus one
+ * space (or at the end of the text). Pointers stay valid until ctcdec_result_free. */
+typedef struct ctcdec_packed {
+  int64_t n_utts, n_beams, n_words;
+  const int64_t* beam_off;      /* [n_utts + 1]  */
+  const char* text_blob;
+  const int64_t* text_off;      /* [n_beams + 1] */
+  const double* logit_score;    /* [n_beams]     */
+  const double* lm_score;       /* [n_beams]     */
+  const int64_t* word_cnt_off;  /* [n_beams + 1] */
+  const int32_t* word_byte_off; /* [n_words]     */
+  const int32_t* word_start;    /* [n_words]     */
+  const int32_t* word_end;      /* [n_words]     */
+  const ctcdec_lm_state* lm_state; /* [n_beams]  */
+} ctcdec_packed;
+int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out);
+
+/* timing of the last call's device stages in milliseconds (HIP events on the decode stream):
+ * [0] frame-prune kernel, [1] beam kernel, [2] total device time incl. result copy */
+int ctcdec_result_timing(const ctcdec_result* r, double* ms3);
+void ctcdec_result_free(ctcdec_result* r);
+
+const char* ctcdec_last_error(void);
+const char* ctcdec_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTCDEC_H */

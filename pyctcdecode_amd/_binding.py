@@ -1,0 +1,150 @@
+"""ctypes binding of include/ctcdec.h.
+
+The library is the in-tree ``pyctcdecode_amd/libctcdec.so`` built by ``__graft_entry__.build()``
+(hipcc, gfx950).  There is no fallback of any kind: if the shared object is missing or no HIP
+device is usable, every decode entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctcdec.so")
+
+MAX_CTX = 5
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("beam_width", C.c_int32),
+        ("prune_history", C.c_int32),
+        ("n_best", C.c_int32),
+        ("want_lm_state", C.c_int32),
+        ("beam_prune_logp", C.c_double),
+        ("token_min_logp", C.c_double),
+        ("hotword_weight", C.c_double),
+        ("alpha", C.c_double),
+        ("beta", C.c_double),
+        ("unk_score_offset", C.c_double),
+        ("log_base_change", C.c_double),
+        ("lm_score_boundary", C.c_int32),
+        ("first_frame", C.c_int32),
+    ]
+
+
+class LmState(C.Structure):
+    _fields_ = [("length", C.c_int32), ("words", C.c_uint32 * MAX_CTX), ("backoff", C.c_float * MAX_CTX)]
+
+
+class Packed(C.Structure):
+    _fields_ = [
+        ("n_utts", C.c_int64),
+        ("n_beams", C.c_int64),
+        ("n_words", C.c_int64),
+        ("beam_off", C.POINTER(C.c_int64)),
+        ("text_blob", C.c_void_p),
+        ("text_off", C.POINTER(C.c_int64)),
+        ("logit_score", C.POINTER(C.c_double)),
+        ("lm_score", C.POINTER(C.c_double)),
+        ("word_cnt_off", C.POINTER(C.c_int64)),
+        ("word_byte_off", C.POINTER(C.c_int32)),
+        ("word_start", C.POINTER(C.c_int32)),
+        ("word_end", C.POINTER(C.c_int32)),
+        ("lm_state", C.POINTER(LmState)),
+    ]
+
+
+# every symbol include/ctcdec.h declares: name -> (restype, argtypes)
+_VP = C.c_void_p
+_PROTOS = {
+    "ctcdec_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "ctcdec_destroy": (None, [_VP]),
+    "ctcdec_lm_load_arpa": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int32)]),
+    "ctcdec_lm_set_unigrams": (C.c_int, [_VP, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
+                                         C.POINTER(C.c_int64)]),
+    "ctcdec_lm_share": (C.c_int, [_VP, _VP]),
+    "ctcdec_lm_prefix_flags": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(C.c_uint32)]),
+    "ctcdec_lm_word_index": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(C.c_uint32)]),
+    "ctcdec_lm_word_string": (C.c_int, [_VP, C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_int64)]),
+    "ctcdec_lm_start_state": (C.c_int, [_VP, C.c_int32, C.POINTER(LmState)]),
+    "ctcdec_lm_base_score": (C.c_int, [_VP, C.POINTER(LmState), C.c_uint32, C.POINTER(LmState),
+                                       C.POINTER(C.c_float)]),
+    "ctcdec_set_hotwords": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64), C.c_int64]),
+    "ctcdec_decode_batch": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(Params), C.POINTER(LmState), C.POINTER(_VP)]),
+    "ctcdec_result_num_utts": (C.c_int32, [_VP]),
+    "ctcdec_result_num_beams": (C.c_int32, [_VP, C.c_int32]),
+    "ctcdec_result_text": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_int64)]),
+    "ctcdec_result_scores": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ctcdec_result_frames": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                       C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
+                                       C.POINTER(C.POINTER(C.c_int32))]),
+    "ctcdec_result_lm_state": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(LmState)]),
+    "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
+    "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "ctcdec_result_free": (None, [_VP]),
+    "ctcdec_last_error": (C.c_char_p, []),
+    "ctcdec_version": (C.c_char_p, []),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded libctcdec with typed prototypes."""
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()'). pyctcdecode_amd has no CPU fallback." % path
+            )
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self.dll, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, rc: int) -> None:
+        if rc == 0:
+            return
+        msg = (self.dll.ctcdec_last_error() or b"").decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        if rc == -2:
+            raise OSError(msg)
+        if rc == -4:
+            raise NotImplementedError(msg)
+        raise NativeError("libctcdec error %d: %s" % (rc, msg))
+
+
+_LIB: Optional[Library] = None
+
+
+def get_library() -> Library:
+    global _LIB
+    if _LIB is None:
+        _LIB = Library()
+    return _LIB
+
+
+def pack_strings(strings: Sequence[str]):
+    """UTF-8 blob + int64 offsets (n+1)."""
+    enc = [s.encode("utf-8") for s in strings]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    if enc:
+        off[1:] = np.cumsum([len(e) for e in enc])
+    blob = b"".join(enc)
+    return blob, off
+
+
+def off_ptr(off: np.ndarray):
+    return off.ctypes.data_as(C.POINTER(C.c_int64))

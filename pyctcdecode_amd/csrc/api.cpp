@@ -1,0 +1,575 @@
+// api.cpp -- the C ABI of include/ctcdec.h on top of backend.h + host_tables.h.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/ctcdec.h"
+#include "backend.h"
+#include "beam_core.h"
+#include "host_tables.h"
+
+using namespace ctc;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes, std::string* err) {
+    if (bytes <= cap && p) return 0;
+    if (p) be::release(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    p = be::alloc(want, err);
+    if (!p) return -1;
+    cap = want;
+    return 0;
+  }
+  void drop() {
+    if (p) be::release(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+template <class T>
+int upload(DevBuf& b, const std::vector<T>& v, std::string* err) {
+  size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 16);
+  if (b.ensure(bytes, err)) return -1;
+  if (!v.empty() && be::h2d(b.p, v.data(), sizeof(T) * v.size(), err)) return -1;
+  return 0;
+}
+
+struct BeamResult {
+  std::string text;
+  std::vector<int32_t> word_off, start, end;
+  double logit = 0, lm = 0;
+  ctcdec_lm_state state;
+};
+
+}  // namespace
+
+struct ctcdec_decoder {
+  HostAlphabet alpha;
+  std::shared_ptr<HostLM> lm_ptr = std::make_shared<HostLM>();
+  HostLM& lm_ref() { return *lm_ptr; }
+  const HostLM& lm_ref() const { return *lm_ptr; }
+  bool has_lm = false;
+  HostHotwords hot;
+  bool tables_dirty = true, hot_dirty = true;
+  DevBuf d_tok, d_tok_hot, d_uni, d_ngr, d_pref, d_hot;
+  // per-call workspace (grow only)
+  DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
+      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head;
+  ~ctcdec_decoder() {
+    DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
+                     &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
+                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head};
+    for (DevBuf* b : all) b->drop();
+  }
+};
+
+struct ctcdec_result {
+  std::vector<std::vector<BeamResult>> utts;
+  double ms[3] = {0, 0, 0};
+  // packed view (built on demand by ctcdec_result_pack)
+  bool packed = false;
+  std::vector<int64_t> beam_off, text_off, word_cnt_off;
+  std::string text_blob;
+  std::vector<double> logit, lm;
+  std::vector<int32_t> word_byte_off, word_start, word_end;
+  std::vector<ctcdec_lm_state> states;
+};
+
+static int sync_tables(ctcdec_decoder* d, std::string* err) {
+  if (d->tables_dirty) {
+    if (d->has_lm) d->lm_ref().fill_token_starts(&d->alpha);
+    if (upload(d->d_tok, d->alpha.tok, err)) return -1;
+    if (d->has_lm) {
+      if (upload(d->d_uni, d->lm_ref().unigrams, err)) return -1;
+      if (upload(d->d_ngr, d->lm_ref().ngram_table, err)) return -1;
+      if (upload(d->d_pref, d->lm_ref().prefix_table, err)) return -1;
+    }
+    d->tables_dirty = false;
+    d->hot_dirty = true;
+  }
+  if (d->hot_dirty) {
+    if (d->hot.tok_hot.size() != d->alpha.tok.size()) d->hot.build({}, d->alpha);
+    if (upload(d->d_tok_hot, d->hot.tok_hot, err)) return -1;
+    if (upload(d->d_hot, d->hot.table, err)) return -1;
+    d->hot_dirty = false;
+  }
+  return 0;
+}
+
+static void device_tables(const ctcdec_decoder* d, DeviceTables* t) {
+  memset(t, 0, sizeof(*t));
+  if (d->has_lm) d->lm_ref().tables(t);
+  t->tok = (const TokInfo*)d->d_tok.p;
+  t->tok_hot = (const TokHot*)d->d_tok_hot.p;
+  if (d->has_lm) {
+    t->unigrams = (const UnigramEntry*)d->d_uni.p;
+    t->ngrams = (const NgramEntry*)d->d_ngr.p;
+    t->prefixes = (const PrefixEntry*)d->d_pref.p;
+  } else {
+    t->n_hist = 1;  // lm_order 1 without an LM (decoder.py:551)
+  }
+  t->hot = d->hot.table.empty() ? nullptr : (const HotEntry*)d->d_hot.p;
+  t->hot_mask = d->hot.mask;
+  t->n_labels = (uint32_t)d->alpha.labels.size();
+  t->is_bpe = d->alpha.is_bpe ? 1u : 0u;
+}
+
+extern "C" {
+
+const char* ctcdec_last_error(void) { return g_err.c_str(); }
+const char* ctcdec_version(void) { return "ctcdec 0.1 (gfx950)"; }
+
+int ctcdec_create(const char* labels_blob, const int64_t* labels_off, int32_t n_labels, int32_t is_bpe,
+                  int32_t device, ctcdec_decoder** out) {
+  if (!labels_blob || !labels_off || !out || n_labels <= 0) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  if (n_labels > CTCDEC_MAX_VOCAB) return fail(CTCDEC_ERR_LIMIT, "vocabulary larger than 65535 labels");
+  std::string err;
+  if (be::init(device, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  std::unique_ptr<ctcdec_decoder> d(new ctcdec_decoder());
+  std::vector<std::string> labels;
+  for (int32_t i = 0; i < n_labels; ++i)
+    labels.emplace_back(labels_blob + labels_off[i], (size_t)(labels_off[i + 1] - labels_off[i]));
+  d->alpha.build(labels, is_bpe != 0);
+  d->hot.build({}, d->alpha);
+  *out = d.release();
+  return CTCDEC_OK;
+}
+
+void ctcdec_destroy(ctcdec_decoder* dec) { delete dec; }
+
+int ctcdec_lm_load_arpa(ctcdec_decoder* dec, const char* path, int32_t* order_out) {
+  if (!dec || !path) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  std::string e = dec->lm_ref().load_arpa(path);
+  if (!e.empty()) return fail(CTCDEC_ERR_IO, e);
+  dec->has_lm = true;
+  dec->tables_dirty = true;
+  if (order_out) *order_out = dec->lm_ref().order;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_set_unigrams(ctcdec_decoder* dec, int32_t has_unigrams, const char* blob, const int64_t* off,
+                           int64_t n_unigrams, int64_t* n_kept_out) {
+  if (!dec || !dec->has_lm) return fail(CTCDEC_ERR_ARG, "no language model loaded");
+  std::vector<std::string> uni;
+  if (has_unigrams)
+    for (int64_t i = 0; i < n_unigrams; ++i) uni.emplace_back(blob + off[i], (size_t)(off[i + 1] - off[i]));
+  dec->lm_ref().set_unigrams(has_unigrams != 0, uni);
+  dec->tables_dirty = true;
+  if (n_kept_out) *n_kept_out = (int64_t)dec->lm_ref().uniset_size;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src) {
+  if (!dst || !src || !src->has_lm) return fail(CTCDEC_ERR_ARG, "source has no language model");
+  dst->lm_ptr = src->lm_ptr;
+  dst->has_lm = true;
+  dst->tables_dirty = true;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_prefix_flags(const ctcdec_decoder* dec, const char* s, int64_t len, uint32_t* flags_out) {
+  if (!dec || !dec->has_lm || !flags_out) return fail(CTCDEC_ERR_ARG, "no language model loaded");
+  uint32_t wid = 0, fl = 0;
+  const HostLM& lm = dec->lm_ref();
+  *flags_out = 0;
+  if (len > 0 && prefix_lookup(lm.prefix_table.data(), lm.prefix_mask, hash_bytes(s, (size_t)len), &wid, &fl))
+    *flags_out = fl;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_word_index(const ctcdec_decoder* dec, const char* w, int64_t len, uint32_t* index_out) {
+  if (!dec || !dec->has_lm || !index_out) return fail(CTCDEC_ERR_ARG, "no language model loaded");
+  *index_out = dec->lm_ref().index(std::string(w, (size_t)len));
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_word_string(const ctcdec_decoder* dec, uint32_t index, const char** str_out, int64_t* len_out) {
+  if (!dec || !dec->has_lm || index >= dec->lm_ref().words.size()) return fail(CTCDEC_ERR_ARG, "bad word index");
+  *str_out = dec->lm_ref().words[index].data();
+  *len_out = (int64_t)dec->lm_ref().words[index].size();
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_start_state(const ctcdec_decoder* dec, int32_t begin_sentence, ctcdec_lm_state* out) {
+  if (!dec || !dec->has_lm || !out) return fail(CTCDEC_ERR_ARG, "no language model loaded");
+  LmState st;
+  dec->lm_ref().start_state(begin_sentence != 0, &st);
+  out->length = st.len;
+  for (int k = 0; k < MAX_CTX; ++k) {
+    out->words[k] = st.words[k];
+    out->backoff[k] = st.backoff[k];
+  }
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_base_score(const ctcdec_decoder* dec, const ctcdec_lm_state* in, uint32_t word_index,
+                         ctcdec_lm_state* out, float* log10_prob_out) {
+  if (!dec || !dec->has_lm || !in || !out || !log10_prob_out) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  if (word_index >= dec->lm_ref().words.size() || in->length < 0 || in->length > MAX_CTX)
+    return fail(CTCDEC_ERR_ARG, "bad LM state or word index");
+  DeviceTables t;
+  dec->lm_ref().tables(&t);
+  LmState a, b;
+  a.len = in->length;
+  for (int k = 0; k < MAX_CTX; ++k) {
+    a.words[k] = in->words[k];
+    a.backoff[k] = in->backoff[k];
+  }
+  *log10_prob_out = lm_base_score(t, a, word_index, &b);
+  out->length = b.len;
+  for (int k = 0; k < MAX_CTX; ++k) {
+    out->words[k] = b.words[k];
+    out->backoff[k] = b.backoff[k];
+  }
+  return CTCDEC_OK;
+}
+
+int ctcdec_set_hotwords(ctcdec_decoder* dec, const char* blob, const int64_t* off, int64_t n_words) {
+  if (!dec) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  std::vector<std::string> uni;
+  for (int64_t i = 0; i < n_words; ++i) uni.emplace_back(blob + off[i], (size_t)(off[i + 1] - off[i]));
+  dec->hot.build(uni, dec->alpha);
+  dec->hot_dirty = true;
+  return CTCDEC_OK;
+}
+
+static void replay(const ctcdec_decoder* d, const EmitNode* toks, uint32_t n, BeamResult* r) {
+  std::string cur;
+  auto close_word = [&](int32_t s, int32_t e) {
+    if (cur.empty()) return;
+    if (!r->text.empty()) r->text.push_back(' ');
+    r->word_off.push_back((int32_t)r->text.size());
+    r->text += cur;
+    r->start.push_back(s);
+    r->end.push_back(e);
+    cur.clear();
+  };
+  for (uint32_t k = 0; k < n; ++k) {
+    uint32_t br = toks[k].tok_branch >> 16, tok = toks[k].tok_branch & 0xFFFFu;
+    if (br == BR_BOUNDARY) {
+      close_word(toks[k].wstart, toks[k].wend);
+      cur = d->alpha.clean[tok];
+    } else if (br == BR_SPACE) {
+      close_word(toks[k].wstart, toks[k].wend);
+    } else if (br == BR_APPEND) {
+      cur += d->alpha.labels[tok];
+    } else if (br == BR_FINAL) {
+      close_word(toks[k].wstart, toks[k].wend);
+    }
+  }
+  r->word_off.push_back((int32_t)r->text.size());
+}
+
+int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames,
+                        int32_t n_utts, int32_t dtype, int32_t is_device, const ctcdec_params* p,
+                        const ctcdec_lm_state* start_states, ctcdec_result** out) {
+  if (!dec || !p || !out || n_utts < 0 || (n_utts > 0 && (!utt_logits || !utt_frames)))
+    return fail(CTCDEC_ERR_ARG, "bad arguments");
+  if (dtype != CTCDEC_F32 && dtype != CTCDEC_F64) return fail(CTCDEC_ERR_ARG, "dtype must be f32 or f64");
+  if (p->beam_width < 1) return fail(CTCDEC_ERR_ARG, "beam_width must be >= 1");
+  if (p->beam_width > CTCDEC_MAX_BEAM_WIDTH)
+    return fail(CTCDEC_ERR_LIMIT, "beam_width above the supported maximum of 256");
+  std::string err;
+  auto t_begin = std::chrono::steady_clock::now();
+  std::unique_ptr<ctcdec_result> res(new ctcdec_result());
+  res->utts.resize((size_t)n_utts);
+  if (n_utts == 0) {
+    *out = res.release();
+    return CTCDEC_OK;
+  }
+  if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  const int V = (int)dec->alpha.labels.size();
+  const size_t esz = dtype == CTCDEC_F32 ? 4 : 8;
+
+  std::vector<int64_t> row0((size_t)n_utts + 1, 0);
+  for (int32_t u = 0; u < n_utts; ++u) {
+    if (utt_frames[u] < 0) return fail(CTCDEC_ERR_ARG, "negative frame count");
+    row0[(size_t)u + 1] = row0[(size_t)u] + utt_frames[u];
+  }
+  const int64_t R = row0[(size_t)n_utts];
+
+  // logits: device pointers are used in place, host matrices are staged
+  std::vector<const void*> ptrs((size_t)n_utts);
+  if (is_device) {
+    for (int32_t u = 0; u < n_utts; ++u) ptrs[(size_t)u] = utt_logits[u];
+  } else {
+    if (dec->w_logits.ensure((size_t)std::max<int64_t>(R, 1) * V * esz, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    for (int32_t u = 0; u < n_utts; ++u) {
+      char* dst = (char*)dec->w_logits.p + (size_t)row0[(size_t)u] * V * esz;
+      size_t bytes = (size_t)utt_frames[u] * V * esz;
+      if (bytes && be::h2d(dst, utt_logits[u], bytes, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      ptrs[(size_t)u] = dst;
+    }
+  }
+  if (upload(dec->w_ptrs, ptrs, &err) || upload(dec->w_row0, row0, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+
+  // survivor bound: rows are normalised log-probabilities, so at most floor(e^-min) labels pass
+  int max_surv = V;
+  if (p->token_min_logp > log(1e-15)) {  // frames are clipped at ln(MIN_TOKEN_CLIP_P) (constants.py:17)
+    double bound = floor(exp(-p->token_min_logp)) + 2.0;
+    if (bound < (double)V) max_surv = (int)bound;
+  }
+  if (max_surv < 1) max_surv = 1;
+
+  const int B = p->beam_width;
+
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    size_t rows = (size_t)std::max<int64_t>(R, 1);
+    if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
+        dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
+        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    if (be::zero(dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    be::PruneArgs pa;
+    pa.utt_logits = (const void* const*)dec->w_ptrs.p;
+    pa.utt_row0 = (const int64_t*)dec->w_row0.p;
+    pa.n_utts = n_utts;
+    pa.n_rows = R;
+    pa.n_labels = V;
+    pa.dtype = dtype;
+    pa.token_min_logp = p->token_min_logp;
+    pa.max_surv = max_surv;
+    pa.row_sum = (double*)dec->w_rowsum.p;
+    pa.utt_is_prob = (uint32_t*)dec->w_isprob.p;
+    pa.surv_cnt = (uint32_t*)dec->w_scnt.p;
+    pa.surv_id = (uint16_t*)dec->w_sid.p;
+    pa.surv_lp = (double*)dec->w_slp.p;
+    pa.overflow = (uint32_t*)dec->w_flags.p;
+    if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    uint32_t ovf = 0;
+    if (be::d2h(&ovf, dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    if (!ovf) break;
+    if (max_surv == V) return fail(CTCDEC_ERR_INTERNAL, "survivor overflow at full vocabulary");
+    max_surv = V;  // un-normalised probability rows can exceed the bound: redo at full width
+  }
+
+  // arenas
+  std::vector<uint64_t> toff((size_t)n_utts + 1, 0), eoff((size_t)n_utts + 1, 0);
+  for (int32_t u = 0; u < n_utts; ++u) {
+    uint64_t T = (uint64_t)utt_frames[u];
+    toff[(size_t)u + 1] = toff[(size_t)u] + (T + 1) * (uint64_t)B + 2;
+    eoff[(size_t)u + 1] = eoff[(size_t)u] + T * (uint64_t)B + 2;
+  }
+  int n_best = p->n_best > 0 ? std::min(p->n_best, B) : B;
+  unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + n_utts);
+  if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
+      dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_toff, toff, &err) ||
+      upload(dec->w_eoff, eoff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
+      dec->w_nout.ensure((size_t)n_utts * 4, &err) || dec->w_status.ensure((size_t)n_utts * 4, &err) ||
+      dec->w_tok.ensure((size_t)std::max<unsigned long long>(tok_cap, 1) * sizeof(EmitNode), &err) ||
+      dec->w_head.ensure(16, &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  if (be::zero(dec->w_head.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  const LmState* d_start = nullptr;
+  if (start_states && dec->has_lm) {
+    std::vector<LmState> st((size_t)n_utts);
+    for (int32_t u = 0; u < n_utts; ++u) {
+      LmState& s = st[(size_t)u];
+      memset(&s, 0, sizeof(s));
+      if (start_states[u].length < 0) {
+        dec->lm_ref().start_state(p->lm_score_boundary != 0, &s);
+      } else {
+        if (start_states[u].length > MAX_CTX) return fail(CTCDEC_ERR_ARG, "LM start state too long");
+        s.len = start_states[u].length;
+        for (int k = 0; k < s.len; ++k) {
+          if (start_states[u].words[k] >= dec->lm_ref().words.size()) return fail(CTCDEC_ERR_ARG, "bad LM state word");
+          s.words[k] = start_states[u].words[k];
+          s.backoff[k] = start_states[u].backoff[k];
+        }
+      }
+    }
+    if (upload(dec->w_start, st, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    d_start = (const LmState*)dec->w_start.p;
+  } else if (dec->has_lm) {
+    std::vector<LmState> st((size_t)n_utts);
+    LmState s0;
+    dec->lm_ref().start_state(p->lm_score_boundary != 0, &s0);
+    for (auto& s : st) s = s0;
+    if (upload(dec->w_start, st, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    d_start = (const LmState*)dec->w_start.p;
+  }
+
+  be::BeamArgs ba;
+  device_tables(dec, &ba.tables);
+  DecodeParams& dp = ba.params;
+  memset(&dp, 0, sizeof(dp));
+  dp.beam_width = B;
+  dp.prune_history = p->prune_history ? 1 : 0;
+  dp.n_best = n_best;
+  dp.first_frame = p->first_frame;
+  dp.beam_prune_logp = p->beam_prune_logp;
+  dp.token_min_logp = p->token_min_logp;
+  dp.hot_weight = p->hotword_weight;
+  dp.alpha = p->alpha;
+  dp.beta = p->beta;
+  dp.unk = p->unk_score_offset;
+  dp.log_base_change = p->log_base_change;
+  dp.score_boundary = p->lm_score_boundary ? 1 : 0;
+  dp.max_surv = max_surv;
+  ba.n_utts = n_utts;
+  ba.utt_row0 = (const int64_t*)dec->w_row0.p;
+  ba.surv_cnt = (const uint32_t*)dec->w_scnt.p;
+  ba.surv_id = (const uint16_t*)dec->w_sid.p;
+  ba.surv_lp = (const double*)dec->w_slp.p;
+  ba.text_nodes = (TextNode*)dec->w_text.p;
+  ba.emit_nodes = (EmitNode*)dec->w_emit.p;
+  ba.text_off = (const uint64_t*)dec->w_toff.p;
+  ba.emit_off = (const uint64_t*)dec->w_eoff.p;
+  ba.start_states = d_start;
+  ba.out = (OutBeam*)dec->w_out.p;
+  ba.out_stride = n_best;
+  ba.n_out = (uint32_t*)dec->w_nout.p;
+  ba.status = (uint32_t*)dec->w_status.p;
+  ba.tok_pool = (EmitNode*)dec->w_tok.p;
+  ba.tok_pool_head = (unsigned long long*)dec->w_head.p;
+  ba.tok_pool_cap = tok_cap;
+  if (be::launch_beam(ba, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+
+  // results back
+  std::vector<uint32_t> n_out((size_t)n_utts), status((size_t)n_utts);
+  std::vector<OutBeam> obs((size_t)n_utts * n_best);
+  unsigned long long head = 0;
+  if (be::d2h(n_out.data(), dec->w_nout.p, (size_t)n_utts * 4, &err) ||
+      be::d2h(status.data(), dec->w_status.p, (size_t)n_utts * 4, &err) ||
+      be::d2h(&head, dec->w_head.p, 8, &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  for (int32_t u = 0; u < n_utts; ++u)
+    if (status[(size_t)u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[(size_t)u]) +
+                                                                  " for utterance " + std::to_string(u));
+  if (be::d2h(obs.data(), dec->w_out.p, obs.size() * sizeof(OutBeam), &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  std::vector<EmitNode> toks((size_t)head);
+  if (head && be::d2h(toks.data(), dec->w_tok.p, (size_t)head * sizeof(EmitNode), &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  be::last_timing(&res->ms[0], &res->ms[1]);
+
+  for (int32_t u = 0; u < n_utts; ++u) {
+    auto& beams = res->utts[(size_t)u];
+    beams.resize(n_out[(size_t)u]);
+    for (uint32_t k = 0; k < n_out[(size_t)u]; ++k) {
+      const OutBeam& ob = obs[(size_t)u * n_best + k];
+      BeamResult& r = beams[k];
+      r.logit = ob.logit_score;
+      r.lm = ob.lm_score;
+      r.state.length = ob.state.len;
+      for (int j = 0; j < MAX_CTX; ++j) {
+        r.state.words[j] = ob.state.words[j];
+        r.state.backoff[j] = ob.state.backoff[j];
+      }
+      if ((unsigned long long)ob.tok_off + ob.tok_cnt > head) return fail(CTCDEC_ERR_INTERNAL, "token pool range");
+      replay(dec, toks.data() + ob.tok_off, ob.tok_cnt, &r);
+    }
+  }
+  res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  *out = res.release();
+  return CTCDEC_OK;
+}
+
+int32_t ctcdec_result_num_utts(const ctcdec_result* r) { return r ? (int32_t)r->utts.size() : 0; }
+int32_t ctcdec_result_num_beams(const ctcdec_result* r, int32_t utt) {
+  if (!r || utt < 0 || (size_t)utt >= r->utts.size()) return 0;
+  return (int32_t)r->utts[(size_t)utt].size();
+}
+static const BeamResult* get_beam(const ctcdec_result* r, int32_t utt, int32_t beam) {
+  if (!r || utt < 0 || (size_t)utt >= r->utts.size()) return nullptr;
+  const auto& b = r->utts[(size_t)utt];
+  if (beam < 0 || (size_t)beam >= b.size()) return nullptr;
+  return &b[(size_t)beam];
+}
+int ctcdec_result_text(const ctcdec_result* r, int32_t utt, int32_t beam, const char** s, int64_t* len) {
+  const BeamResult* b = get_beam(r, utt, beam);
+  if (!b) return fail(CTCDEC_ERR_ARG, "no such beam");
+  *s = b->text.data();
+  *len = (int64_t)b->text.size();
+  return CTCDEC_OK;
+}
+int ctcdec_result_scores(const ctcdec_result* r, int32_t utt, int32_t beam, double* logit, double* lm) {
+  const BeamResult* b = get_beam(r, utt, beam);
+  if (!b) return fail(CTCDEC_ERR_ARG, "no such beam");
+  *logit = b->logit;
+  *lm = b->lm;
+  return CTCDEC_OK;
+}
+int ctcdec_result_frames(const ctcdec_result* r, int32_t utt, int32_t beam, int32_t* n_words,
+                         const int32_t** word_off, const int32_t** start, const int32_t** end) {
+  const BeamResult* b = get_beam(r, utt, beam);
+  if (!b) return fail(CTCDEC_ERR_ARG, "no such beam");
+  *n_words = (int32_t)b->start.size();
+  *word_off = b->word_off.data();
+  *start = b->start.data();
+  *end = b->end.data();
+  return CTCDEC_OK;
+}
+int ctcdec_result_lm_state(const ctcdec_result* r, int32_t utt, int32_t beam, ctcdec_lm_state* out) {
+  const BeamResult* b = get_beam(r, utt, beam);
+  if (!b) return fail(CTCDEC_ERR_ARG, "no such beam");
+  *out = b->state;
+  return CTCDEC_OK;
+}
+int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {
+  if (!r || !out) return fail(CTCDEC_ERR_ARG, "no result");
+  if (!r->packed) {
+    r->beam_off.assign(1, 0);
+    r->text_off.assign(1, 0);
+    r->word_cnt_off.assign(1, 0);
+    for (const auto& beams : r->utts) {
+      for (const BeamResult& b : beams) {
+        r->text_blob += b.text;
+        r->text_off.push_back((int64_t)r->text_blob.size());
+        r->logit.push_back(b.logit);
+        r->lm.push_back(b.lm);
+        r->states.push_back(b.state);
+        for (size_t k = 0; k < b.start.size(); ++k) {
+          r->word_byte_off.push_back(b.word_off[k]);
+          r->word_start.push_back(b.start[k]);
+          r->word_end.push_back(b.end[k]);
+        }
+        r->word_cnt_off.push_back((int64_t)r->word_start.size());
+      }
+      r->beam_off.push_back((int64_t)r->logit.size());
+    }
+    r->packed = true;
+  }
+  out->n_utts = (int64_t)r->utts.size();
+  out->n_beams = (int64_t)r->logit.size();
+  out->n_words = (int64_t)r->word_start.size();
+  out->beam_off = r->beam_off.data();
+  out->text_blob = r->text_blob.data();
+  out->text_off = r->text_off.data();
+  out->logit_score = r->logit.data();
+  out->lm_score = r->lm.data();
+  out->word_cnt_off = r->word_cnt_off.data();
+  out->word_byte_off = r->word_byte_off.data();
+  out->word_start = r->word_start.data();
+  out->word_end = r->word_end.data();
+  out->lm_state = r->states.data();
+  return CTCDEC_OK;
+}
+
+int ctcdec_result_timing(const ctcdec_result* r, double* ms3) {
+  if (!r) return fail(CTCDEC_ERR_ARG, "no result");
+  ms3[0] = r->ms[0];
+  ms3[1] = r->ms[1];
+  ms3[2] = r->ms[2];
+  return CTCDEC_OK;
+}
+void ctcdec_result_free(ctcdec_result* r) { delete r; }
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// backend.h -- the narrow device interface api.cpp is written against.
+//   * pyctcdecode_amd/csrc/backend_hip.hip : the product (MI355X / gfx950 HIP kernels)
+//   * tests/sim/backend_sim.cpp            : sequential CPU execution of the same beam_core.h,
+//                                            test infrastructure only (never built into the product)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "common.h"
+
+namespace ctc {
+namespace be {
+
+const char* name();
+int init(int device, std::string* err);
+void* alloc(size_t bytes, std::string* err);
+void release(void* p);
+int h2d(void* dst, const void* src, size_t bytes, std::string* err);
+int d2h(void* dst, const void* src, size_t bytes, std::string* err);
+int zero(void* dst, size_t bytes, std::string* err);
+int sync(std::string* err);
+
+// Frame-prune stage: input normalisation (decoder.py:759-765), token prune (decoder.py:444-445)
+// and CPython-set ordering of the survivors, for every frame of every utterance.
+struct PruneArgs {
+  const void* const* utt_logits;  // [n_utts] device pointers to [T_u, V] matrices
+  const int64_t* utt_row0;        // [n_utts + 1] prefix sums of T_u (device)
+  int32_t n_utts;
+  int64_t n_rows;
+  int32_t n_labels;
+  int32_t dtype;  // ctcdec_dtype
+  double token_min_logp;
+  int32_t max_surv;
+  double* row_sum;       // [n_rows] scratch
+  uint32_t* utt_is_prob; // [n_utts] out: 1 when the input looks like probabilities
+  uint32_t* surv_cnt;    // [n_rows]
+  uint16_t* surv_id;     // [n_rows * max_surv]
+  double* surv_lp;       // [n_rows * max_surv]
+  uint32_t* overflow;    // [1] set when a row had more than max_surv survivors
+};
+int launch_prune(const PruneArgs& a, std::string* err);
+
+// Beam stage: one workgroup per utterance.
+struct BeamArgs {
+  DeviceTables tables;  // device pointers
+  DecodeParams params;
+  int32_t n_utts;
+  const int64_t* utt_row0;   // [n_utts + 1] (device)
+  const uint32_t* surv_cnt;
+  const uint16_t* surv_id;
+  const double* surv_lp;
+  TextNode* text_nodes;      // arena for all utterances
+  EmitNode* emit_nodes;
+  const uint64_t* text_off;  // [n_utts + 1] node offsets (device)
+  const uint64_t* emit_off;  // [n_utts + 1]
+  const LmState* start_states;  // [n_utts] or nullptr
+  OutBeam* out;                 // [n_utts * out_stride]
+  int32_t out_stride;
+  uint32_t* n_out;              // [n_utts]
+  uint32_t* status;             // [n_utts]
+  EmitNode* tok_pool;
+  unsigned long long* tok_pool_head;  // [1]
+  unsigned long long tok_pool_cap;
+};
+int launch_beam(const BeamArgs& a, std::string* err);
+
+// stage timing (ms) of the last launch_prune / launch_beam pair, measured on the decode stream
+void last_timing(double* prune_ms, double* beam_ms);
+
+}  // namespace be
+}  // namespace ctc

@@ -1,0 +1,950 @@
+// beam_core.h -- the per-utterance CTC prefix-beam recursion (reference:
+// BeamSearchDecoderCTC._partial_decode_logits decoder.py:426-556, _finalize_beams :558-602,
+// _get_lm_beams :346-424, _merge_beams :211-224, _prune_history :227-258).
+//
+// One workgroup owns one utterance and walks its frames in order; everything a frame needs
+// (live beam table, candidate keys, merge table, candidate pool, sort buffer) lives in LDS.
+// Global memory holds only the read-only scorer tables, the per-frame survivor lists written by
+// the frame-prune kernel, and two append-only arenas (TextNode, EmitNode).
+//
+// The code is written against an execution context `Ctx` {tid, nt, sync(), LDS atomics} so the
+// same source runs as a HIP workgroup (kernels.hip) and as a 1-thread sequential simulation
+// (tests/sim, test infrastructure only -- the product never runs it).
+#pragma once
+#include <math.h>
+#include "common.h"
+
+namespace ctc {
+
+constexpr uint32_t NO_CHAR = 0xFFFFu;
+constexpr uint32_t M2_HOT_ON = 16u;        // partial is a prefix of a hot word
+constexpr uint32_t M2_HOT_COMPLETE = 32u;  // partial is itself a hot word
+constexpr uint32_t EMPTY_PARTIAL_M2 = PF_ON_TABLE | M2_HOT_ON;
+
+enum : uint32_t { MODE_A = 0, MODE_ALL_B = 1, MODE_FIRST_B = 2, MODE_C = 3, MODE_D = 4 };
+enum : uint32_t { ST_TEXT_OVERFLOW = 1u, ST_EMIT_OVERFLOW = 2u, ST_POOL_OVERFLOW = 4u, ST_TOK_OVERFLOW = 8u };
+
+struct BeamSoA {
+  double *logit, *lm_hw, *pscore, *c_lm_hw;
+  uint64_t *text_h, *part_h, *hist_h, *c_text_h, *c_hist_h;
+  uint32_t *text_node, *comp_node, *emit_node, *word_id, *meta1, *meta2, *depth;
+  int32_t *pstart, *pend;
+};
+
+// sizes that shape the LDS carve-up (host computes the same numbers for the launch)
+struct LdsShape {
+  int bw;    // beam capacity (beam_width rounded up to 8)
+  int cand;  // candidates per chunk
+  int pool;  // pool capacity
+  int surv;  // survivors per frame capacity
+};
+
+CTC_HD size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// LDS shape for a beam width and survivor bound (same numbers on host and device)
+inline LdsShape make_shape(int beam_width, int max_surv) {
+  LdsShape s;
+  s.bw = (beam_width + 7) & ~7;
+  s.cand = 512;
+  while (s.cand < 2 * s.bw) s.cand <<= 1;
+  s.pool = 2 * s.cand;
+  s.surv = (max_surv + 3) & ~3;
+  return s;
+}
+
+struct LdsView {
+  BeamSoA beams[2];
+  // survivors of the current frame
+  uint32_t* sid;
+  double* slp;
+  uint32_t* smode;   // MODE_* | first_non_repeat << 8
+  // candidates of the current chunk
+  uint64_t *ck_text, *ck_part;
+  double* c_logit;
+  uint32_t *crep, *rmin, *rmax, *rcnt;
+  uint32_t* table;  // 2*cand slots, stores q+1
+  // pool of merged, scored candidates of the current frame
+  double *p_score, *p_logit;
+  uint32_t *p_arr, *p_don;
+  // sort buffer (aliases the candidate arrays)
+  uint64_t *s_k0, *s_k1;
+  // scalars
+  uint32_t* scal;  // [0] pool_n [1] text_next [2] emit_next [3] flag [4] need_comp [5] n_sel [6] status [7] n_new
+  uint64_t* smax;  // sortable max score
+  uint32_t* keep;  // per selected beam: kept by history prune
+  uint64_t *hk_h, *hk_p;  // history-prune keys of the selected beams
+  uint32_t* hk_c;
+  // gather temp used when the pool is compacted (aliases the tail of the candidate arrays)
+  double *g_score, *g_logit;
+  uint32_t *g_arr, *g_don;
+};
+
+template <class F>
+CTC_HD void carve_beams(BeamSoA& b, char*& p, int bw, F&& take) {
+  b.logit = (double*)take(p, 8 * bw);
+  b.lm_hw = (double*)take(p, 8 * bw);
+  b.pscore = (double*)take(p, 8 * bw);
+  b.c_lm_hw = (double*)take(p, 8 * bw);
+  b.text_h = (uint64_t*)take(p, 8 * bw);
+  b.part_h = (uint64_t*)take(p, 8 * bw);
+  b.hist_h = (uint64_t*)take(p, 8 * bw);
+  b.c_text_h = (uint64_t*)take(p, 8 * bw);
+  b.c_hist_h = (uint64_t*)take(p, 8 * bw);
+  b.text_node = (uint32_t*)take(p, 4 * bw);
+  b.comp_node = (uint32_t*)take(p, 4 * bw);
+  b.emit_node = (uint32_t*)take(p, 4 * bw);
+  b.word_id = (uint32_t*)take(p, 4 * bw);
+  b.meta1 = (uint32_t*)take(p, 4 * bw);
+  b.meta2 = (uint32_t*)take(p, 4 * bw);
+  b.depth = (uint32_t*)take(p, 4 * bw);
+  b.pstart = (int32_t*)take(p, 4 * bw);
+  b.pend = (int32_t*)take(p, 4 * bw);
+}
+
+// Carves `base` into the view; returns bytes used. With base == nullptr it only measures.
+CTC_HD size_t lds_carve(LdsView* v, char* base, const LdsShape& s) {
+  char* p = base;
+  auto take = [](char*& q, size_t bytes) {
+    char* r = q;
+    q += align16(bytes);
+    return r;
+  };
+  LdsView tmp;
+  LdsView& o = v ? *v : tmp;
+  carve_beams(o.beams[0], p, s.bw, take);
+  carve_beams(o.beams[1], p, s.bw, take);
+  o.sid = (uint32_t*)take(p, 4 * s.surv);
+  o.slp = (double*)take(p, 8 * s.surv);
+  o.smode = (uint32_t*)take(p, 4 * s.surv);
+  o.p_score = (double*)take(p, 8 * s.pool);
+  o.p_logit = (double*)take(p, 8 * s.pool);
+  o.p_arr = (uint32_t*)take(p, 4 * s.pool);
+  o.p_don = (uint32_t*)take(p, 4 * s.pool);
+  o.scal = (uint32_t*)take(p, 4 * 16);
+  o.smax = (uint64_t*)take(p, 8 * 2);
+  o.keep = (uint32_t*)take(p, 4 * s.bw);
+  o.hk_h = (uint64_t*)take(p, 8 * s.bw);
+  o.hk_p = (uint64_t*)take(p, 8 * s.bw);
+  o.hk_c = (uint32_t*)take(p, 4 * s.bw);
+  // candidate arrays and the sort buffer share one region
+  char* shared0 = p;
+  o.ck_text = (uint64_t*)take(p, 8 * s.cand);
+  o.ck_part = (uint64_t*)take(p, 8 * s.cand);
+  o.c_logit = (double*)take(p, 8 * s.cand);
+  o.crep = (uint32_t*)take(p, 4 * s.cand);
+  o.rmin = (uint32_t*)take(p, 4 * s.cand);
+  o.rmax = (uint32_t*)take(p, 4 * s.cand);
+  o.rcnt = (uint32_t*)take(p, 4 * s.cand);
+  o.table = (uint32_t*)take(p, 4 * 2 * s.cand);
+  char* q = shared0;
+  o.s_k0 = (uint64_t*)take(q, 8 * s.pool);
+  o.s_k1 = (uint64_t*)take(q, 8 * s.pool);
+  o.g_score = (double*)take(q, 8 * s.bw);
+  o.g_logit = (double*)take(q, 8 * s.bw);
+  o.g_arr = (uint32_t*)take(q, 4 * s.bw);
+  o.g_don = (uint32_t*)take(q, 4 * s.bw);
+  if (q > p) p = q;
+  return (size_t)(p - base);
+}
+
+// per-utterance global-memory view
+struct UttIO {
+  const uint32_t* surv_cnt;  // [T]
+  const uint16_t* surv_id;   // [T * max_surv]   CPython-set order
+  const double* surv_lp;     // [T * max_surv]
+  int32_t T;
+  TextNode* text_nodes;
+  uint32_t text_cap;
+  EmitNode* emit_nodes;
+  uint32_t emit_cap;
+  const LmState* start_state;  // nullptr: LM default
+  OutBeam* out;                // [beam_width]
+  uint32_t* n_out;
+  uint32_t* status;
+  EmitNode* tok_pool;          // global pool of back-traced emission lists
+  unsigned long long* tok_pool_head;
+  unsigned long long tok_pool_cap;
+};
+
+// ---------------------------------------------------------------------------------------------
+CTC_HD uint64_t score_sort_key(double s) {
+  // ascending key order == descending score order; -0.0 and +0.0 compare equal like in Python
+  if (s == 0.0) s = 0.0;
+  union { double d; uint64_t u; } c;
+  c.d = s;
+  uint64_t asc = (c.u >> 63) ? ~c.u : (c.u | (1ull << 63));
+  return ~asc;
+}
+
+CTC_HD double lse2(double a, double b) {  // decoder.py:170-177
+  if (a >= b) return a + log(1.0 + exp(b - a));
+  return b + log(1.0 + exp(a - b));
+}
+
+CTC_HD uint64_t hist_hash(const uint64_t* ring, uint32_t cnt) {
+  uint64_t h = 0x9E3779B97F4A7C15ull + cnt;
+  for (uint32_t k = cnt; k-- > 0;) h = mix64(h ^ ring[k]) + 0x632BE59BD9B4E019ull;
+  return h;
+}
+
+// language_model.py:141-150 (hot word) / :326-336 (unigram trie) / decoder.py:363-367,397-409
+CTC_HD double partial_score(const DeviceTables& t, const DecodeParams& prm, uint32_t pf_flags,
+                            uint32_t hot_min_len, uint32_t plen) {
+  if (hot_min_len > 0) return prm.hot_weight * (double)plen / (double)hot_min_len;
+  if (!t.has_lm) return 0.0;
+  bool on_trie = t.has_trie && (pf_flags & PF_UNI_PREFIX);
+  double s = prm.unk * (on_trie ? 0.0 : 1.0);
+  if (plen > 6) s = s * (double)plen / 6.0;
+  return s;
+}
+
+CTC_HD double total_score(const DeviceTables& t, double logit, double lm_hw, double ps, uint32_t plen) {
+  if (!t.has_lm) return logit + lm_hw + ps;  // decoder.py:363-367
+  double s = lm_hw;
+  if (plen > 0) s = s + ps;  // decoder.py:398-409
+  return logit + s;          // decoder.py:420
+}
+
+// language_model.py:338-360 without the EOS term
+CTC_HD double lm_word_score(const DeviceTables& t, const DecodeParams& prm, float base, uint32_t wflags,
+                            double end_score, bool eos) {
+  double lm = (double)base;
+  bool oov = (t.uniset_nonempty && !(wflags & PF_UNI_WORD)) || !(wflags & PF_LM_WORD);
+  if (oov) lm += prm.unk;
+  if (eos) lm = lm + end_score;
+  return prm.alpha * lm * prm.log_base_change + prm.beta;
+}
+
+template <class Ctx>
+struct BeamDecoder {
+  Ctx& ctx;
+  LdsView& L;
+  const LdsShape& shape;
+  const DeviceTables& tab;
+  const DecodeParams& prm;
+  const UttIO& io;
+  int cur;  // live beam buffer
+  int N;    // live beams
+
+  CTC_HD BeamDecoder(Ctx& c, LdsView& l, const LdsShape& s, const DeviceTables& t, const DecodeParams& p,
+                     const UttIO& i)
+      : ctx(c), L(l), shape(s), tab(t), prm(p), io(i), cur(0), N(1) {}
+
+  CTC_HD uint32_t last_char(const BeamSoA& b, int i) const { return b.meta1[i] & 0xFFFFu; }
+  CTC_HD uint32_t plen(const BeamSoA& b, int i) const { return b.meta1[i] >> 16; }
+
+  // ---- completion of beam i's open word: the (text (+) partial) prefix ----------------------
+  CTC_HD void make_completion(BeamSoA& b, int i) {
+    uint32_t idx = ctx.atomic_add(&L.scal[1], 1u);
+    if (idx >= io.text_cap) {
+      ctx.atomic_or(&L.scal[6], ST_TEXT_OVERFLOW);
+      idx = io.text_cap - 1;
+    }
+    const TextNode& src = io.text_nodes[b.text_node[i]];
+    TextNode nn;
+    uint32_t m2 = b.meta2[i];
+    double raw = src.raw_lm;
+    if (tab.has_lm) {
+      float base = lm_base_score(tab, src.state, b.word_id[i], &nn.state);
+      raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
+    } else {
+      nn.state = src.state;
+    }
+    uint64_t wh = b.part_h[i];
+    nn.text_h = text_push(src.text_h, wh);
+    nn.raw_lm = raw;
+    nn.hw_cnt = src.hw_cnt + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
+    nn.lm_hw = raw + prm.hot_weight * (double)nn.hw_cnt;
+    uint32_t rc = src.ring_cnt + 1 > tab.n_hist ? tab.n_hist : src.ring_cnt + 1;
+    nn.ring_cnt = rc;
+    nn.ring[0] = wh;
+    for (int k = 1; k < MAX_CTX; ++k) nn.ring[k] = (uint32_t)k < rc ? src.ring[k - 1] : 0;
+    nn.hist_h = hist_hash(nn.ring, rc);
+    nn.pad0 = 0;
+    io.text_nodes[idx] = nn;
+    b.comp_node[i] = idx;
+    b.c_text_h[i] = nn.text_h;
+    b.c_lm_hw[i] = nn.lm_hw;
+    b.c_hist_h[i] = nn.hist_h;
+  }
+
+  // ---- branch of candidate (survivor s, beam i): decoder.py:452,474,500,518 -----------------
+  CTC_HD uint32_t branch_of(const BeamSoA& b, uint32_t tflags, uint32_t mode_word, uint32_t c, int i) const {
+    if ((tflags & TK_BLANK) || last_char(b, i) == c) return 0;  // keep prefix (blank / repeat)
+    uint32_t mode = mode_word & 0xFFu;
+    if (mode == MODE_ALL_B) return BR_BOUNDARY;
+    if (mode == MODE_FIRST_B) return (uint32_t)i == (mode_word >> 8) ? BR_BOUNDARY : BR_APPEND;
+    if (mode == MODE_C) return BR_SPACE;
+    return BR_APPEND;
+  }
+
+  // ---- one frame ---------------------------------------------------------------------------
+  CTC_HD void load_survivors(int t) {
+    uint32_t ns = io.surv_cnt[t];
+    const uint16_t* ids = io.surv_id + (size_t)t * prm.max_surv;
+    const double* lps = io.surv_lp + (size_t)t * prm.max_surv;
+    for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
+      L.sid[s] = ids[s];
+      L.slp[s] = lps[s];
+    }
+  }
+
+  CTC_HD void compute_modes(uint32_t ns) {
+    BeamSoA& b = L.beams[cur];
+    // first beam that does not repeat the label (only BPE needs it)
+    for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
+      uint32_t c = L.sid[s];
+      uint32_t fl = tab.tok[c].flags;
+      uint32_t first = (uint32_t)N;
+      uint32_t mode;
+      if (fl & TK_BLANK) {
+        mode = MODE_A;
+      } else if (!tab.is_bpe) {
+        mode = (fl & TK_SPACE) ? MODE_C : MODE_D;
+        if (mode == MODE_C) ctx.atomic_or(&L.scal[4], 1u);
+      } else {
+        int i = 0;
+        while (i < N && last_char(b, i) == c) ++i;
+        first = (uint32_t)i;
+        mode = MODE_D;  // resolved below
+      }
+      L.smode[s] = mode | (first << 8);
+    }
+    ctx.sync();
+    if (tab.is_bpe && ctx.tid == 0) {
+      uint32_t f = L.scal[3];
+      uint32_t need = 0;
+      for (uint32_t s = 0; s < ns; ++s) {
+        uint32_t fl = tab.tok[L.sid[s]].flags;
+        if (fl & TK_BLANK) continue;
+        uint32_t first = L.smode[s] >> 8;
+        bool any = first < (uint32_t)N;
+        uint32_t mode = MODE_D;
+        if (fl & TK_LEAD) {
+          mode = MODE_ALL_B;
+          if (any) f = (fl & TK_TRAIL) ? 1u : 0u;
+        } else if (f && any) {
+          if (fl & TK_TRAIL) {
+            mode = MODE_ALL_B;
+            f = 1u;
+          } else {
+            mode = MODE_FIRST_B;
+            f = 0u;
+          }
+        }
+        if (mode != MODE_D && any) need = 1;
+        L.smode[s] = mode | (first << 8);
+      }
+      L.scal[3] = f;
+      if (need) L.scal[4] = 1u;
+    }
+    ctx.sync();
+  }
+
+  // push one merged+scored candidate into the pool
+  CTC_HD void pool_push(double score, double logit, uint32_t arrival, uint32_t donor) {
+    uint32_t k = ctx.atomic_add(&L.scal[0], 1u);
+    if (k >= (uint32_t)shape.pool) {
+      ctx.atomic_or(&L.scal[6], ST_POOL_OVERFLOW);
+      return;
+    }
+    L.p_score[k] = score;
+    L.p_logit[k] = logit;
+    L.p_arr[k] = arrival;
+    L.p_don[k] = donor;
+  }
+
+  CTC_HD void clear_table() {
+    for (int k = ctx.tid; k < 2 * shape.cand; k += ctx.nt) L.table[k] = 0;
+  }
+
+  // insert candidate q (keys already in ck_*); candidates of one label occupy `group` consecutive
+  // indices and only merge with each other (the key contains last_char). Returns the representative.
+  CTC_HD uint32_t table_insert(uint32_t q, uint32_t group) {
+    uint32_t mask = (uint32_t)(2 * shape.cand - 1);
+    uint64_t kt = L.ck_text[q], kp = L.ck_part[q];
+    uint32_t g = q / group;
+    uint32_t slot = key_slot_hash(kt, kp, g) & mask;
+    for (;;) {
+      uint32_t old = ctx.atomic_cas(&L.table[slot], 0u, q + 1);
+      if (old == 0) return q;
+      uint32_t r = old - 1;
+      if (L.ck_text[r] == kt && L.ck_part[r] == kp && r / group == g) return r;
+      slot = (slot + 1) & mask;
+    }
+  }
+
+  // Sort pool entries with score >= thr by (score desc, arrival asc); result: s_k1 low 32 bits =
+  // pool index in order. Returns count (<= pool_n). Bitonic network over a power of two.
+  CTC_HD uint32_t sort_pool(uint32_t pool_n, double thr) {
+    uint32_t p2 = 1;
+    while (p2 < pool_n) p2 <<= 1;
+    for (uint32_t k = ctx.tid; k < p2; k += ctx.nt) {
+      bool live = k < pool_n && L.p_score[k] >= thr;
+      L.s_k0[k] = live ? score_sort_key(L.p_score[k]) : ~0ull;
+      L.s_k1[k] = live ? (((uint64_t)L.p_arr[k] << 32) | k) : ~0ull;
+    }
+    ctx.sync();
+    for (uint32_t size = 2; size <= p2; size <<= 1) {
+      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+        for (uint32_t k = ctx.tid; k < (p2 >> 1); k += ctx.nt) {
+          uint32_t lo = ((k / stride) * stride * 2) + (k % stride);
+          uint32_t hi = lo + stride;
+          bool up = ((lo & size) == 0);
+          uint64_t a0 = L.s_k0[lo], a1 = L.s_k1[lo], b0 = L.s_k0[hi], b1 = L.s_k1[hi];
+          bool a_gt_b = (a0 > b0) || (a0 == b0 && a1 > b1);
+          if (a_gt_b == up) {
+            L.s_k0[lo] = b0;
+            L.s_k1[lo] = b1;
+            L.s_k0[hi] = a0;
+            L.s_k1[hi] = a1;
+          }
+        }
+        ctx.sync();
+      }
+    }
+    // count live entries (keys != ~0): they are a prefix of the sorted order
+    if (ctx.tid == 0) L.scal[5] = 0;
+    ctx.sync();
+    for (uint32_t k = ctx.tid; k < p2; k += ctx.nt) {
+      bool live = L.s_k1[k] != ~0ull;
+      bool next_live = (k + 1 < p2) && L.s_k1[k + 1] != ~0ull;
+      if (live && !next_live) L.scal[5] = k + 1;
+    }
+    ctx.sync();
+    return L.scal[5];
+  }
+
+  // keep only the best `beam_width` pool entries (exact: pruning is monotone)
+  CTC_HD void prune_pool() {
+    uint32_t pool_n = L.scal[0];
+    double mx = sortable_to_max();
+    uint32_t n = sort_pool(pool_n, mx + prm.beam_prune_logp);
+    if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
+    // gather the survivors through the temp arrays, then rewrite the pool front
+    for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
+      uint32_t idx = (uint32_t)(L.s_k1[k] & 0xFFFFFFFFu);
+      L.g_score[k] = L.p_score[idx];
+      L.g_logit[k] = L.p_logit[idx];
+      L.g_arr[k] = L.p_arr[idx];
+      L.g_don[k] = L.p_don[idx];
+    }
+    ctx.sync();
+    for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
+      L.p_score[k] = L.g_score[k];
+      L.p_logit[k] = L.g_logit[k];
+      L.p_arr[k] = L.g_arr[k];
+      L.p_don[k] = L.g_don[k];
+    }
+    if (ctx.tid == 0) L.scal[0] = n;
+    ctx.sync();
+  }
+
+  CTC_HD double sortable_to_max() const {
+    // smax holds max over pushed scores as an ascending-sortable key
+    uint64_t u = L.smax[0];
+    uint64_t bits = (u >> 63) ? (u & ~(1ull << 63)) : ~u;
+    union { double d; uint64_t u; } c;
+    c.u = bits;
+    return c.d;
+  }
+  CTC_HD static uint64_t asc_key(double s) {
+    if (s == 0.0) s = 0.0;
+    union { double d; uint64_t u; } c;
+    c.d = s;
+    return (c.u >> 63) ? ~c.u : (c.u | (1ull << 63));
+  }
+
+  // Candidate generation + merge + scoring for survivors [s0, s1)
+  CTC_HD void process_chunk(uint32_t s0, uint32_t s1, int frame) {
+    BeamSoA& b = L.beams[cur];
+    uint32_t Q = (s1 - s0) * (uint32_t)N;
+    // conservative running threshold from the chunks already seen (nobody writes smax here)
+    double thr_prev = sortable_to_max() + prm.beam_prune_logp;
+    // G1: keys
+    for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
+      uint32_t s = s0 + q / (uint32_t)N;
+      int i = (int)(q % (uint32_t)N);
+      uint32_t c = L.sid[s];
+      const TokInfo& tk = tab.tok[c];
+      uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+      uint64_t kt = b.text_h[i], kp = b.part_h[i];
+      if (br == BR_BOUNDARY || br == BR_SPACE) {
+        if (plen(b, i) > 0) kt = b.c_text_h[i];
+        kp = br == BR_BOUNDARY ? tk.h_clean : 0;
+      } else if (br == BR_APPEND) {
+        kp = str_concat(kp, tk.pow_raw, tk.h_raw);
+      }
+      L.ck_text[q] = kt;
+      L.ck_part[q] = kp;
+      L.c_logit[q] = b.logit[i] + L.slp[s];
+      L.rmin[q] = 0xFFFFFFFFu;
+      L.rmax[q] = 0;
+      L.rcnt[q] = 0;
+    }
+    ctx.sync();
+    // G2: merge table (candidates of one label only ever merge with each other)
+    for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
+      uint32_t r = table_insert(q, (uint32_t)N);
+      L.crep[q] = r;
+      ctx.atomic_min(&L.rmin[r], q);
+      ctx.atomic_max(&L.rmax[r], q);
+      ctx.atomic_add(&L.rcnt[r], 1u);
+    }
+    ctx.sync();
+    // S: owners fold, score, push
+    for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
+      uint32_t r = L.crep[q];
+      if (L.rmin[r] != q) continue;
+      uint32_t qmax = L.rmax[r], cnt = L.rcnt[r];
+      double lg = L.c_logit[q];
+      if (cnt == 2) {
+        lg = lse2(lg, L.c_logit[qmax]);
+      } else if (cnt > 2) {
+        for (uint32_t q2 = q + 1; q2 <= qmax; ++q2)
+          if (L.crep[q2] == r) lg = lse2(lg, L.c_logit[q2]);
+      }
+      uint32_t s = s0 + q / (uint32_t)N;
+      int i = (int)(q % (uint32_t)N);
+      uint32_t c = L.sid[s];
+      const TokInfo& tk = tab.tok[c];
+      uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+      double lmhw = b.lm_hw[i], ps = b.pscore[i];
+      uint32_t pl = plen(b, i);
+      if (br == BR_BOUNDARY || br == BR_SPACE) {
+        if (pl > 0) lmhw = b.c_lm_hw[i];
+        if (br == BR_BOUNDARY) {
+          pl = tk.len_clean;
+          ps = pl ? partial_score(tab, prm, tk.start_flags, tab.tok_hot ? tab.tok_hot[c].min_len : 0, pl) : 0.0;
+        } else {
+          pl = 0;
+          ps = 0.0;
+        }
+      } else if (br == BR_APPEND) {
+        uint32_t m2 = b.meta2[i];
+        uint32_t wid = 0, pf = 0, hmin = 0, hcomp = 0;
+        uint64_t kp = L.ck_part[q];
+        if (m2 & PF_ON_TABLE) prefix_lookup(tab.prefixes, tab.prefix_mask, kp, &wid, &pf);
+        if (m2 & M2_HOT_ON) hot_lookup(tab.hot, tab.hot_mask, kp, &hmin, &hcomp);
+        pl = pl + tk.len_raw;
+        ps = partial_score(tab, prm, pf, hmin, pl);
+      }
+      double score = total_score(tab, lg, lmhw, ps, pl);
+      ctx.atomic_max64(&L.smax[0], asc_key(score));
+      if (score >= thr_prev) {
+        uint32_t jpos = s;
+        uint32_t imax = qmax % (uint32_t)N;
+        pool_push(score, lg, jpos * (uint32_t)N + (uint32_t)i, (jpos << 8) | imax);
+      }
+    }
+    ctx.sync();
+    clear_table();
+    ctx.sync();
+  }
+
+  // Build beam `dst` of the next table from pool entry `idx`
+  CTC_HD void build_beam(BeamSoA& nb, int dst, uint32_t idx, int frame, bool keep_it) {
+    BeamSoA& b = L.beams[cur];
+    uint32_t don = L.p_don[idx];
+    uint32_t s = don >> 8;
+    int i = (int)(don & 0xFFu);
+    uint32_t c = L.sid[s];
+    const TokInfo& tk = tab.tok[c];
+    uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+    uint32_t pl = plen(b, i);
+    // defaults: keep prefix (blank / repeat)
+    uint64_t th = b.text_h[i], ph = b.part_h[i], hh = b.hist_h[i];
+    double lmhw = b.lm_hw[i], ps = b.pscore[i];
+    uint32_t tnode = b.text_node[i], cnode = b.comp_node[i], wid = b.word_id[i], m2 = b.meta2[i];
+    int32_t pst = b.pstart[i], pen = b.pend[i];
+    uint32_t enode = b.emit_node[i], depth = b.depth[i];
+    uint64_t cth = b.c_text_h[i], chh = b.c_hist_h[i];
+    double clm = b.c_lm_hw[i];
+    if (br == 0) {
+      if (!(tk.flags & TK_BLANK)) pen = frame + 1;  // decoder.py:453-461
+    } else {
+      int32_t wst = pst, wen = pen;
+      if (br == BR_BOUNDARY || br == BR_SPACE) {
+        if (pl > 0) {
+          th = cth;
+          hh = chh;
+          lmhw = clm;
+          tnode = cnode;
+        }
+        if (br == BR_BOUNDARY) {
+          ph = tk.h_clean;
+          uint32_t npl = tk.len_clean;
+          uint32_t hmin = tab.tok_hot ? tab.tok_hot[c].min_len : 0;
+          uint32_t hcomp = tab.tok_hot ? tab.tok_hot[c].complete : 0;
+          if (npl > 0) {
+            m2 = (tk.start_flags & 0xFu) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
+            wid = tk.start_word_id;
+            ps = partial_score(tab, prm, tk.start_flags, hmin, npl);
+          } else {
+            m2 = EMPTY_PARTIAL_M2;
+            wid = 0;
+            ps = 0.0;
+          }
+          pl = npl;
+          pst = frame;
+          pen = frame + 1;
+        } else {
+          ph = 0;
+          pl = 0;
+          m2 = EMPTY_PARTIAL_M2;
+          wid = 0;
+          ps = 0.0;
+          pst = -1;
+          pen = -1;
+        }
+      } else {  // BR_APPEND
+        ph = str_concat(ph, tk.pow_raw, tk.h_raw);
+        uint32_t pf = 0, nw = 0, hmin = 0, hcomp = 0;
+        bool on = (m2 & PF_ON_TABLE) && prefix_lookup(tab.prefixes, tab.prefix_mask, ph, &nw, &pf);
+        bool hon = (m2 & M2_HOT_ON) && hot_lookup(tab.hot, tab.hot_mask, ph, &hmin, &hcomp);
+        pl = pl + tk.len_raw;
+        m2 = (on ? (PF_ON_TABLE | (pf & 7u)) : 0u) | (hon ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) |
+             ((hon ? hmin : 0u) << 8);
+        wid = on ? nw : 0;
+        ps = partial_score(tab, prm, on ? pf : 0u, hon ? hmin : 0u, pl);
+        pst = pst < 0 ? frame : pst;
+        pen = frame + 1;
+      }
+      cnode = 0;
+      if (keep_it) {
+        uint32_t e = ctx.atomic_add(&L.scal[2], 1u);
+        if (e >= io.emit_cap) {
+          ctx.atomic_or(&L.scal[6], ST_EMIT_OVERFLOW);
+          e = io.emit_cap - 1;
+        }
+        EmitNode en;
+        en.parent = enode;
+        en.tok_branch = c | (br << 16);
+        en.wstart = wst;
+        en.wend = wen;
+        io.emit_nodes[e] = en;
+        enode = e;
+        depth += 1;
+      }
+    }
+    if (!keep_it) return;
+    nb.logit[dst] = L.p_logit[idx];
+    nb.lm_hw[dst] = lmhw;
+    nb.pscore[dst] = ps;
+    nb.c_lm_hw[dst] = clm;
+    nb.text_h[dst] = th;
+    nb.part_h[dst] = ph;
+    nb.hist_h[dst] = hh;
+    nb.c_text_h[dst] = cth;
+    nb.c_hist_h[dst] = chh;
+    nb.text_node[dst] = tnode;
+    nb.comp_node[dst] = cnode;
+    nb.emit_node[dst] = enode;
+    nb.word_id[dst] = wid;
+    nb.meta1[dst] = c | (pl << 16);
+    nb.meta2[dst] = m2;
+    nb.depth[dst] = depth;
+    nb.pstart[dst] = pst;
+    nb.pend[dst] = pen;
+  }
+
+  // history-prune key of pool entry idx (decoder.py:250-254): (last words, partial, last_char)
+  CTC_HD void hist_key(uint32_t idx, uint64_t* hh, uint64_t* ph, uint32_t* cc) const {
+    const BeamSoA& b = L.beams[cur];
+    uint32_t don = L.p_don[idx];
+    uint32_t s = don >> 8;
+    int i = (int)(don & 0xFFu);
+    uint32_t c = L.sid[s];
+    const TokInfo& tk = tab.tok[c];
+    uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+    uint64_t h = b.hist_h[i], p = b.part_h[i];
+    if (br == BR_BOUNDARY || br == BR_SPACE) {
+      if (plen(b, i) > 0) h = b.c_hist_h[i];
+      p = br == BR_BOUNDARY ? tk.h_clean : 0;
+    } else if (br == BR_APPEND) {
+      p = str_concat(p, tk.pow_raw, tk.h_raw);
+    }
+    *hh = h;
+    *ph = p;
+    *cc = c;
+  }
+
+  CTC_HD void step(int t) {
+    int frame = prm.first_frame + t;
+    uint32_t ns = io.surv_cnt[t];
+    if (ctx.tid == 0) {
+      L.scal[0] = 0;
+      L.scal[4] = 0;
+      L.smax[0] = asc_key(-INFINITY);
+    }
+    load_survivors(t);
+    ctx.sync();
+    compute_modes(ns);
+    BeamSoA& b = L.beams[cur];
+    if (L.scal[4]) {
+      for (int i = ctx.tid; i < N; i += ctx.nt)
+        if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
+    }
+    ctx.sync();
+    uint32_t per = (uint32_t)shape.cand / (uint32_t)N;
+    if (per == 0) per = 1;
+    for (uint32_t s0 = 0; s0 < ns; s0 += per) {
+      uint32_t s1 = s0 + per < ns ? s0 + per : ns;
+      if (L.scal[0] + (s1 - s0) * (uint32_t)N > (uint32_t)shape.pool) prune_pool();
+      process_chunk(s0, s1, frame);
+    }
+    finish_frame(frame, false);
+  }
+
+  // threshold prune, top-B, history prune, next beam table (decoder.py:545-554)
+  CTC_HD void finish_frame(int frame, bool final_stage) {
+    uint32_t pool_n = L.scal[0];
+    double thr = sortable_to_max() + prm.beam_prune_logp;
+    uint32_t n = sort_pool(pool_n, thr);
+    if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
+    BeamSoA& nb = L.beams[cur ^ 1];
+    if (final_stage) {
+      if (ctx.tid == 0) L.scal[5] = n;
+      ctx.sync();
+      return;
+    }
+    if (prm.prune_history) {
+      // first of each (history, partial, last_char) in sorted order wins
+      for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
+        uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+        hist_key(idx, &L.hk_h[r], &L.hk_p[r], &L.hk_c[r]);
+      }
+      ctx.sync();
+      for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
+        uint64_t hh = L.hk_h[r], ph = L.hk_p[r];
+        uint32_t cc = L.hk_c[r];
+        uint32_t dup = 0;
+        for (uint32_t r2 = 0; r2 < r; ++r2)
+          if (L.hk_h[r2] == hh && L.hk_p[r2] == ph && L.hk_c[r2] == cc) {
+            dup = 1;
+            break;
+          }
+        L.keep[r] = dup ? 0u : 1u;
+      }
+    } else {
+      for (uint32_t r = ctx.tid; r < n; r += ctx.nt) L.keep[r] = 1u;
+    }
+    ctx.sync();
+    for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
+      if (!L.keep[r]) continue;
+      uint32_t dst = 0;
+      for (uint32_t r2 = 0; r2 < r; ++r2) dst += L.keep[r2];
+      uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+      build_beam(nb, (int)dst, idx, frame, true);
+      ctx.atomic_max(&L.scal[7], dst + 1);
+    }
+    ctx.sync();
+    N = (int)L.scal[7];
+    cur ^= 1;
+    ctx.sync();
+    if (ctx.tid == 0) L.scal[7] = 0;
+    ctx.sync();
+  }
+
+  // ---- init / finalisation -------------------------------------------------------------------
+  CTC_HD void init() {
+    if (ctx.tid == 0) {
+      for (int k = 0; k < 16; ++k) L.scal[k] = 0;
+      L.scal[1] = 1;  // text node 0 = empty text
+      L.scal[2] = 1;  // emission node 0 = root
+      TextNode root;
+      root.text_h = 0;
+      root.raw_lm = 0.0;
+      root.lm_hw = 0.0;
+      root.hw_cnt = 0;
+      root.ring_cnt = 0;
+      for (int k = 0; k < MAX_CTX; ++k) root.ring[k] = 0;
+      root.hist_h = hist_hash(root.ring, 0);
+      root.pad0 = 0;
+      LmState st;
+      st.len = 0;
+      for (int k = 0; k < MAX_CTX; ++k) {
+        st.words[k] = 0;
+        st.backoff[k] = 0.f;
+      }
+      if (io.start_state && io.start_state->len >= 0) st = *io.start_state;
+      root.state = st;
+      io.text_nodes[0] = root;
+      EmitNode er;
+      er.parent = 0;
+      er.tok_branch = 0;
+      er.wstart = -1;
+      er.wend = -1;
+      io.emit_nodes[0] = er;
+      BeamSoA& b = L.beams[0];
+      b.logit[0] = 0.0;
+      b.lm_hw[0] = 0.0;
+      b.pscore[0] = 0.0;
+      b.c_lm_hw[0] = 0.0;
+      b.text_h[0] = 0;
+      b.part_h[0] = 0;
+      b.hist_h[0] = root.hist_h;
+      b.c_text_h[0] = 0;
+      b.c_hist_h[0] = 0;
+      b.text_node[0] = 0;
+      b.comp_node[0] = 0;
+      b.emit_node[0] = 0;
+      b.word_id[0] = 0;
+      b.meta1[0] = NO_CHAR;  // last_char None, empty partial
+      b.meta2[0] = EMPTY_PARTIAL_M2;
+      b.depth[0] = 0;
+      b.pstart[0] = -1;
+      b.pend[0] = -1;
+    }
+    clear_table();
+    ctx.sync();
+    cur = 0;
+    N = 1;
+  }
+
+  // _finalize_beams(force_next_word=True, is_end=True) + output records (decoder.py:558-602,653-667)
+  CTC_HD void finalise() {
+    BeamSoA& b = L.beams[cur];
+    if (ctx.tid == 0) {
+      L.scal[0] = 0;
+      L.smax[0] = asc_key(-INFINITY);
+    }
+    ctx.sync();
+    for (int i = ctx.tid; i < N; i += ctx.nt)
+      if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
+    ctx.sync();
+    // candidates: one per beam, key (text (+) partial, "", None)
+    for (int base = 0; base < N; base += shape.cand) {
+      int Q = N - base < shape.cand ? N - base : shape.cand;
+      // (N <= beam capacity <= cand is enforced by the host, so this loop runs once)
+      for (int q = ctx.tid; q < Q; q += ctx.nt) {
+        int i = base + q;
+        L.ck_text[q] = plen(b, i) > 0 ? b.c_text_h[i] : b.text_h[i];
+        L.ck_part[q] = 0;
+        L.c_logit[q] = b.logit[i];
+        L.rmin[q] = 0xFFFFFFFFu;
+        L.rmax[q] = 0;
+        L.rcnt[q] = 0;
+      }
+      ctx.sync();
+      for (int q = ctx.tid; q < Q; q += ctx.nt) {
+        uint32_t r = table_insert((uint32_t)q, 0x7FFFFFFFu);
+        ctx.atomic_min(&L.rmin[r], (uint32_t)q);
+        ctx.atomic_max(&L.rmax[r], (uint32_t)q);
+        ctx.atomic_add(&L.rcnt[r], 1u);
+        L.keep[q] = r;  // keep[] doubles as the representative map here (capacity bw >= N)
+      }
+      ctx.sync();
+      for (int q = ctx.tid; q < Q; q += ctx.nt) {
+        uint32_t r = L.keep[q];
+        if (L.rmin[r] != (uint32_t)q) continue;
+        uint32_t qmax = L.rmax[r];
+        double lg = L.c_logit[q];
+        for (uint32_t q2 = (uint32_t)q + 1; q2 <= qmax; ++q2)
+          if (L.keep[q2] == r) lg = lse2(lg, L.c_logit[q2]);
+        // EOS score through the donor's (text, next_word) split (decoder.py:387-395 with is_eos)
+        int d = base + (int)qmax;
+        const TextNode& src = io.text_nodes[b.text_node[d]];
+        uint32_t m2 = b.meta2[d];
+        uint32_t pl = plen(b, d);
+        uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
+        double lmhw;
+        if (tab.has_lm) {
+          LmState end;
+          uint32_t wid = pl > 0 ? b.word_id[d] : 0u;
+          uint32_t wfl = pl > 0 ? m2 : 0u;
+          float base_s = lm_base_score(tab, src.state, wid, &end);
+          double end_score = 0.0;
+          if (prm.score_boundary) {
+            LmState tmp;
+            end_score = (double)lm_base_score(tab, end, tab.eos_id, &tmp);
+          }
+          double raw = src.raw_lm + lm_word_score(tab, prm, base_s, wfl, end_score, true);
+          lmhw = raw + prm.hot_weight * (double)cnt;
+        } else {
+          lmhw = prm.hot_weight * (double)cnt;
+        }
+        double score = tab.has_lm ? lg + lmhw : lg + lmhw + 0.0;
+        ctx.atomic_max64(&L.smax[0], asc_key(score));
+        pool_push(score, lg, (uint32_t)q, (uint32_t)qmax);
+      }
+      ctx.sync();
+    }
+    finish_frame(0, true);
+    uint32_t n = L.scal[5];
+    uint32_t n_out = n;
+    if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
+    // output records + back-trace of each returned beam's emission chain
+    if (ctx.tid == 0) L.scal[8] = 0;
+    ctx.sync();
+    for (uint32_t r = ctx.tid; r < n_out; r += ctx.nt) {
+      uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+      int d = (int)L.p_don[idx];
+      uint32_t len = b.depth[d] + (plen(b, d) > 0 ? 1u : 0u);
+      L.keep[r] = ctx.atomic_add(&L.scal[8], len);  // offset inside this utterance's block
+    }
+    ctx.sync();
+    if (ctx.tid == 0) {
+      unsigned long long base = ctx.global_add(io.tok_pool_head, (unsigned long long)L.scal[8]);
+      if (base + L.scal[8] > io.tok_pool_cap) {
+        L.scal[6] |= ST_TOK_OVERFLOW;
+        base = 0;
+      }
+      L.smax[1] = base;
+    }
+    ctx.sync();
+    bool tok_ok = !(L.scal[6] & ST_TOK_OVERFLOW);
+    for (uint32_t r = ctx.tid; r < n_out; r += ctx.nt) {
+      uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+      int d = (int)L.p_don[idx];
+      OutBeam ob;
+      ob.logit_score = L.p_logit[idx];
+      ob.lm_score = L.p_score[idx];
+      uint32_t pl = plen(b, d);
+      uint32_t len = b.depth[d] + (pl > 0 ? 1u : 0u);
+      uint32_t off = (uint32_t)(L.smax[1] + L.keep[r]);
+      ob.tok_off = off;
+      ob.tok_cnt = tok_ok ? len : 0;
+      ob.pad = 0;
+      // last_lm_state: state after the last word, before </s> (language_model.py:357)
+      const TextNode& src = io.text_nodes[b.text_node[d]];
+      if (tab.has_lm) {
+        uint32_t wid = pl > 0 ? b.word_id[d] : 0u;
+        lm_base_score(tab, src.state, wid, &ob.state);
+      } else {
+        ob.state = src.state;
+        ob.state.len = -1;
+      }
+      io.out[r] = ob;
+      if (tok_ok) {
+        uint32_t pos = off + len;
+        if (pl > 0) {
+          EmitNode fin;
+          fin.parent = 0;
+          fin.tok_branch = BR_FINAL << 16;
+          fin.wstart = b.pstart[d];
+          fin.wend = b.pend[d];
+          io.tok_pool[--pos] = fin;
+        }
+        uint32_t e = b.emit_node[d];
+        while (e != 0 && pos > off) {
+          EmitNode en = io.emit_nodes[e];
+          io.tok_pool[--pos] = en;
+          e = en.parent;
+        }
+      }
+    }
+    if (ctx.tid == 0) {
+      *io.n_out = n_out;
+      *io.status = L.scal[6];
+    }
+  }
+
+  CTC_HD void run() {
+    init();
+    for (int t = 0; t < io.T; ++t) step(t);
+    finalise();
+  }
+};
+
+}  // namespace ctc

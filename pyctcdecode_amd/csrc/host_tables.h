@@ -1,0 +1,62 @@
+// host_tables.h -- host-side builders for every read-only table the kernels consume: label
+// constants, ARPA -> flat hashed n-gram trie (replaces kenlm.Model, decoder.py:1074), vocabulary
+// prefix table (replaces the pygtrie unigram trie, language_model.py:263) and the per-call
+// hot-word table (replaces HotwordScorer.build_scorer, language_model.py:152-189).
+// Pure C++ (no HIP): shared by the library (api.cpp) and the CPU simulator (tests/sim).
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace ctc {
+
+uint64_t hash_bytes(const char* s, size_t n);                 // H(s)
+uint64_t pow_base(size_t nbytes);                             // STR_BASE^nbytes mod p
+uint32_t utf8_length(const char* s, size_t n);                // code points
+// byte offsets of every code-point boundary after the first code point, including n
+void utf8_boundaries(const char* s, size_t n, std::vector<size_t>* out);
+
+struct HostAlphabet {
+  std::vector<std::string> labels;  // normalised
+  bool is_bpe = false;
+  std::vector<std::string> clean;   // label without boundary marks
+  std::vector<TokInfo> tok;         // start_* fields filled by HostLM::fill_token_starts
+  void build(const std::vector<std::string>& labels_, bool is_bpe_);
+};
+
+struct HostLM {
+  int order = 0;
+  std::vector<std::string> words;  // id -> string, id 0 = <unk>
+  std::unordered_map<std::string, uint32_t> vocab;
+  std::vector<UnigramEntry> unigrams;
+  std::vector<NgramEntry> ngram_table;  // open addressing, empty key 0
+  uint64_t ngram_mask = 0;
+  uint32_t bos_id = 0, eos_id = 0;
+  bool has_trie = false;          // unigrams is not None
+  size_t uniset_size = 0;         // |unigram_set| after filtering to the LM vocabulary
+  std::vector<uint8_t> in_uniset; // by word id
+  std::vector<PrefixEntry> prefix_table;
+  uint64_t prefix_mask = 0;
+  size_t n_ngrams = 0;
+
+  // returns "" on success, else an error message
+  std::string load_arpa(const std::string& path);
+  uint32_t index(const std::string& w) const;  // 0 for OOV and for "<unk>"
+  void set_unigrams(bool has, const std::vector<std::string>& unigrams);
+  void build_prefix_table();
+  void fill_token_starts(HostAlphabet* alpha) const;
+  void start_state(bool begin_sentence, LmState* out) const;
+  void tables(DeviceTables* t) const;  // host pointers (for the host-side query)
+};
+
+struct HostHotwords {
+  std::vector<HotEntry> table;
+  uint64_t mask = 0;
+  std::vector<TokHot> tok_hot;
+  // unigrams: already stripped/split hot-word unigrams
+  void build(const std::vector<std::string>& unigrams, const HostAlphabet& alpha);
+};
+
+}  // namespace ctc

@@ -1,0 +1,463 @@
+"""Drop-in Python surface of the decoder (reference: pyctcdecode/decoder.py).
+
+Same names, positional order and defaults as the reference for ``build_ctcdecoder``,
+``BeamSearchDecoderCTC.decode / decode_beams / decode_batch / decode_beams_batch``, the frozen
+dataclasses ``Beam / LMBeam / OutputBeam`` and ``reset_params / cleanup / clear_class_models``.
+All decoding work happens in libctcdec (HIP, gfx950) through ctypes; this file only marshals.
+The ``pool`` argument of the batch entry points is accepted for signature compatibility and
+ignored: a batch is one device launch (one workgroup per utterance) instead of a process pool.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import logging
+import math
+import os
+from typing import Any, Collection, Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _binding as B
+from .alphabet import Alphabet, verify_alphabet_coverage
+from .constants import (
+    DEFAULT_ALPHA,
+    DEFAULT_BEAM_WIDTH,
+    DEFAULT_BETA,
+    DEFAULT_HOTWORD_WEIGHT,
+    DEFAULT_MIN_TOKEN_LOGP,
+    DEFAULT_PRUNE_BEAMS,
+    DEFAULT_PRUNE_LOGP,
+    DEFAULT_SCORE_LM_BOUNDARY,
+    DEFAULT_UNK_LOGP_OFFSET,
+    LOG_BASE_CHANGE_FACTOR,
+)
+from .language_model import (
+    AbstractLanguageModel,
+    AbstractLMState,
+    HotwordScorer,
+    KenlmState,
+    LanguageModel,
+    NgramModel,
+    NgramState,
+    _default_device,
+    load_unigram_set_from_arpa,
+)
+
+logger = logging.getLogger(__name__)
+
+Frames = Tuple[int, int]
+WordFrames = Tuple[str, Frames]
+
+
+@dataclasses.dataclass(frozen=True)
+class Beam:
+    """decoder.py:69-92 (field order is API)."""
+
+    text: str
+    next_word: str
+    partial_word: str
+    last_char: Optional[str]
+    text_frames: List[Frames]
+    partial_frames: Frames
+    logit_score: float
+
+    @classmethod
+    def from_lm_beam(cls, lm_beam: "LMBeam") -> "Beam":
+        return Beam(
+            text=lm_beam.text,
+            next_word=lm_beam.next_word,
+            partial_word=lm_beam.partial_word,
+            last_char=lm_beam.last_char,
+            text_frames=lm_beam.text_frames,
+            partial_frames=lm_beam.partial_frames,
+            logit_score=lm_beam.logit_score,
+        )
+
+
+@dataclasses.dataclass(frozen=True)
+class LMBeam(Beam):
+    lm_score: float
+
+
+@dataclasses.dataclass(frozen=True)
+class OutputBeam:
+    """decoder.py:102-118."""
+
+    text: str
+    last_lm_state: Optional[AbstractLMState]
+    text_frames: List[WordFrames]
+    logit_score: float
+    lm_score: float
+
+    def get_mp_safe_beam(self) -> "OutputBeam":
+        if self.last_lm_state is None:
+            last_lm_state = None
+        else:
+            last_lm_state = self.last_lm_state.get_mp_safe_state()
+        return dataclasses.replace(self, last_lm_state=last_lm_state)
+
+
+NULL_FRAMES: Frames = (-1, -1)
+EMPTY_START_BEAM = Beam("", "", "", None, [], NULL_FRAMES, 0.0)
+
+
+def _is_device_tensor(x: Any) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class _Batch:
+    """Logit matrices of one call, normalised to what the C ABI takes."""
+
+    def __init__(self, logits_list: Sequence[Any], n_labels: int):
+        self.keep: List[Any] = []  # keeps buffers alive during the call
+        self.ptrs: List[int] = []
+        self.frames: List[int] = []
+        self.is_device = False
+        self.dtype = 0
+        kinds = set()
+        for x in logits_list:
+            shape = tuple(x.shape)
+            if len(shape) != 2:
+                raise ValueError("Input logits have %s dimensions, but need 2: (time, vocabulary)" % len(shape))
+            if shape[-1] != n_labels:
+                raise ValueError(
+                    "Input logits shape is %s, but vocabulary is size %s. "
+                    "Need logits of shape: (time, vocabulary)" % (shape, n_labels)
+                )
+            kinds.add(_is_device_tensor(x) and bool(x.is_cuda))
+        if len(kinds) > 1:
+            raise ValueError("cannot mix host arrays and device tensors in one batch")
+        self.is_device = bool(kinds.pop()) if kinds else False
+        if self.is_device:
+            import torch
+
+            want64 = any(x.dtype == torch.float64 for x in logits_list)
+            for x in logits_list:
+                t = x
+                if want64:
+                    t = t.to(torch.float64)
+                elif t.dtype != torch.float32:
+                    t = t.to(torch.float32)
+                t = t.contiguous()
+                self.keep.append(t)
+                self.ptrs.append(int(t.data_ptr()))
+                self.frames.append(int(t.shape[0]))
+            self.dtype = 1 if want64 else 0
+        else:
+            arrs = [x.detach().cpu().numpy() if _is_device_tensor(x) else np.asarray(x) for x in logits_list]
+            want32 = len(arrs) > 0 and all(a.dtype == np.float32 or a.dtype == np.float16 for a in arrs)
+            for a in arrs:
+                a = np.ascontiguousarray(a, dtype=np.float32 if want32 else np.float64)
+                self.keep.append(a)
+                self.ptrs.append(a.ctypes.data if a.size else 0)
+                self.frames.append(int(a.shape[0]))
+            self.dtype = 0 if want32 else 1
+
+
+class BeamSearchDecoderCTC:
+    # The reference parks the language model in a class-level dict keyed by 16 random bytes so that
+    # fork-pool children find it (decoder.py:262-269); the container and its clean-up functions
+    # are kept because callers and tests manage memory through them.
+    model_container: Dict[bytes, Optional[AbstractLanguageModel]] = {}
+
+    def __init__(self, alphabet: Alphabet, language_model: Optional[AbstractLanguageModel] = None) -> None:
+        self._alphabet = alphabet
+        self._idx2vocab = {n: c for n, c in enumerate(self._alphabet.labels)}
+        self._is_bpe = alphabet.is_bpe
+        self._model_key = os.urandom(16)
+        BeamSearchDecoderCTC.model_container[self._model_key] = language_model
+        if language_model is not None and not isinstance(language_model, LanguageModel):
+            raise NotImplementedError(
+                "only the n-gram LanguageModel can be lowered to the device trie; user-defined "
+                "AbstractLanguageModel subclasses and MultiLanguageModel are not supported "
+                "(there is deliberately no CPU fallback)"
+            )
+        lib = B.get_library()
+        self._lib = lib
+        blob, off = B.pack_strings(self._alphabet.labels)
+        handle = C.c_void_p()
+        lib.check(
+            lib.dll.ctcdec_create(blob, B.off_ptr(off), len(self._alphabet.labels), int(self._is_bpe),
+                                  _default_device(), C.byref(handle))
+        )
+        self._handle = handle
+        if language_model is not None:
+            lib.check(lib.dll.ctcdec_lm_share(handle, language_model._kenlm_model._handle))
+        self._hot_key: Optional[Tuple[str, ...]] = None
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None:
+            try:
+                self._lib.dll.ctcdec_destroy(h)
+            except Exception:  # pragma: no cover
+                pass
+            self._handle = None
+
+    # -- parameter / model management (decoder.py:292-328) -------------------------------------
+    def reset_params(
+        self,
+        alpha: Optional[float] = None,
+        beta: Optional[float] = None,
+        unk_score_offset: Optional[float] = None,
+        lm_score_boundary: Optional[bool] = None,
+    ) -> None:
+        language_model = self._language_model
+        if language_model is None:
+            return
+        params: Dict[str, Any] = {}
+        if alpha is not None:
+            params["alpha"] = alpha
+        if beta is not None:
+            params["beta"] = beta
+        if unk_score_offset is not None:
+            params["unk_score_offset"] = unk_score_offset
+        if lm_score_boundary is not None:
+            params["score_boundary"] = lm_score_boundary
+        language_model.reset_params(**params)
+
+    @classmethod
+    def clear_class_models(cls) -> None:
+        cls.model_container = {}
+
+    def cleanup(self) -> None:
+        if self._model_key in BeamSearchDecoderCTC.model_container:
+            del BeamSearchDecoderCTC.model_container[self._model_key]
+
+    @property
+    def _language_model(self) -> Optional[AbstractLanguageModel]:
+        return BeamSearchDecoderCTC.model_container[self._model_key]
+
+    def _check_logits_dimension(self, logits: Any) -> None:
+        if len(logits.shape) != 2:
+            raise ValueError(
+                "Input logits have %s dimensions, but need 2: (time, vocabulary)" % len(logits.shape)
+            )
+        if logits.shape[-1] != len(self._idx2vocab):
+            raise ValueError(
+                "Input logits shape is %s, but vocabulary is size %s. "
+                "Need logits of shape: (time, vocabulary)" % (tuple(logits.shape), len(self._idx2vocab))
+            )
+
+    # -- the one native call everything funnels into --------------------------------------------
+    def _set_hotwords(self, hotwords: Optional[Iterable[str]]) -> None:
+        unigrams = HotwordScorer.build_scorer(hotwords).unigrams
+        key = tuple(unigrams)
+        if key == self._hot_key:
+            return
+        blob, off = B.pack_strings(unigrams)
+        self._lib.check(self._lib.dll.ctcdec_set_hotwords(self._handle, blob, B.off_ptr(off), len(unigrams)))
+        self._hot_key = key
+
+    def _params(self, beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_weight, n_best) -> B.Params:
+        lm = self._language_model
+        p = B.Params()
+        p.beam_width = int(beam_width)
+        p.prune_history = int(bool(prune_history))
+        p.n_best = int(n_best)
+        p.want_lm_state = 1
+        p.beam_prune_logp = float(beam_prune_logp)
+        p.token_min_logp = float(token_min_logp)
+        p.hotword_weight = float(hotword_weight)
+        p.alpha = float(lm.alpha) if lm is not None else 0.0
+        p.beta = float(lm.beta) if lm is not None else 0.0
+        p.unk_score_offset = float(lm.unk_score_offset) if lm is not None else 0.0
+        p.log_base_change = LOG_BASE_CHANGE_FACTOR
+        p.lm_score_boundary = int(bool(lm.score_boundary)) if lm is not None else 0
+        p.first_frame = 0
+        return p
+
+    def _run(self, logits_list: Sequence[Any], params: B.Params, hotwords, start_states=None):
+        """-> (packed numpy views, result handle). Caller must free the handle."""
+        self._set_hotwords(hotwords)
+        batch = _Batch(logits_list, len(self._idx2vocab))
+        n = len(batch.ptrs)
+        ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
+        frames = (C.c_int32 * max(n, 1))(*batch.frames)
+        st_arr = None
+        if start_states is not None and self._language_model is not None:
+            st_arr = (B.LmState * max(n, 1))()
+            for k, s in enumerate(start_states):
+                if s is None:
+                    st_arr[k].length = -1
+                else:
+                    if not isinstance(s, KenlmState):
+                        raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(s)}")
+                    st_arr[k] = s.state.to_c()
+        res = C.c_void_p()
+        self._lib.check(
+            self._lib.dll.ctcdec_decode_batch(self._handle, ptrs, frames, n, batch.dtype, int(batch.is_device),
+                                              C.byref(params), st_arr, C.byref(res))
+        )
+        return res
+
+    def _unpack(self, res: C.c_void_p, with_state: bool) -> List[List[OutputBeam]]:
+        pk = B.Packed()
+        self._lib.check(self._lib.dll.ctcdec_result_pack(res, C.byref(pk)))
+        nb, nw, nu = int(pk.n_beams), int(pk.n_words), int(pk.n_utts)
+        beam_off = np.ctypeslib.as_array(pk.beam_off, shape=(nu + 1,))
+        out: List[List[OutputBeam]] = []
+        if nb == 0:
+            return [[] for _ in range(nu)]
+        text_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
+        blob = C.string_at(pk.text_blob, int(text_off[nb])) if text_off[nb] else b""
+        logit = np.ctypeslib.as_array(pk.logit_score, shape=(nb,))
+        lm = np.ctypeslib.as_array(pk.lm_score, shape=(nb,))
+        wco = np.ctypeslib.as_array(pk.word_cnt_off, shape=(nb + 1,))
+        if nw:
+            wstart = np.ctypeslib.as_array(pk.word_start, shape=(nw,))
+            wend = np.ctypeslib.as_array(pk.word_end, shape=(nw,))
+        has_lm = self._language_model is not None
+        for u in range(nu):
+            beams = []
+            for k in range(int(beam_off[u]), int(beam_off[u + 1])):
+                text = blob[int(text_off[k]) : int(text_off[k + 1])].decode("utf-8")
+                words = text.split(" ") if text else []
+                w0, w1 = int(wco[k]), int(wco[k + 1])
+                frames = [(words[j], (int(wstart[w0 + j]), int(wend[w0 + j]))) for j in range(w1 - w0)]
+                state = None
+                if with_state and has_lm:
+                    state = KenlmState(NgramState.from_c(pk.lm_state[k]))
+                beams.append(OutputBeam(text, state, frames, float(logit[k]), float(lm[k])))
+            out.append(beams)
+        return out
+
+    # -- public decode surface (decoder.py:730-945) ----------------------------------------------
+    def decode_beams(
+        self,
+        logits: Any,
+        beam_width: int = DEFAULT_BEAM_WIDTH,
+        beam_prune_logp: float = DEFAULT_PRUNE_LOGP,
+        token_min_logp: float = DEFAULT_MIN_TOKEN_LOGP,
+        prune_history: bool = DEFAULT_PRUNE_BEAMS,
+        hotwords: Optional[Iterable[str]] = None,
+        hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
+        lm_start_state: Optional[AbstractLMState] = None,
+    ) -> List[OutputBeam]:
+        self._check_logits_dimension(logits)
+        params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_weight, 0)
+        res = self._run([logits], params, hotwords, [lm_start_state])
+        try:
+            return self._unpack(res, True)[0]
+        finally:
+            self._lib.dll.ctcdec_result_free(res)
+
+    def decode(
+        self,
+        logits: Any,
+        beam_width: int = DEFAULT_BEAM_WIDTH,
+        beam_prune_logp: float = DEFAULT_PRUNE_LOGP,
+        token_min_logp: float = DEFAULT_MIN_TOKEN_LOGP,
+        hotwords: Optional[Iterable[str]] = None,
+        hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
+        lm_start_state: Optional[AbstractLMState] = None,
+    ) -> str:
+        self._check_logits_dimension(logits)
+        # prune_history=True: only the best beam is read (decoder.py:888)
+        params = self._params(beam_width, beam_prune_logp, token_min_logp, True, hotword_weight, 1)
+        res = self._run([logits], params, hotwords, [lm_start_state])
+        try:
+            return self._unpack(res, False)[0][0].text
+        finally:
+            self._lib.dll.ctcdec_result_free(res)
+
+    def decode_batch(
+        self,
+        pool: Any,
+        logits_list: Sequence[Any],
+        beam_width: int = DEFAULT_BEAM_WIDTH,
+        beam_prune_logp: float = DEFAULT_PRUNE_LOGP,
+        token_min_logp: float = DEFAULT_MIN_TOKEN_LOGP,
+        hotwords: Optional[Iterable[str]] = None,
+        hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
+    ) -> List[str]:
+        """decoder.py:895-945. ``pool`` is ignored (one device launch decodes the whole batch)."""
+        logits_list = list(logits_list)
+        for logits in logits_list:
+            self._check_logits_dimension(logits)
+        if len(logits_list) == 0:
+            return []
+        params = self._params(beam_width, beam_prune_logp, token_min_logp, True, hotword_weight, 1)
+        res = self._run(logits_list, params, hotwords)
+        try:
+            pk = B.Packed()
+            self._lib.check(self._lib.dll.ctcdec_result_pack(res, C.byref(pk)))
+            nb = int(pk.n_beams)
+            text_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
+            blob = C.string_at(pk.text_blob, int(text_off[nb])) if text_off[nb] else b""
+            return [blob[int(text_off[k]) : int(text_off[k + 1])].decode("utf-8") for k in range(nb)]
+        finally:
+            self._lib.dll.ctcdec_result_free(res)
+
+    def decode_beams_batch(
+        self,
+        pool: Any,
+        logits_list: Sequence[Any],
+        beam_width: int = DEFAULT_BEAM_WIDTH,
+        beam_prune_logp: float = DEFAULT_PRUNE_LOGP,
+        token_min_logp: float = DEFAULT_MIN_TOKEN_LOGP,
+        prune_history: bool = DEFAULT_PRUNE_BEAMS,
+        hotwords: Optional[Iterable[str]] = None,
+        hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
+    ) -> List[List[OutputBeam]]:
+        """decoder.py:801-857. Beams carry ``last_lm_state=None`` like the reference's mp-safe beams."""
+        logits_list = list(logits_list)
+        for logits in logits_list:
+            self._check_logits_dimension(logits)
+        if len(logits_list) == 0:
+            return []
+        params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_weight, 0)
+        res = self._run(logits_list, params, hotwords)
+        try:
+            return self._unpack(res, False)
+        finally:
+            self._lib.dll.ctcdec_result_free(res)
+
+    def last_timing_ms(self) -> Tuple[float, float, float]:  # pragma: no cover - diagnostics
+        raise NotImplementedError
+
+    # -- streaming (decoder.py:669-728): SURVEY 8(f) rank 3, not built yet -----------------------
+    def get_starting_state(self):
+        raise NotImplementedError("partial_decode_beams streaming state is not implemented on the device path yet")
+
+    def partial_decode_beams(self, *args, **kwargs):
+        raise NotImplementedError("partial_decode_beams streaming state is not implemented on the device path yet")
+
+
+def build_ctcdecoder(
+    labels: List[str],
+    kenlm_model_path: Optional[str] = None,
+    unigrams: Optional[Collection[str]] = None,
+    alpha: float = DEFAULT_ALPHA,
+    beta: float = DEFAULT_BETA,
+    unk_score_offset: float = DEFAULT_UNK_LOGP_OFFSET,
+    lm_score_boundary: bool = DEFAULT_SCORE_LM_BOUNDARY,
+) -> BeamSearchDecoderCTC:
+    """decoder.py:1051-1099."""
+    kenlm_model = None if kenlm_model_path is None else NgramModel(kenlm_model_path)
+    if kenlm_model_path is not None and kenlm_model_path.endswith(".arpa"):
+        logger.info("Using arpa instead of binary LM file, decoder instantiation might be slow.")
+    if unigrams is None and kenlm_model_path is not None:
+        if kenlm_model_path.endswith(".arpa"):
+            unigrams = load_unigram_set_from_arpa(kenlm_model_path)
+        else:
+            logger.warning(
+                "Unigrams not provided and cannot be automatically determined from LM file (only "
+                "arpa format). Decoding accuracy might be reduced."
+            )
+    alphabet = Alphabet.build_alphabet(labels)
+    if unigrams is not None:
+        verify_alphabet_coverage(alphabet, unigrams)
+    if kenlm_model is not None:
+        language_model: Optional[AbstractLanguageModel] = LanguageModel(
+            kenlm_model,
+            unigrams,
+            alpha=alpha,
+            beta=beta,
+            unk_score_offset=unk_score_offset,
+            score_boundary=lm_score_boundary,
+        )
+    else:
+        language_model = None
+    return BeamSearchDecoderCTC(alphabet, language_model)

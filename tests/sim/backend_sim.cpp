@@ -1,0 +1,143 @@
+// backend_sim.cpp -- TEST INFRASTRUCTURE ONLY.  A sequential CPU implementation of backend.h that
+// runs the very same beam_core.h / set_order.h source the HIP kernels compile, one "thread" per
+// workgroup.  It exists so the beam logic can be debugged against the oracle in a container without
+// a GPU.  It is built into tests/_build/libctcdec_sim.so by tests/sim/build_sim.py, is never
+// linked into pyctcdecode_amd/libctcdec.so and the product never loads it.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../pyctcdecode_amd/csrc/backend.h"
+#include "../../pyctcdecode_amd/csrc/beam_core.h"
+#include "../../pyctcdecode_amd/csrc/set_order.h"
+
+namespace ctc {
+namespace be {
+
+struct SeqCtx {
+  int tid = 0, nt = 1;
+  void sync() {}
+  uint32_t atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+  void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+  void atomic_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+  void atomic_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+  void atomic_max64(uint64_t* p, uint64_t v) { if (v > *p) *p = v; }
+  uint32_t atomic_cas(uint32_t* p, uint32_t cmp, uint32_t val) { uint32_t o = *p; if (o == cmp) *p = val; return o; }
+  unsigned long long global_add(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+};
+
+const char* name() { return "sim"; }
+int init(int, std::string*) { return 0; }
+void* alloc(size_t bytes, std::string* err) {
+  void* p = malloc(bytes ? bytes : 1);
+  if (!p && err) *err = "out of host memory";
+  return p;
+}
+void release(void* p) { free(p); }
+int h2d(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
+int d2h(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
+int zero(void* d, size_t n, std::string*) { memset(d, 0, n); return 0; }
+int sync(std::string*) { return 0; }
+void last_timing(double* a, double* b) { *a = 0; *b = 0; }
+
+static double load(const void* base, int dtype, size_t idx) {
+  return dtype == 0 ? (double)((const float*)base)[idx] : ((const double*)base)[idx];
+}
+
+int launch_prune(const PruneArgs& a, std::string*) {
+  const int V = a.n_labels;
+  const double clip_lo = log(1e-15);
+  std::vector<double> lp((size_t)V);
+  std::vector<uint16_t> asc((size_t)V + 1), order((size_t)V + 2);
+  uint32_t cap = set_table_cap((uint32_t)V + 1);
+  std::vector<uint16_t> ta(cap), tr(cap), sc(cap);
+  for (int u = 0; u < a.n_utts; ++u) {
+    const void* x = a.utt_logits[u];
+    int64_t r0 = a.utt_row0[u], T = a.utt_row0[u + 1] - r0;
+    double tot = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+      double s = 0.0;
+      for (int v = 0; v < V; ++v) s += load(x, a.dtype, (size_t)t * V + v);
+      a.row_sum[r0 + t] = s;
+      tot += s;
+    }
+    double mean = T > 0 ? tot / (double)T : NAN;
+    bool is_prob = fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);  // math.isclose(mean, 1)
+    a.utt_is_prob[u] = is_prob ? 1u : 0u;
+    for (int64_t t = 0; t < T; ++t) {
+      if (is_prob) {
+        for (int v = 0; v < V; ++v) {
+          double p = load(x, a.dtype, (size_t)t * V + v);
+          p = p < 1e-15 ? 1e-15 : (p > 1.0 ? 1.0 : p);
+          lp[(size_t)v] = log(p);
+        }
+      } else {
+        double mx = -INFINITY;
+        for (int v = 0; v < V; ++v) mx = fmax(mx, load(x, a.dtype, (size_t)t * V + v));
+        if (!isfinite(mx)) mx = 0.0;
+        double se = 0.0;
+        for (int v = 0; v < V; ++v) se += exp(load(x, a.dtype, (size_t)t * V + v) - mx);
+        double lse = log(se);
+        for (int v = 0; v < V; ++v) {
+          double y = (load(x, a.dtype, (size_t)t * V + v) - mx) - lse;
+          lp[(size_t)v] = y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
+        }
+      }
+      uint32_t n = 0, amax = 0;
+      for (int v = 0; v < V; ++v) {
+        if (lp[(size_t)v] > lp[amax]) amax = (uint32_t)v;
+        if (lp[(size_t)v] >= a.token_min_logp) asc[n++] = (uint16_t)v;
+      }
+      uint32_t m = cpython_set_order(asc.data(), n, amax, ta.data(), tr.data(), sc.data(), order.data());
+      size_t row = (size_t)(r0 + t);
+      if (m > (uint32_t)a.max_surv) {
+        *a.overflow = 1;
+        m = (uint32_t)a.max_surv;
+      }
+      a.surv_cnt[row] = m;
+      for (uint32_t k = 0; k < m; ++k) {
+        a.surv_id[row * a.max_surv + k] = order[k];
+        a.surv_lp[row * a.max_surv + k] = lp[order[k]];
+      }
+    }
+  }
+  return 0;
+}
+
+int launch_beam(const BeamArgs& a, std::string*) {
+  LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
+  size_t bytes = lds_carve(nullptr, nullptr, shape);
+  std::vector<char> lds(bytes + 64);
+  char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+  for (int u = 0; u < a.n_utts; ++u) {
+    memset(base, 0xCD, bytes);  // poison: catch reads of never-written LDS
+    LdsView view;
+    lds_carve(&view, base, shape);
+    UttIO io;
+    int64_t r0 = a.utt_row0[u];
+    io.surv_cnt = a.surv_cnt + r0;
+    io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
+    io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
+    io.T = (int32_t)(a.utt_row0[u + 1] - r0);
+    io.text_nodes = a.text_nodes + a.text_off[u];
+    io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
+    io.emit_nodes = a.emit_nodes + a.emit_off[u];
+    io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+    io.start_state = a.start_states ? a.start_states + u : nullptr;
+    io.out = a.out + (size_t)u * a.out_stride;
+    io.n_out = a.n_out + u;
+    io.status = a.status + u;
+    io.tok_pool = a.tok_pool;
+    io.tok_pool_head = a.tok_pool_head;
+    io.tok_pool_cap = a.tok_pool_cap;
+    SeqCtx ctx;
+    BeamDecoder<SeqCtx> dec(ctx, view, shape, a.tables, a.params, io);
+    dec.run();
+  }
+  return 0;
+}
+
+}  // namespace be
+}  // namespace ctc
