@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py -- logit-frames/s of decode_batch on MI355X (BASELINE.json metric).
+
+Workload ("step" = one decode_batch over one batch of synthetic logits already resident in HBM):
+BASELINE config "Conformer-CTC BPE vocab V=1024, 4-gram LM + hotword boost, beam=100, batch=4096
+[T=1000] sharded over 8 GPUs" => 512 utterances x T=1000 x V=1024 per GPU (weak scaling: each rank
+decodes its own 512 utterances, texts are gathered over RCCL at the end of every step).
+Inputs: D_words(boost 6.0) of SURVEY 8(d) (seeded, synthetic), fp32 logits, 20k-word synthetic
+4-gram ARPA, 20 in-vocabulary + 5 OOV hot words.
+
+Usage: python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import synth  # noqa: E402
+
+CONFIG_ID = 4
+V = 1024
+T = 1000
+BEAM = 100
+HBM_PEAK = 8.0e12  # B/s (MI355X_MICROARCH.md: 8 TB/s spec)
+
+
+def build_assets(cache_dir, n_words, n_sent):
+    lm = synth.SynthLM(cache_dir, n_words, n_sent, order=4, seed=7,
+                       max_ngrams={2: 200_000, 3: 400_000, 4: 400_000})
+    labels = synth.make_bpe_vocab(lm.words, size=V - 1)
+    hot = lm.hotwords(20, 5)
+    return lm, labels, hot
+
+
+def make_batch(lm, labels, first_utt, n_utts, frames):
+    return [synth.d_words(CONFIG_ID, first_utt + u, frames, labels, True, lm.words, lm.sentences, len(labels),
+                          boost=6.0) for u in range(n_utts)]
+
+
+def cpu_baseline(lm, labels, hot, xs, cores):
+    """The oracle's decode_batch (same algorithm and cost structure as the reference's pure-Python
+    decode_batch) on a fork pool over the host cores, on a bounded sample of the same workload."""
+    import multiprocessing as mp
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    alpha = Alphabet.build_alphabet(labels)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    xs64 = [x.astype(np.float64) for x in xs]
+    frames = sum(x.shape[0] for x in xs64)
+    with mp.get_context("fork").Pool(cores) as pool:  # created after the decoder (README.md:80-85)
+        t0 = time.perf_counter()
+        texts = orc.decode_batch(pool, xs64, beam_width=BEAM, hotwords=hot)
+        dt = time.perf_counter() - t0
+    return texts, frames / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=512, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=T)
+    ap.add_argument("--lm-words", type=int, default=20000)
+    ap.add_argument("--lm-sentences", type=int, default=60000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="utterances in the CPU sample (0: eight per core)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    os.environ["CTCDEC_DEVICE"] = str(local_rank)
+
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.parallel import gather_texts
+
+    cache = os.path.join(ROOT, "gpurun_out", "bench_cache") if os.access(ROOT, os.W_OK) else "/tmp/ctc_bench"
+    if rank == 0:
+        lm, labels, hot = build_assets(cache, args.lm_words, args.lm_sentences)
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        lm, labels, hot = build_assets(cache, args.lm_words, args.lm_sentences)
+    decoder = build_ctcdecoder(labels, lm.path)
+
+    xs = make_batch(lm, labels, rank * args.batch, args.batch, args.frames)
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    total_frames = args.batch * args.frames * world
+
+    def step():
+        texts = decoder.decode_batch(None, dev, beam_width=BEAM, hotwords=hot)
+        if world > 1:
+            texts = gather_texts(texts)
+        return texts
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prune_ms, beam_ms = [], []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        texts = step()
+        prune_ms.append(decoder.last_timing_ms[0])
+        beam_ms.append(decoder.last_timing_ms[1])
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = 1000.0 * dt / args.steps
+        value = total_frames * args.steps / dt
+        frames_per_launch = args.batch * args.frames
+        beam_avg = float(np.mean(beam_ms)) if beam_ms else 0.0
+        prune_avg = float(np.mean(prune_ms)) if prune_ms else 0.0
+        algo_bytes = 4.0 * V * frames_per_launch  # 4*V bytes per logit frame
+        dominant = "beam_decode" if beam_avg >= prune_avg else "frame_prune"
+        dom_ms = max(beam_avg, prune_avg)
+        achieved = algo_bytes / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+        out = {
+            "metric": "logit-frames/sec (whole node) at beam=100, V=1024, 4-gram LM",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[3] per-GPU shard: BPE V=1024, synthetic 4-gram ARPA (%d words) + 25 hot "
+                            "words, beam=100, decode_batch of %d utterances x T=%d, D_words(boost 6.0), fp32 logits "
+                            "resident in HBM" % (args.lm_words, args.batch, args.frames),
+                "utterances_per_gpu": args.batch,
+                "frames_per_utterance": args.frames,
+                "vocab": V,
+                "beam_width": BEAM,
+                "parallelism": "utterance shard per GPU, RCCL all_gather of texts" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dominant,
+                "achieved": achieved / 1e9,
+                "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK,
+                "traffic": None,
+                "kernel_ms": dom_ms,
+                "algorithmic_bytes_per_launch": algo_bytes,
+            },
+            "stages_ms": {"frame_prune": prune_avg, "beam_decode": beam_avg,
+                          "frame_prune_GBps": (algo_bytes / (prune_avg * 1e-3) / 1e9) if prune_avg > 0 else None},
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            n_s = args.cpu_sample or 8 * cores
+            n_s = min(n_s, len(xs))
+            ref_texts, cpu_fps, cpu_dt = cpu_baseline(lm, labels, hot, xs[:n_s], cores)
+            out["cpu_baseline"] = {
+                "value": cpu_fps,
+                "unit": "frames/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": "oracle decode_batch (pure-Python port of the reference) on a fork Pool(%d): first %d "
+                          "utterances x T=%d of the same batch, %.1f s wall" % (cores, n_s, args.frames, cpu_dt),
+                "texts_match_gpu": ref_texts == texts[:n_s],
+            }
+            out["speedup_vs_cpu_port"] = value / cpu_fps if cpu_fps > 0 else None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

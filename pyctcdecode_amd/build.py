@@ -1,0 +1,58 @@
+"""Build pyctcdecode_amd/libctcdec.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libctcdec.so")
+SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip"]
+HEADERS = ["common.h", "beam_core.h", "set_order.h", "backend.h", "host_tables.h"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(SRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return OUT
+    obj_dir = os.path.join(HERE, "csrc", "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = []
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, src + ".o")
+        if src.endswith(".hip"):
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wno-unused-result",
+                   "-c", os.path.join(SRC, src), "-o", obj]
+        else:  # pure host C++ (no HIP headers): ARPA parsing, table builders, C ABI
+            cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-DNDEBUG", "-c", os.path.join(SRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT + ".tmp"] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

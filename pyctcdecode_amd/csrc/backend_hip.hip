@@ -1,0 +1,402 @@
+// backend_hip.hip -- the product backend: HIP kernels for gfx950 (MI355X, CDNA4, wave64).
+//
+//   frame_rowsum / utt_sniff  input sniff of decoder.py:760 (mean row sum ~ 1 => probabilities)
+//   frame_prune               log-softmax + clip (decoder.py:180-197,762-765), token prune and
+//                             argmax (decoder.py:444-445), CPython-set ordering (set_order.h);
+//                             one wave per frame row, fully parallel over all frames of the batch
+//                             -- this is the stage that streams the [T x V] logits from HBM once
+//   beam_decode               the sequential prefix-beam recursion (beam_core.h); one workgroup
+//                             per utterance, beam table / candidates / merge table in LDS
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+
+#include "backend.h"
+#include "beam_core.h"
+#include "set_order.h"
+
+namespace ctc {
+namespace be {
+
+static hipStream_t g_stream = nullptr;
+static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static int g_device = -1;
+static bool g_timing_valid = false;
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+      return -1;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+const char* name() { return "hip-gfx950"; }
+
+int init(int device, std::string* err) {
+  if (g_stream && device == g_device) return 0;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    if (err) *err = "no HIP device available (libctcdec has no CPU fallback)";
+    return -1;
+  }
+  if (device < 0 || device >= n) device = 0;
+  HIP_TRY(hipSetDevice(device));
+  if (!g_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreate(&g_ev[k]));
+  }
+  g_device = device;
+  return 0;
+}
+
+void* alloc(size_t bytes, std::string* err) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    if (err) *err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    return nullptr;
+  }
+  return p;
+}
+void release(void* p) { (void)hipFree(p); }
+int h2d(void* d, const void* s, size_t n, std::string* err) {
+  HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));  // the source is caller memory that may be reused
+  return 0;
+}
+int d2h(void* d, const void* s, size_t n, std::string* err) {
+  HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return 0;
+}
+int zero(void* d, size_t n, std::string* err) {
+  HIP_TRY(hipMemsetAsync(d, 0, n, g_stream));
+  return 0;
+}
+int sync(std::string* err) {
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return 0;
+}
+
+void last_timing(double* prune_ms, double* beam_ms) {
+  *prune_ms = 0;
+  *beam_ms = 0;
+  if (!g_timing_valid) return;
+  float a = 0, b = 0;
+  if (hipEventSynchronize(g_ev[2]) != hipSuccess) return;
+  if (hipEventElapsedTime(&a, g_ev[0], g_ev[1]) == hipSuccess) *prune_ms = a;
+  if (hipEventElapsedTime(&b, g_ev[1], g_ev[2]) == hipSuccess) *beam_ms = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers (wave64)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ double ld(const T* p, size_t i) {
+  return (double)p[i];
+}
+
+// row -> utterance (binary search over the prefix sums)
+__device__ __forceinline__ int find_utt(const int64_t* row0, int n_utts, int64_t row) {
+  int lo = 0, hi = n_utts - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (row0[mid] <= row) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+constexpr int PRUNE_WAVES = 4;  // rows per 256-thread block
+
+template <typename T>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_rowsum(PruneArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + (threadIdx.x >> 6);
+  if (row >= a.n_rows) return;
+  const int u = find_utt(a.utt_row0, a.n_utts, row);
+  const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * a.n_labels;
+  double s = 0.0;
+  for (int v = lane; v < a.n_labels; v += 64) s += ld(x, v);
+  s = wave_sum(s);
+  if (lane == 0) a.row_sum[row] = s;
+}
+
+__global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t r0 = a.utt_row0[u], r1 = a.utt_row0[u + 1];
+  double s = 0.0;
+  for (int64_t r = r0 + lane; r < r1; r += 64) s += a.row_sum[r];
+  s = wave_sum(s);
+  if (lane == 0) {
+    double mean = r1 > r0 ? s / (double)(r1 - r0) : NAN;
+    // math.isclose(mean, 1): |mean - 1| <= 1e-9 * max(|mean|, 1)   (decoder.py:760)
+    bool is_prob = fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);
+    a.utt_is_prob[u] = is_prob ? 1u : 0u;
+  }
+}
+
+// One wave per frame row.  LDS per wave: ascending survivor ids + their log-probs, the two CPython
+// set tables, a resize scratch and the ordered id list.
+template <typename T>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  const uint32_t ms = (uint32_t)a.max_surv;
+  const size_t per_wave = (((size_t)(ms + 1) * 8 + 15) & ~(size_t)15) + (((size_t)(ms + 2) * 2 * 2 + 15) & ~(size_t)15) +
+                          (((size_t)cap * 2 * 3 + 15) & ~(size_t)15);
+  char* base = smem + per_wave * wave;
+  double* asc_lp = (double*)base;
+  uint16_t* asc_id = (uint16_t*)(base + (((size_t)(ms + 1) * 8 + 15) & ~(size_t)15));
+  uint16_t* order = asc_id + (ms + 2);
+  uint16_t* tabA = (uint16_t*)((char*)asc_id + (((size_t)(ms + 2) * 2 * 2 + 15) & ~(size_t)15));
+  uint16_t* tabR = tabA + cap;
+  uint16_t* scratch = tabR + cap;
+  if (row >= a.n_rows) return;
+  const int V = a.n_labels;
+  const int u = find_utt(a.utt_row0, a.n_utts, row);
+  const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V;
+  const bool is_prob = a.utt_is_prob[u] != 0;
+  const double clip_lo = -34.538776394910684;  // ln(1e-15)
+  double mx = 0.0, lse = 0.0;
+  if (!is_prob) {
+    double m = -INFINITY;
+    for (int v = lane; v < V; v += 64) m = fmax(m, ld(x, v));
+    m = wave_max(m);
+    if (!isfinite(m)) m = 0.0;  // decoder.py:186-189
+    double s = 0.0;
+    for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
+    s = wave_sum(s);
+    mx = m;
+    lse = log(s);
+  }
+  // pass 3: log-probabilities, survivors in ascending id order, argmax (first maximum)
+  uint32_t n = 0;
+  double best = -INFINITY;
+  int best_id = 0x7FFFFFFF;
+  bool overflow = false;
+  for (int v0 = 0; v0 < V; v0 += 64) {
+    int v = v0 + lane;
+    double y = -INFINITY;
+    bool in = v < V;
+    if (in) {
+      double xv = ld(x, v);
+      if (is_prob) {
+        double p = xv < 1e-15 ? 1e-15 : (xv > 1.0 ? 1.0 : xv);
+        y = log(p);
+      } else {
+        y = (xv - mx) - lse;
+        y = y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
+      }
+      if (y > best) {
+        best = y;
+        best_id = v;
+      }
+    }
+    bool keep = in && y >= a.token_min_logp;
+    unsigned long long mask = __ballot(keep);
+    if (keep) {
+      uint32_t pos = n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < ms) {
+        asc_id[pos] = (uint16_t)v;
+        asc_lp[pos] = y;
+      }
+    }
+    n += (uint32_t)__popcll(mask);
+  }
+  if (n > ms) {
+    overflow = true;
+    n = ms;
+  }
+  // argmax reduce: larger value wins, equal values -> smaller index (numpy argmax)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ob = __shfl_xor(best, off, 64);
+    int oi = __shfl_xor(best_id, off, 64);
+    if (ob > best || (ob == best && oi < best_id)) {
+      best = ob;
+      best_id = oi;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  uint32_t m = 0;
+  if (lane == 0) m = cpython_set_order(asc_id, n, (uint32_t)best_id, tabA, tabR, scratch, order);
+  m = __shfl(m, 0, 64);
+  __threadfence_block();
+  if (m > ms) {
+    overflow = true;
+    m = ms;
+  }
+  if (lane == 0) {
+    a.surv_cnt[row] = m;
+    if (overflow) *a.overflow = 1u;
+  }
+  uint16_t* out_id = a.surv_id + (size_t)row * ms;
+  double* out_lp = a.surv_lp + (size_t)row * ms;
+  for (uint32_t k = lane; k < m; k += 64) {
+    uint32_t id = order[k];
+    // binary search the ascending list for the log-prob (the argmax may be absent: below threshold)
+    double lp = best;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (asc_id[mid] < id) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n && asc_id[lo] == id) lp = asc_lp[lo];
+    out_id[k] = (uint16_t)id;
+    out_lp[k] = lp;
+  }
+}
+
+int launch_prune(const PruneArgs& a, std::string* err) {
+  g_timing_valid = false;
+  HIP_TRY(hipEventRecord(g_ev[0], g_stream));
+  if (a.n_rows > 0) {
+    uint32_t cap = set_table_cap((uint32_t)a.max_surv + 1);
+    size_t ms = (size_t)a.max_surv;
+    size_t per_wave = (((ms + 1) * 8 + 15) & ~(size_t)15) + (((ms + 2) * 2 * 2 + 15) & ~(size_t)15) +
+                      (((size_t)cap * 2 * 3 + 15) & ~(size_t)15);
+    size_t lds = per_wave * PRUNE_WAVES;
+    if (lds > 160 * 1024) {
+      if (err) *err = "token_min_logp admits too many labels per frame for the LDS set tables";
+      return -1;
+    }
+    dim3 grid((unsigned)((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES)), block(PRUNE_WAVES * 64);
+    if (a.dtype == 0) {
+      hipLaunchKernelGGL(frame_rowsum<float>, grid, block, 0, g_stream, a);
+    } else {
+      hipLaunchKernelGGL(frame_rowsum<double>, grid, block, 0, g_stream, a);
+    }
+    hipLaunchKernelGGL(utt_sniff, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
+    if (a.dtype == 0) {
+      HIP_TRY(hipFuncSetAttribute((const void*)frame_prune<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(frame_prune<float>, grid, block, lds, g_stream, a, cap);
+    } else {
+      HIP_TRY(hipFuncSetAttribute((const void*)frame_prune<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(frame_prune<double>, grid, block, lds, g_stream, a, cap);
+    }
+    HIP_TRY(hipGetLastError());
+  } else if (a.n_utts > 0) {
+    hipLaunchKernelGGL(utt_sniff, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(g_ev[1], g_stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// beam kernel
+// ---------------------------------------------------------------------------------------------
+struct GpuCtx {
+  int tid, nt;
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+  // LDS atomics (ds_*): workgroup scope, relaxed -- phases are separated by s_barrier
+  __device__ __forceinline__ uint32_t atomic_add(CTC_LDS uint32_t* p, uint32_t v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void atomic_or(CTC_LDS uint32_t* p, uint32_t v) {
+    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void atomic_min(CTC_LDS uint32_t* p, uint32_t v) {
+    __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void atomic_max(CTC_LDS uint32_t* p, uint32_t v) {
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ void atomic_max64(CTC_LDS uint64_t* p, uint64_t v) {
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ __forceinline__ uint32_t atomic_cas(CTC_LDS uint32_t* p, uint32_t cmp, uint32_t val) {
+    __hip_atomic_compare_exchange_strong(p, &cmp, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    return cmp;
+  }
+  __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {
+    return atomicAdd(p, v);
+  }
+};
+
+constexpr int BEAM_THREADS = 256;
+
+template <int BW>
+__global__ __launch_bounds__(BEAM_THREADS) void beam_decode(BeamArgs a, int surv_cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int u = blockIdx.x;
+  // compile-time layout: every LDS array sits at a constant offset (ds_* immediate offsets)
+  LdsShape shape;
+  shape.bw = BW;
+  shape.cand = CAND_CHUNK;
+  shape.pool = 2 * CAND_CHUNK;
+  shape.surv = surv_cap;
+  LdsView view;
+  lds_carve(view, (lds_bytes_t)smem, shape);
+  UttIO io;
+  const int64_t r0 = a.utt_row0[u];
+  io.surv_cnt = a.surv_cnt + r0;
+  io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
+  io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
+  io.T = (int32_t)(a.utt_row0[u + 1] - r0);
+  io.text_nodes = a.text_nodes + a.text_off[u];
+  io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
+  io.emit_nodes = a.emit_nodes + a.emit_off[u];
+  io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+  io.start_state = a.start_states ? a.start_states + u : nullptr;
+  io.out = a.out + (size_t)u * a.out_stride;
+  io.n_out = a.n_out + u;
+  io.status = a.status + u;
+  io.tok_pool = a.tok_pool;
+  io.tok_pool_head = a.tok_pool_head;
+  io.tok_pool_cap = a.tok_pool_cap;
+  GpuCtx ctx{(int)threadIdx.x, BEAM_THREADS};
+  BeamDecoder<GpuCtx> dec(ctx, view, shape, a.tables, a.params, io);
+  dec.run();
+}
+
+int launch_beam(const BeamArgs& a, std::string* err) {
+  LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
+  size_t lds = lds_bytes(shape);
+  if (lds > 160 * 1024) {
+    if (err) *err = "beam table does not fit LDS (" + std::to_string(lds) + " bytes)";
+    return -1;
+  }
+  if (a.n_utts > 0) {
+    dim3 grid((unsigned)a.n_utts), block(BEAM_THREADS);
+#define CTC_LAUNCH_BEAM(BWV)                                                                                  \
+  do {                                                                                                        \
+    HIP_TRY(hipFuncSetAttribute((const void*)beam_decode<BWV>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                (int)lds));                                                                   \
+    hipLaunchKernelGGL(beam_decode<BWV>, grid, block, lds, g_stream, a, shape.surv);                          \
+  } while (0)
+    switch (shape.bw) {
+      case 32: CTC_LAUNCH_BEAM(32); break;
+      case 64: CTC_LAUNCH_BEAM(64); break;
+      case 128: CTC_LAUNCH_BEAM(128); break;
+      default: CTC_LAUNCH_BEAM(256); break;
+    }
+#undef CTC_LAUNCH_BEAM
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(g_ev[2], g_stream));
+  g_timing_valid = true;
+  return 0;
+}
+
+}  // namespace be
+}  // namespace ctc

@@ -16,6 +16,22 @@
 
 namespace ctc {
 
+// LDS-resident arrays are addressed through 32-bit address_space(3) pointers on the device so that
+// every access is a ds_* instruction with a constant offset (the layout is a compile-time constant
+// of the kernel instantiation); on the host (sim, sizing) they are ordinary pointers.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CTC_SIM)
+#define CTC_LDS __attribute__((address_space(3)))
+#else
+#define CTC_LDS
+#endif
+template <class T>
+struct LPtr {
+  CTC_LDS T* p;
+  CTC_HD CTC_LDS T& operator[](int i) const { return p[i]; }
+  CTC_HD CTC_LDS T& operator[](uint32_t i) const { return p[i]; }
+};
+typedef CTC_LDS char* lds_bytes_t;
+
 constexpr uint32_t NO_CHAR = 0xFFFFu;
 constexpr uint32_t M2_HOT_ON = 16u;        // partial is a prefix of a hot word
 constexpr uint32_t M2_HOT_COMPLETE = 32u;  // partial is itself a hot word
@@ -25,10 +41,16 @@ enum : uint32_t { MODE_A = 0, MODE_ALL_B = 1, MODE_FIRST_B = 2, MODE_C = 3, MODE
 enum : uint32_t { ST_TEXT_OVERFLOW = 1u, ST_EMIT_OVERFLOW = 2u, ST_POOL_OVERFLOW = 4u, ST_TOK_OVERFLOW = 8u };
 
 struct BeamSoA {
-  double *logit, *lm_hw, *pscore, *c_lm_hw;
-  uint64_t *text_h, *part_h, *hist_h, *c_text_h, *c_hist_h;
-  uint32_t *text_node, *comp_node, *emit_node, *word_id, *meta1, *meta2, *depth;
-  int32_t *pstart, *pend;
+  LPtr<double> logit, lm_hw, pscore, c_lm_hw;
+  LPtr<uint64_t> text_h, part_h, hist_h, c_text_h, c_hist_h;
+  LPtr<uint32_t> text_node, comp_node, emit_node, word_id, meta1, meta2, depth;
+  LPtr<int32_t> pstart, pend;
+};
+
+struct Surv {  // one surviving label of the current frame
+  uint32_t id;
+  uint32_t mode;  // MODE_* | first_non_repeat << 8
+  double lp;
 };
 
 // sizes that shape the LDS carve-up (host computes the same numbers for the launch)
@@ -42,109 +64,113 @@ struct LdsShape {
 CTC_HD size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // LDS shape for a beam width and survivor bound (same numbers on host and device)
-inline LdsShape make_shape(int beam_width, int max_surv) {
+CTC_HD int beam_bucket(int beam_width) {  // beam-table capacities the kernel is instantiated for
+  return beam_width <= 32 ? 32 : beam_width <= 64 ? 64 : beam_width <= 128 ? 128 : 256;
+}
+constexpr int CAND_CHUNK = 512;  // candidates merged per pass (>= 2 * largest beam bucket)
+CTC_HD LdsShape make_shape(int beam_width, int max_surv) {
   LdsShape s;
-  s.bw = (beam_width + 7) & ~7;
-  s.cand = 512;
-  while (s.cand < 2 * s.bw) s.cand <<= 1;
-  s.pool = 2 * s.cand;
+  s.bw = beam_bucket(beam_width);
+  s.cand = CAND_CHUNK;
+  s.pool = 2 * CAND_CHUNK;
   s.surv = (max_surv + 3) & ~3;
   return s;
 }
 
 struct LdsView {
   BeamSoA beams[2];
-  // survivors of the current frame
-  uint32_t* sid;
-  double* slp;
-  uint32_t* smode;   // MODE_* | first_non_repeat << 8
   // candidates of the current chunk
-  uint64_t *ck_text, *ck_part;
-  double* c_logit;
-  uint32_t *crep, *rmin, *rmax, *rcnt;
-  uint32_t* table;  // 2*cand slots, stores q+1
+  LPtr<uint64_t> ck_text, ck_part;
+  LPtr<double> c_logit;
+  LPtr<uint32_t> crep, rmin, rmax, rcnt;
+  LPtr<uint32_t> table;  // 2*cand slots, stores q+1
   // pool of merged, scored candidates of the current frame
-  double *p_score, *p_logit;
-  uint32_t *p_arr, *p_don;
+  LPtr<double> p_score, p_logit;
+  LPtr<uint32_t> p_arr, p_don;
   // sort buffer (aliases the candidate arrays)
-  uint64_t *s_k0, *s_k1;
+  LPtr<uint64_t> s_k0, s_k1;
   // scalars
-  uint32_t* scal;  // [0] pool_n [1] text_next [2] emit_next [3] flag [4] need_comp [5] n_sel [6] status [7] n_new
-  uint64_t* smax;  // sortable max score
-  uint32_t* keep;  // per selected beam: kept by history prune
-  uint64_t *hk_h, *hk_p;  // history-prune keys of the selected beams
-  uint32_t* hk_c;
+  LPtr<uint32_t> scal;  // [0] pool_n [1] text_next [2] emit_next [3] flag [4] need_comp [5] n_sel [6] status [7] n_new [8] tok_len
+  LPtr<uint64_t> smax;  // [0] sortable max score [1] token pool base
+  LPtr<uint32_t> keep;  // per selected beam: kept by history prune
+  LPtr<uint64_t> hk_h, hk_p;  // history-prune keys of the selected beams
+  LPtr<uint32_t> hk_c;
   // gather temp used when the pool is compacted (aliases the tail of the candidate arrays)
-  double *g_score, *g_logit;
-  uint32_t *g_arr, *g_don;
+  LPtr<double> g_score, g_logit;
+  LPtr<uint32_t> g_arr, g_don;
+  // survivors of the current frame (last: its size is the only run-time quantity)
+  LPtr<Surv> surv;
 };
 
-template <class F>
-CTC_HD void carve_beams(BeamSoA& b, char*& p, int bw, F&& take) {
-  b.logit = (double*)take(p, 8 * bw);
-  b.lm_hw = (double*)take(p, 8 * bw);
-  b.pscore = (double*)take(p, 8 * bw);
-  b.c_lm_hw = (double*)take(p, 8 * bw);
-  b.text_h = (uint64_t*)take(p, 8 * bw);
-  b.part_h = (uint64_t*)take(p, 8 * bw);
-  b.hist_h = (uint64_t*)take(p, 8 * bw);
-  b.c_text_h = (uint64_t*)take(p, 8 * bw);
-  b.c_hist_h = (uint64_t*)take(p, 8 * bw);
-  b.text_node = (uint32_t*)take(p, 4 * bw);
-  b.comp_node = (uint32_t*)take(p, 4 * bw);
-  b.emit_node = (uint32_t*)take(p, 4 * bw);
-  b.word_id = (uint32_t*)take(p, 4 * bw);
-  b.meta1 = (uint32_t*)take(p, 4 * bw);
-  b.meta2 = (uint32_t*)take(p, 4 * bw);
-  b.depth = (uint32_t*)take(p, 4 * bw);
-  b.pstart = (int32_t*)take(p, 4 * bw);
-  b.pend = (int32_t*)take(p, 4 * bw);
+template <class T>
+CTC_HD LPtr<T> lds_take(lds_bytes_t& p, size_t bytes) {
+  LPtr<T> r;
+  r.p = (CTC_LDS T*)p;
+  p += align16(bytes);
+  return r;
 }
 
-// Carves `base` into the view; returns bytes used. With base == nullptr it only measures.
-CTC_HD size_t lds_carve(LdsView* v, char* base, const LdsShape& s) {
-  char* p = base;
-  auto take = [](char*& q, size_t bytes) {
-    char* r = q;
-    q += align16(bytes);
-    return r;
-  };
-  LdsView tmp;
-  LdsView& o = v ? *v : tmp;
-  carve_beams(o.beams[0], p, s.bw, take);
-  carve_beams(o.beams[1], p, s.bw, take);
-  o.sid = (uint32_t*)take(p, 4 * s.surv);
-  o.slp = (double*)take(p, 8 * s.surv);
-  o.smode = (uint32_t*)take(p, 4 * s.surv);
-  o.p_score = (double*)take(p, 8 * s.pool);
-  o.p_logit = (double*)take(p, 8 * s.pool);
-  o.p_arr = (uint32_t*)take(p, 4 * s.pool);
-  o.p_don = (uint32_t*)take(p, 4 * s.pool);
-  o.scal = (uint32_t*)take(p, 4 * 16);
-  o.smax = (uint64_t*)take(p, 8 * 2);
-  o.keep = (uint32_t*)take(p, 4 * s.bw);
-  o.hk_h = (uint64_t*)take(p, 8 * s.bw);
-  o.hk_p = (uint64_t*)take(p, 8 * s.bw);
-  o.hk_c = (uint32_t*)take(p, 4 * s.bw);
+CTC_HD void carve_beams(BeamSoA& b, lds_bytes_t& p, int bw) {
+  b.logit = lds_take<double>(p, 8 * bw);
+  b.lm_hw = lds_take<double>(p, 8 * bw);
+  b.pscore = lds_take<double>(p, 8 * bw);
+  b.c_lm_hw = lds_take<double>(p, 8 * bw);
+  b.text_h = lds_take<uint64_t>(p, 8 * bw);
+  b.part_h = lds_take<uint64_t>(p, 8 * bw);
+  b.hist_h = lds_take<uint64_t>(p, 8 * bw);
+  b.c_text_h = lds_take<uint64_t>(p, 8 * bw);
+  b.c_hist_h = lds_take<uint64_t>(p, 8 * bw);
+  b.text_node = lds_take<uint32_t>(p, 4 * bw);
+  b.comp_node = lds_take<uint32_t>(p, 4 * bw);
+  b.emit_node = lds_take<uint32_t>(p, 4 * bw);
+  b.word_id = lds_take<uint32_t>(p, 4 * bw);
+  b.meta1 = lds_take<uint32_t>(p, 4 * bw);
+  b.meta2 = lds_take<uint32_t>(p, 4 * bw);
+  b.depth = lds_take<uint32_t>(p, 4 * bw);
+  b.pstart = lds_take<int32_t>(p, 4 * bw);
+  b.pend = lds_take<int32_t>(p, 4 * bw);
+}
+
+// Carves `base` into the view; returns bytes used.
+CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
+  lds_bytes_t p = base;
+  carve_beams(o.beams[0], p, s.bw);
+  carve_beams(o.beams[1], p, s.bw);
+  o.p_score = lds_take<double>(p, 8 * s.pool);
+  o.p_logit = lds_take<double>(p, 8 * s.pool);
+  o.p_arr = lds_take<uint32_t>(p, 4 * s.pool);
+  o.p_don = lds_take<uint32_t>(p, 4 * s.pool);
+  o.scal = lds_take<uint32_t>(p, 4 * 16);
+  o.smax = lds_take<uint64_t>(p, 8 * 2);
+  o.keep = lds_take<uint32_t>(p, 4 * s.bw);
+  o.hk_h = lds_take<uint64_t>(p, 8 * s.bw);
+  o.hk_p = lds_take<uint64_t>(p, 8 * s.bw);
+  o.hk_c = lds_take<uint32_t>(p, 4 * s.bw);
   // candidate arrays and the sort buffer share one region
-  char* shared0 = p;
-  o.ck_text = (uint64_t*)take(p, 8 * s.cand);
-  o.ck_part = (uint64_t*)take(p, 8 * s.cand);
-  o.c_logit = (double*)take(p, 8 * s.cand);
-  o.crep = (uint32_t*)take(p, 4 * s.cand);
-  o.rmin = (uint32_t*)take(p, 4 * s.cand);
-  o.rmax = (uint32_t*)take(p, 4 * s.cand);
-  o.rcnt = (uint32_t*)take(p, 4 * s.cand);
-  o.table = (uint32_t*)take(p, 4 * 2 * s.cand);
-  char* q = shared0;
-  o.s_k0 = (uint64_t*)take(q, 8 * s.pool);
-  o.s_k1 = (uint64_t*)take(q, 8 * s.pool);
-  o.g_score = (double*)take(q, 8 * s.bw);
-  o.g_logit = (double*)take(q, 8 * s.bw);
-  o.g_arr = (uint32_t*)take(q, 4 * s.bw);
-  o.g_don = (uint32_t*)take(q, 4 * s.bw);
+  lds_bytes_t shared0 = p;
+  o.ck_text = lds_take<uint64_t>(p, 8 * s.cand);
+  o.ck_part = lds_take<uint64_t>(p, 8 * s.cand);
+  o.c_logit = lds_take<double>(p, 8 * s.cand);
+  o.crep = lds_take<uint32_t>(p, 4 * s.cand);
+  o.rmin = lds_take<uint32_t>(p, 4 * s.cand);
+  o.rmax = lds_take<uint32_t>(p, 4 * s.cand);
+  o.rcnt = lds_take<uint32_t>(p, 4 * s.cand);
+  o.table = lds_take<uint32_t>(p, 4 * 2 * s.cand);
+  lds_bytes_t q = shared0;
+  o.s_k0 = lds_take<uint64_t>(q, 8 * s.pool);
+  o.s_k1 = lds_take<uint64_t>(q, 8 * s.pool);
+  o.g_score = lds_take<double>(q, 8 * s.bw);
+  o.g_logit = lds_take<double>(q, 8 * s.bw);
+  o.g_arr = lds_take<uint32_t>(q, 4 * s.bw);
+  o.g_don = lds_take<uint32_t>(q, 4 * s.bw);
   if (q > p) p = q;
+  o.surv = lds_take<Surv>(p, sizeof(Surv) * s.surv);
   return (size_t)(p - base);
+}
+
+CTC_HD size_t lds_bytes(const LdsShape& s) {
+  LdsView tmp;
+  return lds_carve(tmp, (lds_bytes_t) nullptr, s);
 }
 
 // per-utterance global-memory view
@@ -183,7 +209,9 @@ CTC_HD double lse2(double a, double b) {  // decoder.py:170-177
 
 CTC_HD uint64_t hist_hash(const uint64_t* ring, uint32_t cnt) {
   uint64_t h = 0x9E3779B97F4A7C15ull + cnt;
-  for (uint32_t k = cnt; k-- > 0;) h = mix64(h ^ ring[k]) + 0x632BE59BD9B4E019ull;
+#pragma unroll
+  for (int k = MAX_CTX - 1; k >= 0; --k)
+    if ((uint32_t)k < cnt) h = mix64(h ^ ring[k]) + 0x632BE59BD9B4E019ull;
   return h;
 }
 
@@ -258,6 +286,7 @@ struct BeamDecoder {
     uint32_t rc = src.ring_cnt + 1 > tab.n_hist ? tab.n_hist : src.ring_cnt + 1;
     nn.ring_cnt = rc;
     nn.ring[0] = wh;
+#pragma unroll
     for (int k = 1; k < MAX_CTX; ++k) nn.ring[k] = (uint32_t)k < rc ? src.ring[k - 1] : 0;
     nn.hist_h = hist_hash(nn.ring, rc);
     nn.pad0 = 0;
@@ -284,8 +313,8 @@ struct BeamDecoder {
     const uint16_t* ids = io.surv_id + (size_t)t * prm.max_surv;
     const double* lps = io.surv_lp + (size_t)t * prm.max_surv;
     for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
-      L.sid[s] = ids[s];
-      L.slp[s] = lps[s];
+      L.surv[s].id = ids[s];
+      L.surv[s].lp = lps[s];
     }
   }
 
@@ -293,7 +322,7 @@ struct BeamDecoder {
     BeamSoA& b = L.beams[cur];
     // first beam that does not repeat the label (only BPE needs it)
     for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
-      uint32_t c = L.sid[s];
+      uint32_t c = L.surv[s].id;
       uint32_t fl = tab.tok[c].flags;
       uint32_t first = (uint32_t)N;
       uint32_t mode;
@@ -308,16 +337,16 @@ struct BeamDecoder {
         first = (uint32_t)i;
         mode = MODE_D;  // resolved below
       }
-      L.smode[s] = mode | (first << 8);
+      L.surv[s].mode = mode | (first << 8);
     }
     ctx.sync();
     if (tab.is_bpe && ctx.tid == 0) {
       uint32_t f = L.scal[3];
       uint32_t need = 0;
       for (uint32_t s = 0; s < ns; ++s) {
-        uint32_t fl = tab.tok[L.sid[s]].flags;
+        uint32_t fl = tab.tok[L.surv[s].id].flags;
         if (fl & TK_BLANK) continue;
-        uint32_t first = L.smode[s] >> 8;
+        uint32_t first = L.surv[s].mode >> 8;
         bool any = first < (uint32_t)N;
         uint32_t mode = MODE_D;
         if (fl & TK_LEAD) {
@@ -333,7 +362,7 @@ struct BeamDecoder {
           }
         }
         if (mode != MODE_D && any) need = 1;
-        L.smode[s] = mode | (first << 8);
+        L.surv[s].mode = mode | (first << 8);
       }
       L.scal[3] = f;
       if (need) L.scal[4] = 1u;
@@ -438,6 +467,8 @@ struct BeamDecoder {
     }
     if (ctx.tid == 0) L.scal[0] = n;
     ctx.sync();
+    clear_table();  // the gather temp may overlap the (all-zero between chunks) merge table
+    ctx.sync();
   }
 
   CTC_HD double sortable_to_max() const {
@@ -465,9 +496,9 @@ struct BeamDecoder {
     for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
       uint32_t s = s0 + q / (uint32_t)N;
       int i = (int)(q % (uint32_t)N);
-      uint32_t c = L.sid[s];
+      uint32_t c = L.surv[s].id;
       const TokInfo& tk = tab.tok[c];
-      uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+      uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
       uint64_t kt = b.text_h[i], kp = b.part_h[i];
       if (br == BR_BOUNDARY || br == BR_SPACE) {
         if (plen(b, i) > 0) kt = b.c_text_h[i];
@@ -477,7 +508,7 @@ struct BeamDecoder {
       }
       L.ck_text[q] = kt;
       L.ck_part[q] = kp;
-      L.c_logit[q] = b.logit[i] + L.slp[s];
+      L.c_logit[q] = b.logit[i] + L.surv[s].lp;
       L.rmin[q] = 0xFFFFFFFFu;
       L.rmax[q] = 0;
       L.rcnt[q] = 0;
@@ -506,9 +537,9 @@ struct BeamDecoder {
       }
       uint32_t s = s0 + q / (uint32_t)N;
       int i = (int)(q % (uint32_t)N);
-      uint32_t c = L.sid[s];
+      uint32_t c = L.surv[s].id;
       const TokInfo& tk = tab.tok[c];
-      uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+      uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
       double lmhw = b.lm_hw[i], ps = b.pscore[i];
       uint32_t pl = plen(b, i);
       if (br == BR_BOUNDARY || br == BR_SPACE) {
@@ -548,9 +579,9 @@ struct BeamDecoder {
     uint32_t don = L.p_don[idx];
     uint32_t s = don >> 8;
     int i = (int)(don & 0xFFu);
-    uint32_t c = L.sid[s];
+    uint32_t c = L.surv[s].id;
     const TokInfo& tk = tab.tok[c];
-    uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+    uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
     uint32_t pl = plen(b, i);
     // defaults: keep prefix (blank / repeat)
     uint64_t th = b.text_h[i], ph = b.part_h[i], hh = b.hist_h[i];
@@ -654,9 +685,9 @@ struct BeamDecoder {
     uint32_t don = L.p_don[idx];
     uint32_t s = don >> 8;
     int i = (int)(don & 0xFFu);
-    uint32_t c = L.sid[s];
+    uint32_t c = L.surv[s].id;
     const TokInfo& tk = tab.tok[c];
-    uint32_t br = branch_of(b, tk.flags, L.smode[s], c, i);
+    uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
     uint64_t h = b.hist_h[i], p = b.part_h[i];
     if (br == BR_BOUNDARY || br == BR_SPACE) {
       if (plen(b, i) > 0) h = b.c_hist_h[i];
@@ -712,7 +743,12 @@ struct BeamDecoder {
       // first of each (history, partial, last_char) in sorted order wins
       for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
         uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
-        hist_key(idx, &L.hk_h[r], &L.hk_p[r], &L.hk_c[r]);
+        uint64_t hh, ph;
+        uint32_t cc;
+        hist_key(idx, &hh, &ph, &cc);
+        L.hk_h[r] = hh;
+        L.hk_p[r] = ph;
+        L.hk_c[r] = cc;
       }
       ctx.sync();
       for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {

@@ -257,30 +257,42 @@ CTC_HD float lm_base_score(const DeviceTables& t, const LmState& in, uint32_t wi
   UnigramEntry u = t.unigrams[wid];
   float prob = u.prob;
   float obo[MAX_CTX + 1];
+#pragma unroll
+  for (int k = 0; k <= MAX_CTX; ++k) obo[k] = 0.f;
   obo[0] = u.backoff;
   int matched = 1;
-  int max_n = (int)t.lm_order < in.len + 1 ? (int)t.lm_order : in.len + 1;
-  for (int n = 2; n <= max_n; ++n) {
-    uint64_t k = ngram_key_begin((uint32_t)n);
-    for (int c = n - 2; c >= 0; --c) k = ngram_key_push(k, in.words[c]);
-    k = ngram_key_end(ngram_key_push(k, wid));
-    float p, b;
-    if (!t.ngrams || !ngram_lookup(t.ngrams, t.ngram_mask, k, &p, &b)) break;
-    prob = p;
-    obo[n - 1] = b;
-    matched = n;
+  const int in_len = in.len;
+  const int max_n = (int)t.lm_order < in_len + 1 ? (int)t.lm_order : in_len + 1;
+  bool go = t.ngrams != nullptr;
+#pragma unroll
+  for (int n = 2; n <= MAX_CTX + 1; ++n) {
+    if (go && n <= max_n) {
+      uint64_t k = ngram_key_begin((uint32_t)n);
+#pragma unroll
+      for (int c = MAX_CTX - 1; c >= 0; --c)
+        if (c <= n - 2) k = ngram_key_push(k, in.words[c]);
+      k = ngram_key_end(ngram_key_push(k, wid));
+      float p, b;
+      if (ngram_lookup(t.ngrams, t.ngram_mask, k, &p, &b)) {
+        prob = p;
+        obo[n - 1] = b;
+        matched = n;
+      } else {
+        go = false;
+      }
+    }
   }
-  for (int i = matched - 1; i < in.len; ++i) prob = prob + in.backoff[i];  // fp32, shortest first
-  int keep = matched < (int)t.lm_order - 1 ? matched : (int)t.lm_order - 1;
+#pragma unroll
+  for (int i = 0; i < MAX_CTX; ++i)
+    if (i >= matched - 1 && i < in_len) prob = prob + in.backoff[i];  // fp32, shortest context first
+  const int keep = matched < (int)t.lm_order - 1 ? matched : (int)t.lm_order - 1;
   LmState o;
   o.len = keep;
+#pragma unroll
   for (int k = 0; k < MAX_CTX; ++k) {
-    o.words[k] = 0;
-    o.backoff[k] = 0.f;
-  }
-  for (int k = 0; k < keep; ++k) {
-    o.words[k] = k == 0 ? wid : in.words[k - 1];
-    o.backoff[k] = obo[k];
+    bool on = k < keep;
+    o.words[k] = on ? (k == 0 ? wid : in.words[k > 0 ? k - 1 : 0]) : 0u;
+    o.backoff[k] = on ? obo[k] : 0.f;
   }
   *out = o;
   return prob;

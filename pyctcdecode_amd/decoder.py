@@ -132,6 +132,8 @@ class _Batch:
         if self.is_device:
             import torch
 
+            # our kernels run on their own stream: make sure the producer of the logits is done
+            torch.cuda.current_stream().synchronize()
             want64 = any(x.dtype == torch.float64 for x in logits_list)
             for x in logits_list:
                 t = x
@@ -290,6 +292,10 @@ class BeamSearchDecoderCTC:
             self._lib.dll.ctcdec_decode_batch(self._handle, ptrs, frames, n, batch.dtype, int(batch.is_device),
                                               C.byref(params), st_arr, C.byref(res))
         )
+        ms = (C.c_double * 3)()
+        self._lib.dll.ctcdec_result_timing(res, ms)
+        # [frame-prune kernels, beam kernel (HIP events on the decode stream), whole native call]
+        self.last_timing_ms = (float(ms[0]), float(ms[1]), float(ms[2]))
         return res
 
     def _unpack(self, res: C.c_void_p, with_state: bool) -> List[List[OutputBeam]]:
@@ -413,9 +419,6 @@ class BeamSearchDecoderCTC:
             return self._unpack(res, False)
         finally:
             self._lib.dll.ctcdec_result_free(res)
-
-    def last_timing_ms(self) -> Tuple[float, float, float]:  # pragma: no cover - diagnostics
-        raise NotImplementedError
 
     # -- streaming (decoder.py:669-728): SURVEY 8(f) rank 3, not built yet -----------------------
     def get_starting_state(self):

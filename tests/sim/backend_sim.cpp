@@ -108,13 +108,13 @@ int launch_prune(const PruneArgs& a, std::string*) {
 
 int launch_beam(const BeamArgs& a, std::string*) {
   LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
-  size_t bytes = lds_carve(nullptr, nullptr, shape);
+  size_t bytes = lds_bytes(shape);
   std::vector<char> lds(bytes + 64);
   char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
   for (int u = 0; u < a.n_utts; ++u) {
     memset(base, 0xCD, bytes);  // poison: catch reads of never-written LDS
     LdsView view;
-    lds_carve(&view, base, shape);
+    lds_carve(view, base, shape);
     UttIO io;
     int64_t r0 = a.utt_row0[u];
     io.surv_cnt = a.surv_cnt + r0;

@@ -1,0 +1,160 @@
+"""GPU (-m gpu): the HIP path through the C ABI against (a) the reference's golden vectors,
+(b) the oracle on seeded inputs at sizes it finishes in seconds, (c) size-independent properties
+at BASELINE sizes.  Tolerance: order and frames exact (near-ties: see golden_util.check_beams),
+scores within 1e-6 absolute-relative (north-star bound: 1e-4)."""
+import numpy as np
+import pytest
+
+import synth
+from tests.golden_util import LM_DIR, check_beams, lm_path, load_cases
+
+pytestmark = pytest.mark.gpu
+
+CASES, INPUTS = load_cases()
+TOL = 1e-6
+
+
+def _loaded_native():
+    from pyctcdecode_amd import _binding as B
+
+    lib = B.get_library()
+    assert lib.path.endswith("pyctcdecode_amd/libctcdec.so"), lib.path
+    return lib
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_hip_matches_reference_golden(case):
+    from pyctcdecode_amd import build_ctcdecoder
+
+    _loaded_native()
+    dec = build_ctcdecoder(case["labels"], lm_path(case["lm"]), case["unigrams"], **case["build"])
+    out = dec.decode_beams(INPUTS[case["input"]], **case["decode"])
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in out], case["expected"],
+                tol=TOL, what=case["name"])
+
+
+def _oracle_expected(orc, x, kw):
+    with np.errstate(all="ignore"):
+        out = orc.decode_beams(x, **kw)
+    return [{"text": o[0], "frames": [[w, int(a), int(b)] for w, (a, b) in o[2]], "logit": o[3], "lm": o[4]} for o in out]
+
+
+@pytest.fixture(scope="module")
+def lm():
+    return synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2)
+
+
+@pytest.fixture(scope="module")
+def bpe(lm):
+    return synth.make_bpe_vocab(lm.words, size=1023)
+
+
+def test_hip_vs_oracle_flat_char_beam100(lm):
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS)
+    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe)
+    xs = [synth.d_flat(2, u, 60, 29) for u in range(4)]
+    # device-resident fp32 input, decode_beams_batch
+    got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], prune_history=True)
+    for u, x in enumerate(xs):
+        exp = _oracle_expected(orc, x.astype(np.float64), {"prune_history": True})
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL, what="flat%d" % u)
+
+
+def test_hip_vs_oracle_bpe1024_lm_hotwords(lm, bpe):
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    dec = build_ctcdecoder(bpe, lm.path)
+    alpha = Alphabet.build_alphabet(bpe)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    hot = lm.hotwords(6, 2)
+    xs = [synth.d_words(4, u, 80, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0) for u in range(3)]
+    xs.append(synth.d_flat(4, 7, 40, 1024))
+    got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], hotwords=hot, prune_history=True)
+    for u, x in enumerate(xs):
+        exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL, what="bpe%d" % u)
+    texts = dec.decode_batch(None, xs, hotwords=hot)
+    assert texts == [g[0].text for g in got]
+
+
+def test_hip_ragged_batch_and_edge_cases(lm):
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, lm.path)
+    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    xs = [synth.d_words(2, u, T, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=6.0)
+          for u, T in enumerate([1, 0, 37, 5, 64, 2])]
+    texts = dec.decode_batch(None, xs)
+    assert texts == [orc.decode(x.astype(np.float64)) for x in xs]
+    # beam_width=1 and max beam bucket
+    for bw in (1, 200):
+        got = dec.decode_beams(xs[4], beam_width=bw)
+        exp = _oracle_expected(orc, xs[4].astype(np.float64), {"beam_width": bw})
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="bw%d" % bw)
+    with pytest.raises(NotImplementedError):
+        dec.decode_beams(xs[4], beam_width=300)
+    with pytest.raises(ValueError):
+        dec.decode(np.zeros((4, 7), dtype=np.float32))
+
+
+def test_hip_full_size_properties(lm, bpe):
+    """BASELINE-size frames (T=1000, V=1024, beam 100, 4-gram, hot words): the oracle is too slow for
+    a batch, so check size-independent properties: batch == single, device == host input,
+    permutation invariance, determinism, frame monotonicity, score identity."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(bpe, lm.path)
+    hot = lm.hotwords(6, 2)
+    xs = [synth.d_words(4, u, 1000, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0) for u in range(6)]
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    a = dec.decode_beams_batch(None, dev, hotwords=hot, prune_history=True)
+    b = dec.decode_beams_batch(None, xs, hotwords=hot, prune_history=True)  # host input path
+    c = dec.decode_beams_batch(None, dev[::-1], hotwords=hot, prune_history=True)[::-1]
+    single = [dec.decode_beams(x, hotwords=hot, prune_history=True) for x in dev[:2]]
+    for u in range(6):
+        ta = [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a[u]]
+        assert ta == [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in b[u]]
+        assert ta == [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in c[u]]
+        if u < 2:
+            assert ta == [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in single[u]]
+        scores = [o.lm_score for o in a[u]]
+        assert scores == sorted(scores, reverse=True) and len(scores) >= 1
+        assert scores[0] - scores[-1] <= 10.0 + 1e-9
+        for o in a[u]:
+            assert len(o.text.split()) == len(o.text_frames)
+            ends = [f[1][1] for f in o.text_frames]
+            starts = [f[1][0] for f in o.text_frames]
+            assert all(0 <= s < e <= 1000 for s, e in zip(starts, ends))
+            assert all(starts[k + 1] >= ends[k] - 0 for k in range(len(starts) - 1))
+
+
+def test_hip_oracle_one_full_length_utterance(lm, bpe):
+    """One full-size utterance (T=1000, V=1024, beam 100, 4-gram + hot words) against the oracle."""
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    dec = build_ctcdecoder(bpe, lm.path)
+    alpha = Alphabet.build_alphabet(bpe)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    hot = lm.hotwords(6, 2)
+    x = synth.d_words(4, 11, 1000, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0)
+    got = dec.decode_beams(x, hotwords=hot, prune_history=True)
+    exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="full")
