@@ -107,6 +107,14 @@ class Library:
                 "g.build()'). pyctcdecode_amd has no CPU fallback." % path
             )
         self.path = path
+        # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as the system
+        # one). If this library were loaded first it would pull in /opt/rocm's copy and torch's later
+        # initialisation would find "no HIP GPUs"; importing torch first makes both share torch's copy,
+        # which is also what makes torch device pointers valid in our kernels.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # standalone use: the system HIP runtime
+            pass
         self.dll = C.CDLL(path)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(self.dll, name)  # AttributeError if the symbol is not exported
