@@ -65,6 +65,13 @@ def cpu_baseline(lm, labels, hot, xs, cores):
     return texts, frames / dt, dt
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,7 +95,6 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
     os.environ["CTCDEC_DEVICE"] = str(local_rank)
 
     from pyctcdecode_amd import build_ctcdecoder
@@ -101,10 +107,24 @@ def main():
         dist.barrier()
     if rank != 0:
         lm, labels, hot = build_assets(cache, args.lm_words, args.lm_sentences)
-    decoder = build_ctcdecoder(labels, lm.path)
-
+    log("assets ready")
     xs = make_batch(lm, labels, rank * args.batch, args.batch, args.frames)
+    log("batch generated")
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # timed BEFORE the HIP runtime exists in this process: forking a pool afterwards is unsafe
+        cores = os.cpu_count() or 1
+        n_s = min(args.cpu_sample or 4 * cores, len(xs))
+        ref_texts, cpu_fps, cpu_dt = cpu_baseline(lm, labels, hot, xs[:n_s], cores)
+        cpu = (cores, n_s, ref_texts, cpu_fps, cpu_dt)
+        log("cpu baseline: %.0f frames/s on %d cores (%d utterances, %.1f s)" % (cpu_fps, cores, n_s, cpu_dt))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.set_device(local_rank)
+    decoder = build_ctcdecoder(labels, lm.path)
+    log("decoder built")
     dev = [torch.from_numpy(x).cuda() for x in xs]
+    log("logits on device")
     total_frames = args.batch * args.frames * world
 
     def step():
@@ -120,6 +140,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+        log("warmup step done: prune %.2f ms, beam %.2f ms, native call %.2f ms" % decoder.last_timing_ms)
     prune_ms, beam_ms = [], []
     fence()
     t0 = time.perf_counter()
@@ -129,6 +150,7 @@ def main():
         beam_ms.append(decoder.last_timing_ms[1])
     fence()
     dt = time.perf_counter() - t0
+    log("timed steps done: %.1f ms/step" % (1000 * dt / args.steps))
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -181,11 +203,8 @@ def main():
             "stages_ms": {"frame_prune": prune_avg, "beam_decode": beam_avg,
                           "frame_prune_GBps": (algo_bytes / (prune_avg * 1e-3) / 1e9) if prune_avg > 0 else None},
         }
-        if not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            n_s = args.cpu_sample or 8 * cores
-            n_s = min(n_s, len(xs))
-            ref_texts, cpu_fps, cpu_dt = cpu_baseline(lm, labels, hot, xs[:n_s], cores)
+        if cpu is not None:
+            cores, n_s, ref_texts, cpu_fps, cpu_dt = cpu
             out["cpu_baseline"] = {
                 "value": cpu_fps,
                 "unit": "frames/s",

@@ -289,6 +289,16 @@ class OracleState:
         self.partial_memo = partial_memo
 
 
+# Decoders live in a module-level registry so that fork-pool workers find them (and their LM) in
+# inherited memory instead of un-pickling them per task -- the reference does the same with its
+# class-level ``model_container`` (decoder.py:262-269, 289-290).
+_REGISTRY: Dict[int, "OracleDecoder"] = {}
+
+
+def _decode_by_key(key: int, kw: dict, logits: np.ndarray) -> str:
+    return _REGISTRY[key].decode(logits, **kw)
+
+
 class OracleDecoder:
     """Restated BeamSearchDecoderCTC.  ``labels`` must already be normalised
     (alphabet.py:34-110): blank is "", word separator is " " (char) or a leading U+2581 (BPE)."""
@@ -297,6 +307,8 @@ class OracleDecoder:
         self.labels = list(labels)
         self.is_bpe = is_bpe
         self.lm = lm
+        self._key = id(self)
+        _REGISTRY[self._key] = self
 
     # -- scoring (pure functions with memo) ----------------------------------------------------
     def _text_entry(self, memo, text: str, word: str, hw: HotwordOracle, eos: bool):
@@ -527,7 +539,8 @@ class OracleDecoder:
             return [self.decode(x, **kw) for x in logits_list]
         import functools
 
-        return pool.map(functools.partial(self.decode, **kw), logits_list)
+        # workers were forked after this decoder was built: look it up by key (nothing big is pickled)
+        return pool.map(functools.partial(_decode_by_key, self._key, kw), logits_list)
 
 
 def build_oracle(
