@@ -87,6 +87,7 @@ _PROTOS = {
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "ctcdec_result_free": (None, [_VP]),
+    "ctcdec_profile_phases": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),
     "ctcdec_last_error": (C.c_char_p, []),
     "ctcdec_version": (C.c_char_p, []),
 }

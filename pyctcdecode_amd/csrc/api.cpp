@@ -72,11 +72,13 @@ struct ctcdec_decoder {
   DevBuf d_tok, d_tok_hot, d_uni, d_ngr, d_pref, d_hot;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
-      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head;
+      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof;
+  bool profile = false;
+  unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
-                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head};
+                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof};
     for (DevBuf* b : all) b->drop();
   }
 };
@@ -441,6 +443,11 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
   ba.tok_pool = (EmitNode*)dec->w_tok.p;
   ba.tok_pool_head = (unsigned long long*)dec->w_head.p;
   ba.tok_pool_cap = tok_cap;
+  ba.prof = nullptr;
+  if (dec->profile) {
+    if (dec->w_prof.ensure(N_PROF * 8, &err) || be::zero(dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    ba.prof = (unsigned long long*)dec->w_prof.p;
+  }
   if (be::launch_beam(ba, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
   // results back
@@ -459,6 +466,7 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
   if (head && be::d2h(toks.data(), dec->w_tok.p, (size_t)head * sizeof(EmitNode), &err))
     return fail(CTCDEC_ERR_DEVICE, err);
   be::last_timing(&res->ms[0], &res->ms[1]);
+  if (dec->profile && be::d2h(dec->prof, dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
   for (int32_t u = 0; u < n_utts; ++u) {
     auto& beams = res->utts[(size_t)u];
@@ -560,6 +568,14 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {
   out->word_start = r->word_start.data();
   out->word_end = r->word_end.data();
   out->lm_state = r->states.data();
+  return CTCDEC_OK;
+}
+
+int ctcdec_profile_phases(ctcdec_decoder* dec, int32_t enable, uint64_t* ticks_out, int32_t n) {
+  if (!dec) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  dec->profile = enable != 0;
+  if (ticks_out)
+    for (int k = 0; k < n && k < N_PROF; ++k) ticks_out[k] = dec->prof[k];
   return CTCDEC_OK;
 }
 

@@ -63,6 +63,7 @@ struct BeamArgs {
   EmitNode* tok_pool;
   unsigned long long* tok_pool_head;  // [1]
   unsigned long long tok_pool_cap;
+  unsigned long long* prof;  // [N_PROF] phase cycle counters of utterance 0, or nullptr
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "backend.h"
 #include "beam_core.h"
@@ -328,22 +329,22 @@ struct GpuCtx {
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
     return cmp;
   }
+  __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)wall_clock64(); }
   __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {
     return atomicAdd(p, v);
   }
 };
 
-constexpr int BEAM_THREADS = 256;
-
-template <int BW>
-__global__ __launch_bounds__(BEAM_THREADS) void beam_decode(BeamArgs a, int surv_cap) {
+template <int BW, int NT>
+__global__ __launch_bounds__(NT) void beam_decode(BeamArgs a, int surv_cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = blockIdx.x;
   // compile-time layout: every LDS array sits at a constant offset (ds_* immediate offsets)
   LdsShape shape;
   shape.bw = BW;
   shape.cand = CAND_CHUNK;
-  shape.pool = 2 * CAND_CHUNK;
+  shape.pool = CAND_CHUNK + BW;
+  shape.sortn = 1024;
   shape.surv = surv_cap;
   LdsView view;
   lds_carve(view, (lds_bytes_t)smem, shape);
@@ -364,9 +365,27 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_decode(BeamArgs a, int surv
   io.tok_pool = a.tok_pool;
   io.tok_pool_head = a.tok_pool_head;
   io.tok_pool_cap = a.tok_pool_cap;
-  GpuCtx ctx{(int)threadIdx.x, BEAM_THREADS};
+  io.prof = (u == 0) ? a.prof : nullptr;
+  GpuCtx ctx{(int)threadIdx.x, NT};
   BeamDecoder<GpuCtx> dec(ctx, view, shape, a.tables, a.params, io);
   dec.run();
+}
+
+template <int BW, int NT>
+static int launch_beam_t(const BeamArgs& a, const LdsShape& shape, size_t lds, std::string* err) {
+  HIP_TRY(hipFuncSetAttribute((const void*)beam_decode<BW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((beam_decode<BW, NT>), dim3((unsigned)a.n_utts), dim3(NT), lds, g_stream, a, shape.surv);
+  return 0;
+}
+
+template <int NT>
+static int launch_beam_nt(const BeamArgs& a, const LdsShape& shape, size_t lds, std::string* err) {
+  switch (shape.bw) {
+    case 32: return launch_beam_t<32, NT>(a, shape, lds, err);
+    case 64: return launch_beam_t<64, NT>(a, shape, lds, err);
+    case 128: return launch_beam_t<128, NT>(a, shape, lds, err);
+    default: return launch_beam_t<256, NT>(a, shape, lds, err);
+  }
 }
 
 int launch_beam(const BeamArgs& a, std::string* err) {
@@ -377,20 +396,17 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     return -1;
   }
   if (a.n_utts > 0) {
-    dim3 grid((unsigned)a.n_utts), block(BEAM_THREADS);
-#define CTC_LAUNCH_BEAM(BWV)                                                                                  \
-  do {                                                                                                        \
-    HIP_TRY(hipFuncSetAttribute((const void*)beam_decode<BWV>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)lds));                                                                   \
-    hipLaunchKernelGGL(beam_decode<BWV>, grid, block, lds, g_stream, a, shape.surv);                          \
-  } while (0)
-    switch (shape.bw) {
-      case 32: CTC_LAUNCH_BEAM(32); break;
-      case 64: CTC_LAUNCH_BEAM(64); break;
-      case 128: CTC_LAUNCH_BEAM(128); break;
-      default: CTC_LAUNCH_BEAM(256); break;
+    // Threads per utterance: the recursion is latency-bound and a typical frame has ~100 candidates, so
+    // one wave per utterance (no cross-wave barriers) wins as soon as there are enough utterances to
+    // occupy the CUs; few utterances get four waves each. CTCDEC_BEAM_THREADS overrides (tuning only).
+    int nt = a.n_utts >= 128 ? 64 : 256;
+    if (const char* env = getenv("CTCDEC_BEAM_THREADS")) {
+      int v = atoi(env);
+      if (v == 64 || v == 128 || v == 256) nt = v;
     }
-#undef CTC_LAUNCH_BEAM
+    int rc = nt == 64 ? launch_beam_nt<64>(a, shape, lds, err)
+                      : nt == 128 ? launch_beam_nt<128>(a, shape, lds, err) : launch_beam_nt<256>(a, shape, lds, err);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(g_ev[2], g_stream));

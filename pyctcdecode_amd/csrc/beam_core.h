@@ -58,6 +58,7 @@ struct LdsShape {
   int bw;    // beam capacity (beam_width rounded up to 8)
   int cand;  // candidates per chunk
   int pool;  // pool capacity
+  int sortn; // sort-buffer entries (power of two >= pool)
   int surv;  // survivors per frame capacity
 };
 
@@ -72,7 +73,8 @@ CTC_HD LdsShape make_shape(int beam_width, int max_surv) {
   LdsShape s;
   s.bw = beam_bucket(beam_width);
   s.cand = CAND_CHUNK;
-  s.pool = 2 * CAND_CHUNK;
+  s.pool = CAND_CHUNK + s.bw;  // one chunk of fresh candidates + the best beam_width kept so far
+  s.sortn = 1024;              // >= pool for every bucket (pool <= 768)
   s.surv = (max_surv + 3) & ~3;
   return s;
 }
@@ -87,6 +89,7 @@ struct LdsView {
   // pool of merged, scored candidates of the current frame
   LPtr<double> p_score, p_logit;
   LPtr<uint32_t> p_arr, p_don;
+  LPtr<uint32_t> p_wid, p_m2;  // prefix/hot-word view of the candidate's new partial word
   // sort buffer (aliases the candidate arrays)
   LPtr<uint64_t> s_k0, s_k1;
   // scalars
@@ -97,7 +100,7 @@ struct LdsView {
   LPtr<uint32_t> hk_c;
   // gather temp used when the pool is compacted (aliases the tail of the candidate arrays)
   LPtr<double> g_score, g_logit;
-  LPtr<uint32_t> g_arr, g_don;
+  LPtr<uint32_t> g_arr, g_don, g_wid, g_m2;
   // survivors of the current frame (last: its size is the only run-time quantity)
   LPtr<Surv> surv;
 };
@@ -140,6 +143,8 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.p_logit = lds_take<double>(p, 8 * s.pool);
   o.p_arr = lds_take<uint32_t>(p, 4 * s.pool);
   o.p_don = lds_take<uint32_t>(p, 4 * s.pool);
+  o.p_wid = lds_take<uint32_t>(p, 4 * s.pool);
+  o.p_m2 = lds_take<uint32_t>(p, 4 * s.pool);
   o.scal = lds_take<uint32_t>(p, 4 * 16);
   o.smax = lds_take<uint64_t>(p, 8 * 2);
   o.keep = lds_take<uint32_t>(p, 4 * s.bw);
@@ -157,12 +162,14 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.rcnt = lds_take<uint32_t>(p, 4 * s.cand);
   o.table = lds_take<uint32_t>(p, 4 * 2 * s.cand);
   lds_bytes_t q = shared0;
-  o.s_k0 = lds_take<uint64_t>(q, 8 * s.pool);
-  o.s_k1 = lds_take<uint64_t>(q, 8 * s.pool);
+  o.s_k0 = lds_take<uint64_t>(q, 8 * s.sortn);
+  o.s_k1 = lds_take<uint64_t>(q, 8 * s.sortn);
   o.g_score = lds_take<double>(q, 8 * s.bw);
   o.g_logit = lds_take<double>(q, 8 * s.bw);
   o.g_arr = lds_take<uint32_t>(q, 4 * s.bw);
   o.g_don = lds_take<uint32_t>(q, 4 * s.bw);
+  o.g_wid = lds_take<uint32_t>(q, 4 * s.bw);
+  o.g_m2 = lds_take<uint32_t>(q, 4 * s.bw);
   if (q > p) p = q;
   o.surv = lds_take<Surv>(p, sizeof(Surv) * s.surv);
   return (size_t)(p - base);
@@ -190,7 +197,9 @@ struct UttIO {
   EmitNode* tok_pool;          // global pool of back-traced emission lists
   unsigned long long* tok_pool_head;
   unsigned long long tok_pool_cap;
+  unsigned long long* prof;  // optional per-phase cycle accumulators (diagnostics), else nullptr
 };
+constexpr int N_PROF = 12;
 
 // ---------------------------------------------------------------------------------------------
 CTC_HD uint64_t score_sort_key(double s) {
@@ -253,6 +262,18 @@ struct BeamDecoder {
   const UttIO& io;
   int cur;  // live beam buffer
   int N;    // live beams
+  unsigned long long t_last = 0;
+  unsigned long long t_acc[N_PROF] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  // diagnostics: attribute the cycles since the previous tick to `phase` (thread 0, only if asked)
+  template <int PHASE>
+  CTC_HD void tick() {
+    if (io.prof && ctx.tid == 0) {
+      unsigned long long now = ctx.clock();
+      t_acc[PHASE] += now - t_last;
+      t_last = now;
+    }
+  }
 
   CTC_HD BeamDecoder(Ctx& c, LdsView& l, const LdsShape& s, const DeviceTables& t, const DecodeParams& p,
                      const UttIO& i)
@@ -371,7 +392,8 @@ struct BeamDecoder {
   }
 
   // push one merged+scored candidate into the pool
-  CTC_HD void pool_push(double score, double logit, uint32_t arrival, uint32_t donor) {
+  CTC_HD void pool_push(double score, double logit, uint32_t arrival, uint32_t donor, uint32_t wid = 0,
+                        uint32_t m2 = 0) {
     uint32_t k = ctx.atomic_add(&L.scal[0], 1u);
     if (k >= (uint32_t)shape.pool) {
       ctx.atomic_or(&L.scal[6], ST_POOL_OVERFLOW);
@@ -381,6 +403,8 @@ struct BeamDecoder {
     L.p_logit[k] = logit;
     L.p_arr[k] = arrival;
     L.p_don[k] = donor;
+    L.p_wid[k] = wid;
+    L.p_m2[k] = m2;
   }
 
   CTC_HD void clear_table() {
@@ -457,6 +481,8 @@ struct BeamDecoder {
       L.g_logit[k] = L.p_logit[idx];
       L.g_arr[k] = L.p_arr[idx];
       L.g_don[k] = L.p_don[idx];
+      L.g_wid[k] = L.p_wid[idx];
+      L.g_m2[k] = L.p_m2[idx];
     }
     ctx.sync();
     for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
@@ -464,6 +490,8 @@ struct BeamDecoder {
       L.p_logit[k] = L.g_logit[k];
       L.p_arr[k] = L.g_arr[k];
       L.p_don[k] = L.g_don[k];
+      L.p_wid[k] = L.g_wid[k];
+      L.p_m2[k] = L.g_m2[k];
     }
     if (ctx.tid == 0) L.scal[0] = n;
     ctx.sync();
@@ -484,6 +512,47 @@ struct BeamDecoder {
     union { double d; uint64_t u; } c;
     c.d = s;
     return (c.u >> 63) ? ~c.u : (c.u | (1ull << 63));
+  }
+
+
+  // The partial word a candidate ends up with, seen through the prefix / hot-word tables:
+  // length, table flags (meta2 layout), LM word id and partial-word score.
+  struct PartView {
+    uint32_t pl, m2, wid;
+    double ps;
+  };
+  CTC_HD PartView new_partial(const BeamSoA& b, int i, uint32_t c, const TokInfo& tk, uint32_t br,
+                              uint64_t new_part_h) const {
+    PartView v;
+    if (br == 0) {  // blank / repeat: unchanged
+      v.pl = plen(b, i);
+      v.m2 = b.meta2[i];
+      v.wid = b.word_id[i];
+      v.ps = b.pscore[i];
+    } else if (br == BR_BOUNDARY && tk.len_clean > 0) {  // a new word starts with the clean label
+      uint32_t hmin = tab.tok_hot ? tab.tok_hot[c].min_len : 0;
+      uint32_t hcomp = tab.tok_hot ? tab.tok_hot[c].complete : 0;
+      v.pl = tk.len_clean;
+      v.m2 = (tk.start_flags & 0xFu) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
+      v.wid = tk.start_word_id;
+      v.ps = partial_score(tab, prm, tk.start_flags, hmin, v.pl);
+    } else if (br == BR_APPEND) {
+      uint32_t m2 = b.meta2[i];
+      uint32_t pf = 0, nw = 0, hmin = 0, hcomp = 0;
+      bool on = (m2 & PF_ON_TABLE) && prefix_lookup(tab.prefixes, tab.prefix_mask, new_part_h, &nw, &pf);
+      bool hon = (m2 & M2_HOT_ON) && hot_lookup(tab.hot, tab.hot_mask, new_part_h, &hmin, &hcomp);
+      v.pl = plen(b, i) + tk.len_raw;
+      v.m2 = (on ? (PF_ON_TABLE | (pf & 7u)) : 0u) | (hon ? M2_HOT_ON : 0u) | ((hon && hcomp) ? M2_HOT_COMPLETE : 0u) |
+             ((hon ? hmin : 0u) << 8);
+      v.wid = on ? nw : 0;
+      v.ps = partial_score(tab, prm, on ? pf : 0u, hon ? hmin : 0u, v.pl);
+    } else {  // space, or a bare boundary mark: the open word is empty
+      v.pl = 0;
+      v.m2 = EMPTY_PARTIAL_M2;
+      v.wid = 0;
+      v.ps = 0.0;
+    }
+    return v;
   }
 
   // Candidate generation + merge + scoring for survivors [s0, s1)
@@ -514,6 +583,7 @@ struct BeamDecoder {
       L.rcnt[q] = 0;
     }
     ctx.sync();
+    tick<3>();
     // G2: merge table (candidates of one label only ever merge with each other)
     for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
       uint32_t r = table_insert(q, (uint32_t)N);
@@ -523,6 +593,7 @@ struct BeamDecoder {
       ctx.atomic_add(&L.rcnt[r], 1u);
     }
     ctx.sync();
+    tick<4>();
     // S: owners fold, score, push
     for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
       uint32_t r = L.crep[q];
@@ -540,41 +611,26 @@ struct BeamDecoder {
       uint32_t c = L.surv[s].id;
       const TokInfo& tk = tab.tok[c];
       uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
-      double lmhw = b.lm_hw[i], ps = b.pscore[i];
-      uint32_t pl = plen(b, i);
-      if (br == BR_BOUNDARY || br == BR_SPACE) {
-        if (pl > 0) lmhw = b.c_lm_hw[i];
-        if (br == BR_BOUNDARY) {
-          pl = tk.len_clean;
-          ps = pl ? partial_score(tab, prm, tk.start_flags, tab.tok_hot ? tab.tok_hot[c].min_len : 0, pl) : 0.0;
-        } else {
-          pl = 0;
-          ps = 0.0;
-        }
-      } else if (br == BR_APPEND) {
-        uint32_t m2 = b.meta2[i];
-        uint32_t wid = 0, pf = 0, hmin = 0, hcomp = 0;
-        uint64_t kp = L.ck_part[q];
-        if (m2 & PF_ON_TABLE) prefix_lookup(tab.prefixes, tab.prefix_mask, kp, &wid, &pf);
-        if (m2 & M2_HOT_ON) hot_lookup(tab.hot, tab.hot_mask, kp, &hmin, &hcomp);
-        pl = pl + tk.len_raw;
-        ps = partial_score(tab, prm, pf, hmin, pl);
-      }
-      double score = total_score(tab, lg, lmhw, ps, pl);
+      double lmhw = b.lm_hw[i];
+      if ((br == BR_BOUNDARY || br == BR_SPACE) && plen(b, i) > 0) lmhw = b.c_lm_hw[i];
+      PartView pv = new_partial(b, i, c, tk, br, L.ck_part[q]);
+      double score = total_score(tab, lg, lmhw, pv.ps, pv.pl);
       ctx.atomic_max64(&L.smax[0], asc_key(score));
       if (score >= thr_prev) {
-        uint32_t jpos = s;
         uint32_t imax = qmax % (uint32_t)N;
-        pool_push(score, lg, jpos * (uint32_t)N + (uint32_t)i, (jpos << 8) | imax);
+        pool_push(score, lg, s * (uint32_t)N + (uint32_t)i, (s << 8) | imax, pv.wid, pv.m2);
       }
     }
     ctx.sync();
+    tick<5>();
     clear_table();
     ctx.sync();
+    tick<6>();
   }
 
-  // Build beam `dst` of the next table from pool entry `idx`
-  CTC_HD void build_beam(BeamSoA& nb, int dst, uint32_t idx, int frame, bool keep_it) {
+  // Build beam `dst` of the next table from pool entry `idx` (payload = the donor, i.e. the
+  // last-arriving duplicate: decoder.py:221-223)
+  CTC_HD void build_beam(BeamSoA& nb, int dst, uint32_t idx, int frame) {
     BeamSoA& b = L.beams[cur];
     uint32_t don = L.p_don[idx];
     uint32_t s = don >> 8;
@@ -583,20 +639,22 @@ struct BeamDecoder {
     const TokInfo& tk = tab.tok[c];
     uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
     uint32_t pl = plen(b, i);
-    // defaults: keep prefix (blank / repeat)
     uint64_t th = b.text_h[i], ph = b.part_h[i], hh = b.hist_h[i];
-    double lmhw = b.lm_hw[i], ps = b.pscore[i];
-    uint32_t tnode = b.text_node[i], cnode = b.comp_node[i], wid = b.word_id[i], m2 = b.meta2[i];
+    double lmhw = b.lm_hw[i];
+    uint32_t tnode = b.text_node[i], cnode = b.comp_node[i];
     int32_t pst = b.pstart[i], pen = b.pend[i];
     uint32_t enode = b.emit_node[i], depth = b.depth[i];
     uint64_t cth = b.c_text_h[i], chh = b.c_hist_h[i];
     double clm = b.c_lm_hw[i];
+    // the new partial word as seen through the tables was resolved when the candidate was scored
+    uint32_t m2 = L.p_m2[idx], wid = L.p_wid[idx];
+    uint32_t npl = pl;
     if (br == 0) {
       if (!(tk.flags & TK_BLANK)) pen = frame + 1;  // decoder.py:453-461
     } else {
       int32_t wst = pst, wen = pen;
       if (br == BR_BOUNDARY || br == BR_SPACE) {
-        if (pl > 0) {
+        if (pl > 0) {  // the open word is completed (decoder.py:483-495, 501-515)
           th = cth;
           hh = chh;
           lmhw = clm;
@@ -604,61 +662,38 @@ struct BeamDecoder {
         }
         if (br == BR_BOUNDARY) {
           ph = tk.h_clean;
-          uint32_t npl = tk.len_clean;
-          uint32_t hmin = tab.tok_hot ? tab.tok_hot[c].min_len : 0;
-          uint32_t hcomp = tab.tok_hot ? tab.tok_hot[c].complete : 0;
-          if (npl > 0) {
-            m2 = (tk.start_flags & 0xFu) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
-            wid = tk.start_word_id;
-            ps = partial_score(tab, prm, tk.start_flags, hmin, npl);
-          } else {
-            m2 = EMPTY_PARTIAL_M2;
-            wid = 0;
-            ps = 0.0;
-          }
-          pl = npl;
+          npl = tk.len_clean;
           pst = frame;
           pen = frame + 1;
         } else {
           ph = 0;
-          pl = 0;
-          m2 = EMPTY_PARTIAL_M2;
-          wid = 0;
-          ps = 0.0;
+          npl = 0;
           pst = -1;
           pen = -1;
         }
-      } else {  // BR_APPEND
+      } else {  // BR_APPEND (decoder.py:518-534)
         ph = str_concat(ph, tk.pow_raw, tk.h_raw);
-        uint32_t pf = 0, nw = 0, hmin = 0, hcomp = 0;
-        bool on = (m2 & PF_ON_TABLE) && prefix_lookup(tab.prefixes, tab.prefix_mask, ph, &nw, &pf);
-        bool hon = (m2 & M2_HOT_ON) && hot_lookup(tab.hot, tab.hot_mask, ph, &hmin, &hcomp);
-        pl = pl + tk.len_raw;
-        m2 = (on ? (PF_ON_TABLE | (pf & 7u)) : 0u) | (hon ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) |
-             ((hon ? hmin : 0u) << 8);
-        wid = on ? nw : 0;
-        ps = partial_score(tab, prm, on ? pf : 0u, hon ? hmin : 0u, pl);
+        npl = pl + tk.len_raw;
         pst = pst < 0 ? frame : pst;
         pen = frame + 1;
       }
       cnode = 0;
-      if (keep_it) {
-        uint32_t e = ctx.atomic_add(&L.scal[2], 1u);
-        if (e >= io.emit_cap) {
-          ctx.atomic_or(&L.scal[6], ST_EMIT_OVERFLOW);
-          e = io.emit_cap - 1;
-        }
-        EmitNode en;
-        en.parent = enode;
-        en.tok_branch = c | (br << 16);
-        en.wstart = wst;
-        en.wend = wen;
-        io.emit_nodes[e] = en;
-        enode = e;
-        depth += 1;
+      uint32_t e = ctx.atomic_add(&L.scal[2], 1u);
+      if (e >= io.emit_cap) {
+        ctx.atomic_or(&L.scal[6], ST_EMIT_OVERFLOW);
+        e = io.emit_cap - 1;
       }
+      EmitNode en;
+      en.parent = enode;
+      en.tok_branch = c | (br << 16);
+      en.wstart = wst;
+      en.wend = wen;
+      io.emit_nodes[e] = en;
+      enode = e;
+      depth += 1;
     }
-    if (!keep_it) return;
+    double ps = 0.0;
+    if (npl > 0) ps = partial_score(tab, prm, m2 & 7u, (m2 & M2_HOT_ON) ? (m2 >> 8) : 0u, npl);
     nb.logit[dst] = L.p_logit[idx];
     nb.lm_hw[dst] = lmhw;
     nb.pscore[dst] = ps;
@@ -672,7 +707,7 @@ struct BeamDecoder {
     nb.comp_node[dst] = cnode;
     nb.emit_node[dst] = enode;
     nb.word_id[dst] = wid;
-    nb.meta1[dst] = c | (pl << 16);
+    nb.meta1[dst] = c | (npl << 16);
     nb.meta2[dst] = m2;
     nb.depth[dst] = depth;
     nb.pstart[dst] = pst;
@@ -708,15 +743,19 @@ struct BeamDecoder {
       L.scal[4] = 0;
       L.smax[0] = asc_key(-INFINITY);
     }
+    tick<9>();
     load_survivors(t);
     ctx.sync();
+    tick<0>();
     compute_modes(ns);
+    tick<1>();
     BeamSoA& b = L.beams[cur];
     if (L.scal[4]) {
       for (int i = ctx.tid; i < N; i += ctx.nt)
         if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
     }
     ctx.sync();
+    tick<2>();
     uint32_t per = (uint32_t)shape.cand / (uint32_t)N;
     if (per == 0) per = 1;
     for (uint32_t s0 = 0; s0 < ns; s0 += per) {
@@ -732,6 +771,7 @@ struct BeamDecoder {
     uint32_t pool_n = L.scal[0];
     double thr = sortable_to_max() + prm.beam_prune_logp;
     uint32_t n = sort_pool(pool_n, thr);
+    tick<7>();
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     BeamSoA& nb = L.beams[cur ^ 1];
     if (final_stage) {
@@ -771,7 +811,7 @@ struct BeamDecoder {
       uint32_t dst = 0;
       for (uint32_t r2 = 0; r2 < r; ++r2) dst += L.keep[r2];
       uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
-      build_beam(nb, (int)dst, idx, frame, true);
+      build_beam(nb, (int)dst, idx, frame);
       ctx.atomic_max(&L.scal[7], dst + 1);
     }
     ctx.sync();
@@ -780,6 +820,7 @@ struct BeamDecoder {
     ctx.sync();
     if (ctx.tid == 0) L.scal[7] = 0;
     ctx.sync();
+    tick<8>();
   }
 
   // ---- init / finalisation -------------------------------------------------------------------
@@ -978,8 +1019,13 @@ struct BeamDecoder {
 
   CTC_HD void run() {
     init();
+    if (io.prof && ctx.tid == 0) t_last = ctx.clock();
     for (int t = 0; t < io.T; ++t) step(t);
+    tick<9>();
     finalise();
+    tick<10>();
+    if (io.prof && ctx.tid == 0)
+      for (int k = 0; k < N_PROF; ++k) io.prof[k] = t_acc[k];
   }
 };
 

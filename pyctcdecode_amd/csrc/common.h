@@ -255,27 +255,50 @@ CTC_HD bool ngram_lookup(const NgramEntry* tab, uint64_t mask, uint64_t key, flo
 // CPU restatement and DESIGN.md for the state convention).  Returns log10 p as fp32.
 CTC_HD float lm_base_score(const DeviceTables& t, const LmState& in, uint32_t wid, LmState* out) {
   UnigramEntry u = t.unigrams[wid];
+  const int in_len = in.len;
+  const int max_n = !t.ngrams ? 1 : ((int)t.lm_order < in_len + 1 ? (int)t.lm_order : in_len + 1);
+  // First probe of every order is issued up front (independent loads overlap their latency);
+  // kenlm walks the orders one after the other, the result is the same longest match.
+  uint64_t keys[MAX_CTX + 2];
+  uint64_t slots[MAX_CTX + 2];
+  NgramEntry ent[MAX_CTX + 2];
+#pragma unroll
+  for (int n = 2; n <= MAX_CTX + 1; ++n) {
+    keys[n] = 0;
+    slots[n] = 0;
+    ent[n].key = 0;
+    ent[n].prob = 0.f;
+    ent[n].backoff = 0.f;
+    if (n <= max_n) {
+      uint64_t k = ngram_key_begin((uint32_t)n);
+#pragma unroll
+      for (int c = MAX_CTX - 1; c >= 0; --c)
+        if (c <= n - 2) k = ngram_key_push(k, in.words[c]);
+      k = ngram_key_end(ngram_key_push(k, wid));
+      keys[n] = k;
+      slots[n] = mix64(k) & t.ngram_mask;
+      ent[n] = t.ngrams[slots[n]];
+    }
+  }
   float prob = u.prob;
   float obo[MAX_CTX + 1];
 #pragma unroll
   for (int k = 0; k <= MAX_CTX; ++k) obo[k] = 0.f;
   obo[0] = u.backoff;
   int matched = 1;
-  const int in_len = in.len;
-  const int max_n = (int)t.lm_order < in_len + 1 ? (int)t.lm_order : in_len + 1;
-  bool go = t.ngrams != nullptr;
+  bool go = true;
 #pragma unroll
   for (int n = 2; n <= MAX_CTX + 1; ++n) {
     if (go && n <= max_n) {
-      uint64_t k = ngram_key_begin((uint32_t)n);
-#pragma unroll
-      for (int c = MAX_CTX - 1; c >= 0; --c)
-        if (c <= n - 2) k = ngram_key_push(k, in.words[c]);
-      k = ngram_key_end(ngram_key_push(k, wid));
-      float p, b;
-      if (ngram_lookup(t.ngrams, t.ngram_mask, k, &p, &b)) {
-        prob = p;
-        obo[n - 1] = b;
+      NgramEntry e = ent[n];
+      uint64_t s = slots[n];
+      while (e.key != keys[n] && e.key != 0) {  // linear probing past a collision (rare)
+        s = (s + 1) & t.ngram_mask;
+        e = t.ngrams[s];
+      }
+      if (e.key == keys[n]) {
+        prob = e.prob;
+        obo[n - 1] = e.backoff;
         matched = n;
       } else {
         go = false;

@@ -25,6 +25,7 @@ struct SeqCtx {
   void atomic_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
   void atomic_max64(uint64_t* p, uint64_t v) { if (v > *p) *p = v; }
   uint32_t atomic_cas(uint32_t* p, uint32_t cmp, uint32_t val) { uint32_t o = *p; if (o == cmp) *p = val; return o; }
+  unsigned long long clock() { return 0; }
   unsigned long long global_add(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 };
 
@@ -132,6 +133,7 @@ int launch_beam(const BeamArgs& a, std::string*) {
     io.tok_pool = a.tok_pool;
     io.tok_pool_head = a.tok_pool_head;
     io.tok_pool_cap = a.tok_pool_cap;
+    io.prof = nullptr;
     SeqCtx ctx;
     BeamDecoder<SeqCtx> dec(ctx, view, shape, a.tables, a.params, io);
     dec.run();
