@@ -159,10 +159,11 @@ def main():
         lib = decoder._lib
         lib.dll.ctcdec_profile_phases(decoder._handle, 1, None, 0)
         step()
-        ticks = (C.c_uint64 * 12)()
-        lib.dll.ctcdec_profile_phases(decoder._handle, 0, ticks, 12)
-        names = ["load", "modes", "completions", "keys", "merge", "score", "clear", "sort", "rebuild", "rest",
-                 "finalise", "-"]
+        ticks = (C.c_uint64 * 24)()
+        lib.dll.ctcdec_profile_phases(decoder._handle, 0, ticks, 24)
+        names = ["load", "modes", "completions(bar)", "keys", "merge", "score(bar)", "clear", "sort.rank", "rebuild.tail",
+                 "rest", "finalise", "comp.src", "comp.probe", "comp.store", "score.fold", "score.probe", "score.push",
+                 "sort.zero", "sort.compact", "rebuild.hist", "rebuild.dup", "rebuild.build", "comp.syncmem", "-"]
         tot = float(sum(ticks)) or 1.0
         log("phase ticks (utterance 0, 100 MHz): " + ", ".join(
             "%s %.0f us (%.0f%%)" % (n, t / 100.0, 100.0 * t / tot) for n, t in zip(names, ticks) if t))

@@ -163,7 +163,7 @@ int ctcdec_result_timing(const ctcdec_result* r, double* ms3);
 void ctcdec_result_free(ctcdec_result* r);
 
 /* Diagnostics: enable/disable per-phase tick accumulation (100 MHz wall clock) for utterance 0 of the
- * following decode calls and read the 12 counters of the last one (0 load, 1 modes, 2 completions,
+ * following decode calls and read the 24 counters of the last one (0 load, 1 modes, 2 completions,
  * 3 keys, 4 merge, 5 score, 6 clear, 7 sort, 8 rebuild, 9 rest, 10 finalise). No reference analogue. */
 int ctcdec_profile_phases(ctcdec_decoder* dec, int32_t enable, uint64_t* ticks_out, int32_t n);
 

@@ -307,7 +307,13 @@ int launch_prune(const PruneArgs& a, std::string* err) {
 // ---------------------------------------------------------------------------------------------
 struct GpuCtx {
   int tid, nt;
-  __device__ __forceinline__ void sync() { __syncthreads(); }
+  // LDS-only barrier: waits for this wave's LDS traffic, not for global loads/stores in flight
+  // (prefetches and arena stores keep going across it)
+  __device__ __forceinline__ void sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  // full barrier: also makes this workgroup's global stores visible to its other waves
+  __device__ __forceinline__ void sync_mem() { __syncthreads(); }
   // LDS atomics (ds_*): workgroup scope, relaxed -- phases are separated by s_barrier
   __device__ __forceinline__ uint32_t atomic_add(CTC_LDS uint32_t* p, uint32_t v) {
     return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -329,6 +335,20 @@ struct GpuCtx {
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
     return cmp;
   }
+  // max over the 64 lanes of the calling wave (all lanes must call it)
+  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      uint64_t o = __shfl_xor((unsigned long long)v, off, 64);
+      v = o > v ? o : v;
+    }
+    return v;
+  }
+  __device__ __forceinline__ bool is_wave_leader() { return (threadIdx.x & 63) == 0; }
+  __device__ __forceinline__ int wave_width() { return 64; }
+  __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
+  __device__ __forceinline__ void use(double x) { asm volatile("" ::"v"(x)); }
   __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)wall_clock64(); }
   __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {
     return atomicAdd(p, v);

@@ -47,6 +47,13 @@ struct BeamSoA {
   LPtr<int32_t> pstart, pend;
 };
 
+// what the recursion needs to know about a label, staged in LDS for the first survivors of a frame
+struct TokLite {  // 56 B
+  uint64_t h_raw, pow_raw, h_clean;
+  uint32_t len_raw, len_clean, flags, start_flags, start_word_id, hot_min, hot_complete, pad;
+};
+constexpr int TOK_STAGE = 32;
+
 struct Surv {  // one surviving label of the current frame
   uint32_t id;
   uint32_t mode;  // MODE_* | first_non_repeat << 8
@@ -80,7 +87,8 @@ CTC_HD LdsShape make_shape(int beam_width, int max_surv) {
 }
 
 struct LdsView {
-  BeamSoA beams[2];
+  BeamSoA beams0;  // both beam tables: every array holds 2*bw entries, table k starts at k*bw
+  int bw;
   // candidates of the current chunk
   LPtr<uint64_t> ck_text, ck_part;
   LPtr<double> c_logit;
@@ -96,12 +104,14 @@ struct LdsView {
   LPtr<uint32_t> scal;  // [0] pool_n [1] text_next [2] emit_next [3] flag [4] need_comp [5] n_sel [6] status [7] n_new [8] tok_len
   LPtr<uint64_t> smax;  // [0] sortable max score [1] token pool base
   LPtr<uint32_t> keep;  // per selected beam: kept by history prune
+  LPtr<uint32_t> sel;   // pool indices of the selected candidates in (score desc, arrival asc) order
   LPtr<uint64_t> hk_h, hk_p;  // history-prune keys of the selected beams
   LPtr<uint32_t> hk_c;
   // gather temp used when the pool is compacted (aliases the tail of the candidate arrays)
   LPtr<double> g_score, g_logit;
   LPtr<uint32_t> g_arr, g_don, g_wid, g_m2;
   // survivors of the current frame (last: its size is the only run-time quantity)
+  LPtr<TokLite> stok;  // label constants of survivors [0, TOK_STAGE)
   LPtr<Surv> surv;
 };
 
@@ -137,8 +147,8 @@ CTC_HD void carve_beams(BeamSoA& b, lds_bytes_t& p, int bw) {
 // Carves `base` into the view; returns bytes used.
 CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   lds_bytes_t p = base;
-  carve_beams(o.beams[0], p, s.bw);
-  carve_beams(o.beams[1], p, s.bw);
+  carve_beams(o.beams0, p, 2 * s.bw);
+  o.bw = s.bw;
   o.p_score = lds_take<double>(p, 8 * s.pool);
   o.p_logit = lds_take<double>(p, 8 * s.pool);
   o.p_arr = lds_take<uint32_t>(p, 4 * s.pool);
@@ -148,6 +158,7 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.scal = lds_take<uint32_t>(p, 4 * 16);
   o.smax = lds_take<uint64_t>(p, 8 * 2);
   o.keep = lds_take<uint32_t>(p, 4 * s.bw);
+  o.sel = lds_take<uint32_t>(p, 4 * s.bw);
   o.hk_h = lds_take<uint64_t>(p, 8 * s.bw);
   o.hk_p = lds_take<uint64_t>(p, 8 * s.bw);
   o.hk_c = lds_take<uint32_t>(p, 4 * s.bw);
@@ -171,6 +182,7 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.g_wid = lds_take<uint32_t>(q, 4 * s.bw);
   o.g_m2 = lds_take<uint32_t>(q, 4 * s.bw);
   if (q > p) p = q;
+  o.stok = lds_take<TokLite>(p, sizeof(TokLite) * TOK_STAGE);
   o.surv = lds_take<Surv>(p, sizeof(Surv) * s.surv);
   return (size_t)(p - base);
 }
@@ -199,7 +211,7 @@ struct UttIO {
   unsigned long long tok_pool_cap;
   unsigned long long* prof;  // optional per-phase cycle accumulators (diagnostics), else nullptr
 };
-constexpr int N_PROF = 12;
+constexpr int N_PROF = 24;
 
 // ---------------------------------------------------------------------------------------------
 CTC_HD uint64_t score_sort_key(double s) {
@@ -262,8 +274,10 @@ struct BeamDecoder {
   const UttIO& io;
   int cur;  // live beam buffer
   int N;    // live beams
+  uint32_t pf_cnt = 0, pf_id = 0;  // survivors of the NEXT frame, fetched one frame ahead
+  double pf_lp = 0.0;
   unsigned long long t_last = 0;
-  unsigned long long t_acc[N_PROF] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_acc[N_PROF] = {};
 
   // diagnostics: attribute the cycles since the previous tick to `phase` (thread 0, only if asked)
   template <int PHASE>
@@ -279,43 +293,91 @@ struct BeamDecoder {
                      const UttIO& i)
       : ctx(c), L(l), shape(s), tab(t), prm(p), io(i), cur(0), N(1) {}
 
+  // beam table `which` (0/1) as a by-value bundle of LDS pointers (no run-time indexed struct arrays:
+  // those would force the whole view into scratch memory)
+  CTC_HD BeamSoA beams_at(int which) const {
+    const int off = which * L.bw;
+    const BeamSoA& a = L.beams0;
+    BeamSoA r;
+    r.logit.p = a.logit.p + off;
+    r.lm_hw.p = a.lm_hw.p + off;
+    r.pscore.p = a.pscore.p + off;
+    r.c_lm_hw.p = a.c_lm_hw.p + off;
+    r.text_h.p = a.text_h.p + off;
+    r.part_h.p = a.part_h.p + off;
+    r.hist_h.p = a.hist_h.p + off;
+    r.c_text_h.p = a.c_text_h.p + off;
+    r.c_hist_h.p = a.c_hist_h.p + off;
+    r.text_node.p = a.text_node.p + off;
+    r.comp_node.p = a.comp_node.p + off;
+    r.emit_node.p = a.emit_node.p + off;
+    r.word_id.p = a.word_id.p + off;
+    r.meta1.p = a.meta1.p + off;
+    r.meta2.p = a.meta2.p + off;
+    r.depth.p = a.depth.p + off;
+    r.pstart.p = a.pstart.p + off;
+    r.pend.p = a.pend.p + off;
+    return r;
+  }
+
   CTC_HD uint32_t last_char(const BeamSoA& b, int i) const { return b.meta1[i] & 0xFFFFu; }
   CTC_HD uint32_t plen(const BeamSoA& b, int i) const { return b.meta1[i] >> 16; }
 
   // ---- completion of beam i's open word: the (text (+) partial) prefix ----------------------
-  CTC_HD void make_completion(BeamSoA& b, int i) {
+  CTC_HD void make_completion(const BeamSoA& b, int i) {
     uint32_t idx = ctx.atomic_add(&L.scal[1], 1u);
     if (idx >= io.text_cap) {
       ctx.atomic_or(&L.scal[6], ST_TEXT_OVERFLOW);
       idx = io.text_cap - 1;
     }
     const TextNode& src = io.text_nodes[b.text_node[i]];
-    TextNode nn;
-    uint32_t m2 = b.meta2[i];
+    TextNode& dst = io.text_nodes[idx];
+    const uint32_t m2 = b.meta2[i];
     double raw = src.raw_lm;
+    if (io.prof) {
+      ctx.use(raw);
+      tick<11>();
+    }
     if (tab.has_lm) {
-      float base = lm_base_score(tab, src.state, b.word_id[i], &nn.state);
+      float base = lm_base_score(tab, src.state, b.word_id[i], &dst.state);
+      if (io.prof) {
+        ctx.use((double)base);
+        tick<12>();
+      }
       raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
     } else {
-      nn.state = src.state;
-    }
-    uint64_t wh = b.part_h[i];
-    nn.text_h = text_push(src.text_h, wh);
-    nn.raw_lm = raw;
-    nn.hw_cnt = src.hw_cnt + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
-    nn.lm_hw = raw + prm.hot_weight * (double)nn.hw_cnt;
-    uint32_t rc = src.ring_cnt + 1 > tab.n_hist ? tab.n_hist : src.ring_cnt + 1;
-    nn.ring_cnt = rc;
-    nn.ring[0] = wh;
+      dst.state.len = src.state.len;
 #pragma unroll
-    for (int k = 1; k < MAX_CTX; ++k) nn.ring[k] = (uint32_t)k < rc ? src.ring[k - 1] : 0;
-    nn.hist_h = hist_hash(nn.ring, rc);
-    nn.pad0 = 0;
-    io.text_nodes[idx] = nn;
+      for (int k = 0; k < MAX_CTX; ++k) {
+        dst.state.words[k] = src.state.words[k];
+        dst.state.backoff[k] = src.state.backoff[k];
+      }
+    }
+    const uint64_t wh = b.part_h[i];
+    const uint64_t th = text_push(src.text_h, wh);
+    const uint32_t cnt = src.hw_cnt + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
+    const double lmhw = raw + prm.hot_weight * (double)cnt;
+    const uint32_t rc = src.ring_cnt + 1 > tab.n_hist ? tab.n_hist : src.ring_cnt + 1;
+    // history ring (newest first) and its hash, without run-time indexed temporaries
+    uint64_t hh = 0x9E3779B97F4A7C15ull + rc;
+#pragma unroll
+    for (int k = MAX_CTX - 1; k >= 0; --k) {
+      uint64_t rk = k == 0 ? wh : ((uint32_t)k < rc ? src.ring[k > 0 ? k - 1 : 0] : 0ull);
+      dst.ring[k] = rk;
+      if ((uint32_t)k < rc) hh = mix64(hh ^ rk) + 0x632BE59BD9B4E019ull;
+    }
+    dst.text_h = th;
+    dst.raw_lm = raw;
+    dst.lm_hw = lmhw;
+    dst.hist_h = hh;
+    dst.hw_cnt = cnt;
+    dst.ring_cnt = rc;
+    dst.pad0 = 0;
     b.comp_node[i] = idx;
-    b.c_text_h[i] = nn.text_h;
-    b.c_lm_hw[i] = nn.lm_hw;
-    b.c_hist_h[i] = nn.hist_h;
+    b.c_text_h[i] = th;
+    b.c_lm_hw[i] = lmhw;
+    b.c_hist_h[i] = hh;
+    tick<13>();
   }
 
   // ---- branch of candidate (survivor s, beam i): decoder.py:452,474,500,518 -----------------
@@ -329,64 +391,132 @@ struct BeamDecoder {
   }
 
   // ---- one frame ---------------------------------------------------------------------------
-  CTC_HD void load_survivors(int t) {
-    uint32_t ns = io.surv_cnt[t];
-    const uint16_t* ids = io.surv_id + (size_t)t * prm.max_surv;
-    const double* lps = io.surv_lp + (size_t)t * prm.max_surv;
-    for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
-      L.surv[s].id = ids[s];
-      L.surv[s].lp = lps[s];
+  // Label constants of survivor s, read field by field: LDS for the first TOK_STAGE survivors of the
+  // frame (staged by load_survivors), L2 beyond. (No struct copies: those would live in scratch.)
+  struct TkView {
+    const BeamDecoder* d;
+    uint32_t s;
+#define CTC_TK_FIELD(type, name, global_expr)                                            \
+  CTC_HD type name() const {                                                             \
+    if (s < (uint32_t)TOK_STAGE) return d->L.stok[s].name;                               \
+    const uint32_t c = d->L.surv[s].id;                                                  \
+    (void)c;                                                                             \
+    return global_expr;                                                                  \
+  }
+    CTC_TK_FIELD(uint64_t, h_raw, d->tab.tok[c].h_raw)
+    CTC_TK_FIELD(uint64_t, pow_raw, d->tab.tok[c].pow_raw)
+    CTC_TK_FIELD(uint64_t, h_clean, d->tab.tok[c].h_clean)
+    CTC_TK_FIELD(uint32_t, len_raw, d->tab.tok[c].len_raw)
+    CTC_TK_FIELD(uint32_t, len_clean, d->tab.tok[c].len_clean)
+    CTC_TK_FIELD(uint32_t, flags, d->tab.tok[c].flags)
+    CTC_TK_FIELD(uint32_t, start_flags, d->tab.tok[c].start_flags)
+    CTC_TK_FIELD(uint32_t, start_word_id, d->tab.tok[c].start_word_id)
+    CTC_TK_FIELD(uint32_t, hot_min, (d->tab.tok_hot ? d->tab.tok_hot[c].min_len : 0u))
+    CTC_TK_FIELD(uint32_t, hot_complete, (d->tab.tok_hot ? d->tab.tok_hot[c].complete : 0u))
+#undef CTC_TK_FIELD
+  };
+  CTC_HD TkView tok_of(uint32_t s) const { return TkView{this, s}; }
+
+  // stage label c's constants for survivor slot s (field-wise global loads -> LDS stores)
+  CTC_HD void stage_tok(uint32_t s, uint32_t c) {
+    const TokInfo& g = tab.tok[c];
+    L.stok[s].h_raw = g.h_raw;
+    L.stok[s].pow_raw = g.pow_raw;
+    L.stok[s].h_clean = g.h_clean;
+    L.stok[s].len_raw = g.len_raw;
+    L.stok[s].len_clean = g.len_clean;
+    L.stok[s].flags = g.flags;
+    L.stok[s].start_flags = g.start_flags;
+    L.stok[s].start_word_id = g.start_word_id;
+    L.stok[s].hot_min = tab.tok_hot ? tab.tok_hot[c].min_len : 0u;
+    L.stok[s].hot_complete = tab.tok_hot ? tab.tok_hot[c].complete : 0u;
+  }
+
+  // issue the loads of frame t's survivor list; they are consumed by load_survivors(t) one frame later
+  CTC_HD void prefetch(int t) {
+    if (t >= io.T) return;
+    pf_cnt = io.surv_cnt[t];
+    if (ctx.tid < prm.max_surv) {
+      pf_id = io.surv_id[(size_t)t * prm.max_surv + ctx.tid];
+      pf_lp = io.surv_lp[(size_t)t * prm.max_surv + ctx.tid];
     }
   }
 
-  CTC_HD void compute_modes(uint32_t ns) {
-    BeamSoA& b = L.beams[cur];
-    // first beam that does not repeat the label (only BPE needs it)
-    for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
-      uint32_t c = L.surv[s].id;
-      uint32_t fl = tab.tok[c].flags;
-      uint32_t first = (uint32_t)N;
-      uint32_t mode;
-      if (fl & TK_BLANK) {
-        mode = MODE_A;
-      } else if (!tab.is_bpe) {
-        mode = (fl & TK_SPACE) ? MODE_C : MODE_D;
-        if (mode == MODE_C) ctx.atomic_or(&L.scal[4], 1u);
-      } else {
-        int i = 0;
-        while (i < N && last_char(b, i) == c) ++i;
-        first = (uint32_t)i;
-        mode = MODE_D;  // resolved below
-      }
-      L.surv[s].mode = mode | (first << 8);
+  CTC_HD uint32_t load_survivors(int t) {
+    const uint32_t ns = pf_cnt;
+    const uint16_t* ids = io.surv_id + (size_t)t * prm.max_surv;
+    const double* lps = io.surv_lp + (size_t)t * prm.max_surv;
+    if ((uint32_t)ctx.tid < ns) {
+      L.surv[ctx.tid].id = pf_id;
+      L.surv[ctx.tid].lp = pf_lp;
+      if (ctx.tid < TOK_STAGE) stage_tok((uint32_t)ctx.tid, pf_id);
     }
-    ctx.sync();
-    if (tab.is_bpe && ctx.tid == 0) {
+    for (uint32_t s = ctx.tid + ctx.nt; s < ns; s += ctx.nt) {
+      uint32_t id = ids[s];
+      L.surv[s].id = id;
+      L.surv[s].lp = lps[s];
+      if (s < (uint32_t)TOK_STAGE) stage_tok(s, id);
+    }
+    return ns;
+  }
+
+  // Branch mode of every surviving label. For BPE vocabularies the force_next_break flag of
+  // decoder.py:442,474-482 threads through the labels in iteration order; each label acts on the flag
+  // as identity / clear / set, so the flag seen by label s is that of the last non-identity label
+  // before it: one ballot pair per 64 labels instead of a serial walk.
+  CTC_HD void compute_modes(uint32_t ns) {
+    const BeamSoA b = beams_at(cur);
+    if (!tab.is_bpe) {
+      for (uint32_t s = ctx.tid; s < ns; s += ctx.nt) {
+        uint32_t fl = tok_of(s).flags();
+        uint32_t mode = (fl & TK_BLANK) ? MODE_A : ((fl & TK_SPACE) ? MODE_C : MODE_D);
+        if (mode == MODE_C) L.scal[4] = 1u;
+        L.surv[s].mode = mode | ((uint32_t)N << 8);
+      }
+      ctx.sync();
+      return;
+    }
+    const uint32_t W = (uint32_t)ctx.wave_width();
+    if ((uint32_t)ctx.tid < W) {  // the first wave
+      const uint32_t lane = (uint32_t)ctx.tid;
       uint32_t f = L.scal[3];
-      uint32_t need = 0;
-      for (uint32_t s = 0; s < ns; ++s) {
-        uint32_t fl = tab.tok[L.surv[s].id].flags;
-        if (fl & TK_BLANK) continue;
-        uint32_t first = L.surv[s].mode >> 8;
-        bool any = first < (uint32_t)N;
-        uint32_t mode = MODE_D;
-        if (fl & TK_LEAD) {
-          mode = MODE_ALL_B;
-          if (any) f = (fl & TK_TRAIL) ? 1u : 0u;
-        } else if (f && any) {
-          if (fl & TK_TRAIL) {
-            mode = MODE_ALL_B;
-            f = 1u;
-          } else {
-            mode = MODE_FIRST_B;
-            f = 0u;
+      bool need = false;
+      for (uint32_t base = 0; base < ns; base += W) {
+        const uint32_t s = base + lane;
+        uint32_t fl = TK_BLANK, first = (uint32_t)N;
+        bool any = false;
+        if (s < ns) {
+          fl = tok_of(s).flags();
+          if (!(fl & TK_BLANK)) {
+            const uint32_t c = L.surv[s].id;
+            int i = 0;
+            while (i < N && last_char(b, i) == c) ++i;  // first beam that does not repeat the label
+            first = (uint32_t)i;
+            any = i < N;
           }
         }
-        if (mode != MODE_D && any) need = 1;
-        L.surv[s].mode = mode | (first << 8);
+        const bool lead = (fl & TK_LEAD) != 0, trail = (fl & TK_TRAIL) != 0, blank = (fl & TK_BLANK) != 0;
+        // effect on the flag: lead label with a taker -> set to `trail`; other label with a taker and no
+        // trailing mark -> clear; everything else -> identity
+        const bool sets = !blank && any && lead && trail;
+        const bool clears = !blank && any && ((lead && !trail) || (!lead && !trail));
+        const uint64_t m_one = ctx.ballot(sets);
+        const uint64_t m_set = m_one | ctx.ballot(clears);
+        const uint64_t prior = m_set & ((lane >= 64u) ? ~0ull : ((1ull << lane) - 1ull));
+        uint32_t f_in = f;
+        if (prior) f_in = (uint32_t)((m_one >> (63 - ctx.clz64(prior))) & 1ull);
+        uint32_t mode = MODE_D;
+        if (blank) mode = MODE_A;
+        else if (lead) mode = MODE_ALL_B;
+        else if (f_in && any) mode = trail ? MODE_ALL_B : MODE_FIRST_B;
+        if (s < ns) L.surv[s].mode = mode | (first << 8);
+        need = need || (ctx.ballot(!blank && any && mode != MODE_D) != 0ull);
+        if (m_set) f = (uint32_t)((m_one >> (63 - ctx.clz64(m_set))) & 1ull);
       }
-      L.scal[3] = f;
-      if (need) L.scal[4] = 1u;
+      if (lane == 0) {
+        L.scal[3] = f;
+        if (need) L.scal[4] = 1u;
+      }
     }
     ctx.sync();
   }
@@ -427,15 +557,53 @@ struct BeamDecoder {
     }
   }
 
-  // Sort pool entries with score >= thr by (score desc, arrival asc); result: s_k1 low 32 bits =
-  // pool index in order. Returns count (<= pool_n). Bitonic network over a power of two.
+  // Select the pool entries with score >= thr, ordered by (score desc, arrival asc); L.sel[r] = pool
+  // index of rank r for r < min(count, beam_width). Returns the count (may exceed beam_width).
+  // Entries are first compacted (typically ~25 of ~100 survive the threshold); small sets are ranked by
+  // counting (one LDS sweep, no barriers), large ones by a bitonic network.
   CTC_HD uint32_t sort_pool(uint32_t pool_n, double thr) {
-    uint32_t p2 = 1;
-    while (p2 < pool_n) p2 <<= 1;
-    for (uint32_t k = ctx.tid; k < p2; k += ctx.nt) {
-      bool live = k < pool_n && L.p_score[k] >= thr;
-      L.s_k0[k] = live ? score_sort_key(L.p_score[k]) : ~0ull;
-      L.s_k1[k] = live ? (((uint64_t)L.p_arr[k] << 32) | k) : ~0ull;
+    if (ctx.tid == 0) L.scal[5] = 0;
+    ctx.sync();
+    tick<17>();
+    for (uint32_t k = ctx.tid; k < pool_n; k += ctx.nt) {
+      double sc = L.p_score[k];
+      if (sc >= thr) {
+        uint32_t pos = ctx.atomic_add(&L.scal[5], 1u);
+        L.s_k0[pos] = score_sort_key(sc);
+        L.s_k1[pos] = ((uint64_t)L.p_arr[k] << 32) | k;
+      }
+    }
+    ctx.sync();
+    tick<18>();
+    const uint32_t n = L.scal[5];
+    const uint32_t want = (uint32_t)prm.beam_width;
+    if (n <= 256u) {
+      for (uint32_t e = ctx.tid; e < n; e += ctx.nt) {
+        uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
+        uint32_t rank = 0;
+        uint32_t j = 0;
+        for (; j + 4 <= n; j += 4) {  // four independent LDS reads in flight per step
+          uint64_t x0 = L.s_k0[j], x1 = L.s_k0[j + 1], x2 = L.s_k0[j + 2], x3 = L.s_k0[j + 3];
+          uint64_t y0 = L.s_k1[j], y1 = L.s_k1[j + 1], y2 = L.s_k1[j + 2], y3 = L.s_k1[j + 3];
+          rank += ((x0 < a0) || (x0 == a0 && y0 < a1)) ? 1u : 0u;
+          rank += ((x1 < a0) || (x1 == a0 && y1 < a1)) ? 1u : 0u;
+          rank += ((x2 < a0) || (x2 == a0 && y2 < a1)) ? 1u : 0u;
+          rank += ((x3 < a0) || (x3 == a0 && y3 < a1)) ? 1u : 0u;
+        }
+        for (; j < n; ++j) {
+          uint64_t b0 = L.s_k0[j], b1 = L.s_k1[j];
+          rank += ((b0 < a0) || (b0 == a0 && b1 < a1)) ? 1u : 0u;
+        }
+        if (rank < want) L.sel[rank] = (uint32_t)(a1 & 0xFFFFFFFFu);
+      }
+      ctx.sync();
+      return n;
+    }
+    uint32_t p2 = 512;
+    while (p2 < n) p2 <<= 1;
+    for (uint32_t k = n + ctx.tid; k < p2; k += ctx.nt) {
+      L.s_k0[k] = ~0ull;
+      L.s_k1[k] = ~0ull;
     }
     ctx.sync();
     for (uint32_t size = 2; size <= p2; size <<= 1) {
@@ -456,16 +624,9 @@ struct BeamDecoder {
         ctx.sync();
       }
     }
-    // count live entries (keys != ~0): they are a prefix of the sorted order
-    if (ctx.tid == 0) L.scal[5] = 0;
+    for (uint32_t r = ctx.tid; r < want && r < n; r += ctx.nt) L.sel[r] = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFull);
     ctx.sync();
-    for (uint32_t k = ctx.tid; k < p2; k += ctx.nt) {
-      bool live = L.s_k1[k] != ~0ull;
-      bool next_live = (k + 1 < p2) && L.s_k1[k + 1] != ~0ull;
-      if (live && !next_live) L.scal[5] = k + 1;
-    }
-    ctx.sync();
-    return L.scal[5];
+    return n;
   }
 
   // keep only the best `beam_width` pool entries (exact: pruning is monotone)
@@ -476,7 +637,7 @@ struct BeamDecoder {
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     // gather the survivors through the temp arrays, then rewrite the pool front
     for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
-      uint32_t idx = (uint32_t)(L.s_k1[k] & 0xFFFFFFFFu);
+      uint32_t idx = L.sel[k];
       L.g_score[k] = L.p_score[idx];
       L.g_logit[k] = L.p_logit[idx];
       L.g_arr[k] = L.p_arr[idx];
@@ -521,7 +682,7 @@ struct BeamDecoder {
     uint32_t pl, m2, wid;
     double ps;
   };
-  CTC_HD PartView new_partial(const BeamSoA& b, int i, uint32_t c, const TokInfo& tk, uint32_t br,
+  CTC_HD PartView new_partial(const BeamSoA& b, int i, uint32_t c, const TkView& tk, uint32_t br,
                               uint64_t new_part_h) const {
     PartView v;
     if (br == 0) {  // blank / repeat: unchanged
@@ -529,19 +690,45 @@ struct BeamDecoder {
       v.m2 = b.meta2[i];
       v.wid = b.word_id[i];
       v.ps = b.pscore[i];
-    } else if (br == BR_BOUNDARY && tk.len_clean > 0) {  // a new word starts with the clean label
-      uint32_t hmin = tab.tok_hot ? tab.tok_hot[c].min_len : 0;
-      uint32_t hcomp = tab.tok_hot ? tab.tok_hot[c].complete : 0;
-      v.pl = tk.len_clean;
-      v.m2 = (tk.start_flags & 0xFu) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
-      v.wid = tk.start_word_id;
-      v.ps = partial_score(tab, prm, tk.start_flags, hmin, v.pl);
+    } else if (br == BR_BOUNDARY && tk.len_clean() > 0) {  // a new word starts with the clean label
+      uint32_t hmin = tk.hot_min();
+      uint32_t hcomp = tk.hot_complete();
+      v.pl = tk.len_clean();
+      v.m2 = (tk.start_flags() & 0xFu) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
+      v.wid = tk.start_word_id();
+      v.ps = partial_score(tab, prm, tk.start_flags(), hmin, v.pl);
     } else if (br == BR_APPEND) {
       uint32_t m2 = b.meta2[i];
       uint32_t pf = 0, nw = 0, hmin = 0, hcomp = 0;
-      bool on = (m2 & PF_ON_TABLE) && prefix_lookup(tab.prefixes, tab.prefix_mask, new_part_h, &nw, &pf);
-      bool hon = (m2 & M2_HOT_ON) && hot_lookup(tab.hot, tab.hot_mask, new_part_h, &hmin, &hcomp);
-      v.pl = plen(b, i) + tk.len_raw;
+      // first probe of both tables issued together (one memory round trip instead of two)
+      const bool want_p = (m2 & PF_ON_TABLE) && tab.prefixes && new_part_h != 0;
+      const bool want_h = (m2 & M2_HOT_ON) && tab.hot && new_part_h != 0;
+      const uint64_t hk = mix64(new_part_h);
+      uint64_t sp = hk & tab.prefix_mask, sh = hk & tab.hot_mask;
+      PrefixEntry ep = {0, 0, 0};
+      HotEntry eh = {0, 0, 0};
+      if (want_p) ep = tab.prefixes[sp];
+      if (want_h) eh = tab.hot[sh];
+      bool on = false, hon = false;
+      if (want_p) {
+        while (ep.key != new_part_h && ep.key != 0) {
+          sp = (sp + 1) & tab.prefix_mask;
+          ep = tab.prefixes[sp];
+        }
+        on = ep.key == new_part_h;
+        nw = ep.word_id;
+        pf = ep.flags;
+      }
+      if (want_h) {
+        while (eh.key != new_part_h && eh.key != 0) {
+          sh = (sh + 1) & tab.hot_mask;
+          eh = tab.hot[sh];
+        }
+        hon = eh.key == new_part_h;
+        hmin = eh.min_len;
+        hcomp = eh.complete;
+      }
+      v.pl = plen(b, i) + tk.len_raw();
       v.m2 = (on ? (PF_ON_TABLE | (pf & 7u)) : 0u) | (hon ? M2_HOT_ON : 0u) | ((hon && hcomp) ? M2_HOT_COMPLETE : 0u) |
              ((hon ? hmin : 0u) << 8);
       v.wid = on ? nw : 0;
@@ -557,7 +744,7 @@ struct BeamDecoder {
 
   // Candidate generation + merge + scoring for survivors [s0, s1)
   CTC_HD void process_chunk(uint32_t s0, uint32_t s1, int frame) {
-    BeamSoA& b = L.beams[cur];
+    const BeamSoA b = beams_at(cur);
     uint32_t Q = (s1 - s0) * (uint32_t)N;
     // conservative running threshold from the chunks already seen (nobody writes smax here)
     double thr_prev = sortable_to_max() + prm.beam_prune_logp;
@@ -566,14 +753,14 @@ struct BeamDecoder {
       uint32_t s = s0 + q / (uint32_t)N;
       int i = (int)(q % (uint32_t)N);
       uint32_t c = L.surv[s].id;
-      const TokInfo& tk = tab.tok[c];
-      uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
+      const TkView tk = tok_of(s);
+      uint32_t br = branch_of(b, tk.flags(), L.surv[s].mode, c, i);
       uint64_t kt = b.text_h[i], kp = b.part_h[i];
       if (br == BR_BOUNDARY || br == BR_SPACE) {
         if (plen(b, i) > 0) kt = b.c_text_h[i];
-        kp = br == BR_BOUNDARY ? tk.h_clean : 0;
+        kp = br == BR_BOUNDARY ? tk.h_clean() : 0;
       } else if (br == BR_APPEND) {
-        kp = str_concat(kp, tk.pow_raw, tk.h_raw);
+        kp = str_concat(kp, tk.pow_raw(), tk.h_raw());
       }
       L.ck_text[q] = kt;
       L.ck_part[q] = kp;
@@ -594,32 +781,52 @@ struct BeamDecoder {
     }
     ctx.sync();
     tick<4>();
-    // S: owners fold, score, push
-    for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
-      uint32_t r = L.crep[q];
-      if (L.rmin[r] != q) continue;
-      uint32_t qmax = L.rmax[r], cnt = L.rcnt[r];
-      double lg = L.c_logit[q];
-      if (cnt == 2) {
-        lg = lse2(lg, L.c_logit[qmax]);
-      } else if (cnt > 2) {
-        for (uint32_t q2 = q + 1; q2 <= qmax; ++q2)
-          if (L.crep[q2] == r) lg = lse2(lg, L.c_logit[q2]);
+    // S: owners fold, score, push. The loop keeps every wave converged (uniform trip count) so the
+    // running maximum is reduced inside the wave and published with ONE LDS atomic per wave.
+    for (uint32_t base = 0; base < Q; base += (uint32_t)ctx.nt) {
+      const uint32_t q = base + (uint32_t)ctx.tid;
+      uint64_t my_key = 0;  // below every real key
+      bool owner = false;
+      if (q < Q) {
+        const uint32_t r = L.crep[q];
+        owner = L.rmin[r] == q;
       }
-      uint32_t s = s0 + q / (uint32_t)N;
-      int i = (int)(q % (uint32_t)N);
-      uint32_t c = L.surv[s].id;
-      const TokInfo& tk = tab.tok[c];
-      uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
-      double lmhw = b.lm_hw[i];
-      if ((br == BR_BOUNDARY || br == BR_SPACE) && plen(b, i) > 0) lmhw = b.c_lm_hw[i];
-      PartView pv = new_partial(b, i, c, tk, br, L.ck_part[q]);
-      double score = total_score(tab, lg, lmhw, pv.ps, pv.pl);
-      ctx.atomic_max64(&L.smax[0], asc_key(score));
-      if (score >= thr_prev) {
-        uint32_t imax = qmax % (uint32_t)N;
-        pool_push(score, lg, s * (uint32_t)N + (uint32_t)i, (s << 8) | imax, pv.wid, pv.m2);
+      if (owner) {
+        const uint32_t r = L.crep[q];
+        uint32_t qmax = L.rmax[r], cnt = L.rcnt[r];
+        double lg = L.c_logit[q];
+        if (cnt == 2) {
+          lg = lse2(lg, L.c_logit[qmax]);
+        } else if (cnt > 2) {
+          for (uint32_t q2 = q + 1; q2 <= qmax; ++q2)
+            if (L.crep[q2] == r) lg = lse2(lg, L.c_logit[q2]);
+        }
+        uint32_t s = s0 + q / (uint32_t)N;
+        int i = (int)(q % (uint32_t)N);
+        uint32_t c = L.surv[s].id;
+        const TkView tk = tok_of(s);
+        uint32_t br = branch_of(b, tk.flags(), L.surv[s].mode, c, i);
+        double lmhw = b.lm_hw[i];
+        if ((br == BR_BOUNDARY || br == BR_SPACE) && plen(b, i) > 0) lmhw = b.c_lm_hw[i];
+        if (io.prof) {
+          ctx.use(lg + lmhw);
+          tick<14>();
+        }
+        PartView pv = new_partial(b, i, c, tk, br, L.ck_part[q]);
+        if (io.prof) {
+          ctx.use(pv.ps);
+          tick<15>();
+        }
+        double score = total_score(tab, lg, lmhw, pv.ps, pv.pl);
+        my_key = asc_key(score);
+        if (score >= thr_prev) {
+          uint32_t imax = qmax % (uint32_t)N;
+          pool_push(score, lg, s * (uint32_t)N + (uint32_t)i, (s << 8) | imax, pv.wid, pv.m2);
+        }
+        tick<16>();
       }
+      const uint64_t wave_key = ctx.wave_max_u64(my_key);
+      if (ctx.is_wave_leader() && wave_key != 0) ctx.atomic_max64(&L.smax[0], wave_key);
     }
     ctx.sync();
     tick<5>();
@@ -630,14 +837,14 @@ struct BeamDecoder {
 
   // Build beam `dst` of the next table from pool entry `idx` (payload = the donor, i.e. the
   // last-arriving duplicate: decoder.py:221-223)
-  CTC_HD void build_beam(BeamSoA& nb, int dst, uint32_t idx, int frame) {
-    BeamSoA& b = L.beams[cur];
+  CTC_HD void build_beam(const BeamSoA& nb, int dst, uint32_t idx, int frame) {
+    const BeamSoA b = beams_at(cur);
     uint32_t don = L.p_don[idx];
     uint32_t s = don >> 8;
     int i = (int)(don & 0xFFu);
     uint32_t c = L.surv[s].id;
-    const TokInfo& tk = tab.tok[c];
-    uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
+    const TkView tk = tok_of(s);
+    uint32_t br = branch_of(b, tk.flags(), L.surv[s].mode, c, i);
     uint32_t pl = plen(b, i);
     uint64_t th = b.text_h[i], ph = b.part_h[i], hh = b.hist_h[i];
     double lmhw = b.lm_hw[i];
@@ -650,7 +857,7 @@ struct BeamDecoder {
     uint32_t m2 = L.p_m2[idx], wid = L.p_wid[idx];
     uint32_t npl = pl;
     if (br == 0) {
-      if (!(tk.flags & TK_BLANK)) pen = frame + 1;  // decoder.py:453-461
+      if (!(tk.flags() & TK_BLANK)) pen = frame + 1;  // decoder.py:453-461
     } else {
       int32_t wst = pst, wen = pen;
       if (br == BR_BOUNDARY || br == BR_SPACE) {
@@ -661,8 +868,8 @@ struct BeamDecoder {
           tnode = cnode;
         }
         if (br == BR_BOUNDARY) {
-          ph = tk.h_clean;
-          npl = tk.len_clean;
+          ph = tk.h_clean();
+          npl = tk.len_clean();
           pst = frame;
           pen = frame + 1;
         } else {
@@ -672,8 +879,8 @@ struct BeamDecoder {
           pen = -1;
         }
       } else {  // BR_APPEND (decoder.py:518-534)
-        ph = str_concat(ph, tk.pow_raw, tk.h_raw);
-        npl = pl + tk.len_raw;
+        ph = str_concat(ph, tk.pow_raw(), tk.h_raw());
+        npl = pl + tk.len_raw();
         pst = pst < 0 ? frame : pst;
         pen = frame + 1;
       }
@@ -716,19 +923,19 @@ struct BeamDecoder {
 
   // history-prune key of pool entry idx (decoder.py:250-254): (last words, partial, last_char)
   CTC_HD void hist_key(uint32_t idx, uint64_t* hh, uint64_t* ph, uint32_t* cc) const {
-    const BeamSoA& b = L.beams[cur];
+    const BeamSoA b = beams_at(cur);
     uint32_t don = L.p_don[idx];
     uint32_t s = don >> 8;
     int i = (int)(don & 0xFFu);
     uint32_t c = L.surv[s].id;
-    const TokInfo& tk = tab.tok[c];
-    uint32_t br = branch_of(b, tk.flags, L.surv[s].mode, c, i);
+    const TkView tk = tok_of(s);
+    uint32_t br = branch_of(b, tk.flags(), L.surv[s].mode, c, i);
     uint64_t h = b.hist_h[i], p = b.part_h[i];
     if (br == BR_BOUNDARY || br == BR_SPACE) {
       if (plen(b, i) > 0) h = b.c_hist_h[i];
-      p = br == BR_BOUNDARY ? tk.h_clean : 0;
+      p = br == BR_BOUNDARY ? tk.h_clean() : 0;
     } else if (br == BR_APPEND) {
-      p = str_concat(p, tk.pow_raw, tk.h_raw);
+      p = str_concat(p, tk.pow_raw(), tk.h_raw());
     }
     *hh = h;
     *ph = p;
@@ -737,24 +944,27 @@ struct BeamDecoder {
 
   CTC_HD void step(int t) {
     int frame = prm.first_frame + t;
-    uint32_t ns = io.surv_cnt[t];
     if (ctx.tid == 0) {
       L.scal[0] = 0;
       L.scal[4] = 0;
       L.smax[0] = asc_key(-INFINITY);
     }
     tick<9>();
-    load_survivors(t);
+    uint32_t ns = load_survivors(t);
     ctx.sync();
     tick<0>();
     compute_modes(ns);
     tick<1>();
-    BeamSoA& b = L.beams[cur];
+    const BeamSoA b = beams_at(cur);
     if (L.scal[4]) {
+      // TextNodes written in earlier frames are read here by other threads: make them visible
+      ctx.sync_mem();
+      tick<22>();
       for (int i = ctx.tid; i < N; i += ctx.nt)
         if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
     }
     ctx.sync();
+    prefetch(t + 1);  // lands while this frame's candidates are processed
     tick<2>();
     uint32_t per = (uint32_t)shape.cand / (uint32_t)N;
     if (per == 0) per = 1;
@@ -773,7 +983,7 @@ struct BeamDecoder {
     uint32_t n = sort_pool(pool_n, thr);
     tick<7>();
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
-    BeamSoA& nb = L.beams[cur ^ 1];
+    const BeamSoA nb = beams_at(cur ^ 1);
     if (final_stage) {
       if (ctx.tid == 0) L.scal[5] = n;
       ctx.sync();
@@ -782,7 +992,7 @@ struct BeamDecoder {
     if (prm.prune_history) {
       // first of each (history, partial, last_char) in sorted order wins
       for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
-        uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+        uint32_t idx = L.sel[r];
         uint64_t hh, ph;
         uint32_t cc;
         hist_key(idx, &hh, &ph, &cc);
@@ -791,29 +1001,39 @@ struct BeamDecoder {
         L.hk_c[r] = cc;
       }
       ctx.sync();
+      tick<19>();
       for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
         uint64_t hh = L.hk_h[r], ph = L.hk_p[r];
         uint32_t cc = L.hk_c[r];
         uint32_t dup = 0;
-        for (uint32_t r2 = 0; r2 < r; ++r2)
-          if (L.hk_h[r2] == hh && L.hk_p[r2] == ph && L.hk_c[r2] == cc) {
-            dup = 1;
-            break;
-          }
+        uint32_t r2 = 0;
+        for (; r2 + 4 <= r; r2 += 4) {  // no early exit: independent LDS reads pipeline
+          uint64_t h0 = L.hk_h[r2], h1 = L.hk_h[r2 + 1], h2 = L.hk_h[r2 + 2], h3 = L.hk_h[r2 + 3];
+          uint64_t p0 = L.hk_p[r2], p1 = L.hk_p[r2 + 1], p2 = L.hk_p[r2 + 2], p3 = L.hk_p[r2 + 3];
+          uint32_t c0 = L.hk_c[r2], c1 = L.hk_c[r2 + 1], c2 = L.hk_c[r2 + 2], c3 = L.hk_c[r2 + 3];
+          dup |= (h0 == hh && p0 == ph && c0 == cc) ? 1u : 0u;
+          dup |= (h1 == hh && p1 == ph && c1 == cc) ? 1u : 0u;
+          dup |= (h2 == hh && p2 == ph && c2 == cc) ? 1u : 0u;
+          dup |= (h3 == hh && p3 == ph && c3 == cc) ? 1u : 0u;
+        }
+        for (; r2 < r; ++r2) dup |= (L.hk_h[r2] == hh && L.hk_p[r2] == ph && L.hk_c[r2] == cc) ? 1u : 0u;
         L.keep[r] = dup ? 0u : 1u;
       }
     } else {
       for (uint32_t r = ctx.tid; r < n; r += ctx.nt) L.keep[r] = 1u;
     }
     ctx.sync();
+    tick<20>();
     for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
-      if (!L.keep[r]) continue;
       uint32_t dst = 0;
-      for (uint32_t r2 = 0; r2 < r; ++r2) dst += L.keep[r2];
-      uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
-      build_beam(nb, (int)dst, idx, frame);
-      ctx.atomic_max(&L.scal[7], dst + 1);
+      uint32_t r2 = 0;
+      for (; r2 + 4 <= r; r2 += 4) dst += L.keep[r2] + L.keep[r2 + 1] + L.keep[r2 + 2] + L.keep[r2 + 3];
+      for (; r2 < r; ++r2) dst += L.keep[r2];
+      const uint32_t kept = L.keep[r];
+      if (r == n - 1) L.scal[7] = dst + kept;  // size of the next beam table
+      if (kept) build_beam(nb, (int)dst, L.sel[r], frame);
     }
+    tick<21>();
     ctx.sync();
     N = (int)L.scal[7];
     cur ^= 1;
@@ -853,7 +1073,7 @@ struct BeamDecoder {
       er.wstart = -1;
       er.wend = -1;
       io.emit_nodes[0] = er;
-      BeamSoA& b = L.beams[0];
+      const BeamSoA b = beams_at(0);
       b.logit[0] = 0.0;
       b.lm_hw[0] = 0.0;
       b.pscore[0] = 0.0;
@@ -874,21 +1094,22 @@ struct BeamDecoder {
       b.pend[0] = -1;
     }
     clear_table();
-    ctx.sync();
+    ctx.sync_mem();
     cur = 0;
     N = 1;
   }
 
   // _finalize_beams(force_next_word=True, is_end=True) + output records (decoder.py:558-602,653-667)
   CTC_HD void finalise() {
-    BeamSoA& b = L.beams[cur];
+    const BeamSoA b = beams_at(cur);
     if (ctx.tid == 0) {
       L.scal[0] = 0;
       L.smax[0] = asc_key(-INFINITY);
     }
-    ctx.sync();
+    ctx.sync_mem();
     for (int i = ctx.tid; i < N; i += ctx.nt)
       if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
+    ctx.sync_mem();
     ctx.sync();
     // candidates: one per beam, key (text (+) partial, "", None)
     for (int base = 0; base < N; base += shape.cand) {
@@ -955,7 +1176,7 @@ struct BeamDecoder {
     if (ctx.tid == 0) L.scal[8] = 0;
     ctx.sync();
     for (uint32_t r = ctx.tid; r < n_out; r += ctx.nt) {
-      uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+      uint32_t idx = L.sel[r];
       int d = (int)L.p_don[idx];
       uint32_t len = b.depth[d] + (plen(b, d) > 0 ? 1u : 0u);
       L.keep[r] = ctx.atomic_add(&L.scal[8], len);  // offset inside this utterance's block
@@ -972,7 +1193,7 @@ struct BeamDecoder {
     ctx.sync();
     bool tok_ok = !(L.scal[6] & ST_TOK_OVERFLOW);
     for (uint32_t r = ctx.tid; r < n_out; r += ctx.nt) {
-      uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFu);
+      uint32_t idx = L.sel[r];
       int d = (int)L.p_don[idx];
       OutBeam ob;
       ob.logit_score = L.p_logit[idx];
@@ -1020,12 +1241,15 @@ struct BeamDecoder {
   CTC_HD void run() {
     init();
     if (io.prof && ctx.tid == 0) t_last = ctx.clock();
+    prefetch(0);
     for (int t = 0; t < io.T; ++t) step(t);
     tick<9>();
     finalise();
     tick<10>();
-    if (io.prof && ctx.tid == 0)
+    if (io.prof && ctx.tid == 0) {
+#pragma unroll
       for (int k = 0; k < N_PROF; ++k) io.prof[k] = t_acc[k];
+    }
   }
 };
 

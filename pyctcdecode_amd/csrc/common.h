@@ -253,71 +253,80 @@ CTC_HD bool ngram_lookup(const NgramEntry* tab, uint64_t mask, uint64_t key, flo
 
 // kenlm GenericModel::FullScore restated on the flat hashed trie (see oracle/arpa_lm.py for the
 // CPU restatement and DESIGN.md for the state convention).  Returns log10 p as fp32.
+// key of the n-gram (in.words[n-2] ... in.words[0], wid)
+template <int N>
+CTC_HD uint64_t lm_key(const LmState& in, uint32_t wid) {
+  uint64_t k = ngram_key_begin((uint32_t)N);
+#pragma unroll
+  for (int c = N - 2; c >= 0; --c) k = ngram_key_push(k, in.words[c]);
+  return ngram_key_end(ngram_key_push(k, wid));
+}
+
+// finish the probe of one order: first entry `e` was loaded from slot `s`; walk on collisions (rare)
+CTC_HD bool lm_resolve(const DeviceTables& t, uint64_t key, uint64_t s, NgramEntry e, float* prob, float* bo) {
+  while (e.key != key && e.key != 0) {
+    s = (s + 1) & t.ngram_mask;
+    e = t.ngrams[s];
+  }
+  if (e.key != key) return false;
+  *prob = e.prob;
+  *bo = e.backoff;
+  return true;
+}
+
 CTC_HD float lm_base_score(const DeviceTables& t, const LmState& in, uint32_t wid, LmState* out) {
-  UnigramEntry u = t.unigrams[wid];
+  const UnigramEntry u = t.unigrams[wid];
   const int in_len = in.len;
   const int max_n = !t.ngrams ? 1 : ((int)t.lm_order < in_len + 1 ? (int)t.lm_order : in_len + 1);
-  // First probe of every order is issued up front (independent loads overlap their latency);
-  // kenlm walks the orders one after the other, the result is the same longest match.
-  uint64_t keys[MAX_CTX + 2];
-  uint64_t slots[MAX_CTX + 2];
-  NgramEntry ent[MAX_CTX + 2];
-#pragma unroll
-  for (int n = 2; n <= MAX_CTX + 1; ++n) {
-    keys[n] = 0;
-    slots[n] = 0;
-    ent[n].key = 0;
-    ent[n].prob = 0.f;
-    ent[n].backoff = 0.f;
-    if (n <= max_n) {
-      uint64_t k = ngram_key_begin((uint32_t)n);
-#pragma unroll
-      for (int c = MAX_CTX - 1; c >= 0; --c)
-        if (c <= n - 2) k = ngram_key_push(k, in.words[c]);
-      k = ngram_key_end(ngram_key_push(k, wid));
-      keys[n] = k;
-      slots[n] = mix64(k) & t.ngram_mask;
-      ent[n] = t.ngrams[slots[n]];
-    }
-  }
+  // The first probe of every order is issued up front (independent loads overlap their latency);
+  // kenlm walks the orders one after the other, the longest match is the same. Scalars only: no
+  // run-time indexed temporaries (they would live in scratch memory).
+  const NgramEntry none = {0, 0.f, 0.f};
+  uint64_t k2 = 0, k3 = 0, k4 = 0, k5 = 0, k6 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0;
+  NgramEntry e2 = none, e3 = none, e4 = none, e5 = none, e6 = none;
+  if (max_n >= 2) { k2 = lm_key<2>(in, wid); s2 = mix64(k2) & t.ngram_mask; e2 = t.ngrams[s2]; }
+  if (max_n >= 3) { k3 = lm_key<3>(in, wid); s3 = mix64(k3) & t.ngram_mask; e3 = t.ngrams[s3]; }
+  if (max_n >= 4) { k4 = lm_key<4>(in, wid); s4 = mix64(k4) & t.ngram_mask; e4 = t.ngrams[s4]; }
+  if (max_n >= 5) { k5 = lm_key<5>(in, wid); s5 = mix64(k5) & t.ngram_mask; e5 = t.ngrams[s5]; }
+  if (max_n >= 6) { k6 = lm_key<6>(in, wid); s6 = mix64(k6) & t.ngram_mask; e6 = t.ngrams[s6]; }
   float prob = u.prob;
-  float obo[MAX_CTX + 1];
-#pragma unroll
-  for (int k = 0; k <= MAX_CTX; ++k) obo[k] = 0.f;
-  obo[0] = u.backoff;
+  float b0 = u.backoff, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
   int matched = 1;
-  bool go = true;
-#pragma unroll
-  for (int n = 2; n <= MAX_CTX + 1; ++n) {
-    if (go && n <= max_n) {
-      NgramEntry e = ent[n];
-      uint64_t s = slots[n];
-      while (e.key != keys[n] && e.key != 0) {  // linear probing past a collision (rare)
-        s = (s + 1) & t.ngram_mask;
-        e = t.ngrams[s];
-      }
-      if (e.key == keys[n]) {
-        prob = e.prob;
-        obo[n - 1] = e.backoff;
-        matched = n;
-      } else {
-        go = false;
+  if (max_n >= 2 && lm_resolve(t, k2, s2, e2, &prob, &b1)) {
+    matched = 2;
+    if (max_n >= 3 && lm_resolve(t, k3, s3, e3, &prob, &b2)) {
+      matched = 3;
+      if (max_n >= 4 && lm_resolve(t, k4, s4, e4, &prob, &b3)) {
+        matched = 4;
+        if (max_n >= 5 && lm_resolve(t, k5, s5, e5, &prob, &b4)) {
+          matched = 5;
+          if (max_n >= 6 && lm_resolve(t, k6, s6, e6, &prob, &b5)) matched = 6;
+        }
       }
     }
   }
-#pragma unroll
-  for (int i = 0; i < MAX_CTX; ++i)
-    if (i >= matched - 1 && i < in_len) prob = prob + in.backoff[i];  // fp32, shortest context first
+  (void)b5;  // the highest order carries no back-off
+  // back-offs of the skipped contexts, fp32, shortest context first (kenlm FullScore)
+  const float i0 = in.backoff[0], i1 = in.backoff[1], i2 = in.backoff[2], i3 = in.backoff[3], i4 = in.backoff[4];
+  if (0 >= matched - 1 && 0 < in_len) prob = prob + i0;
+  if (1 >= matched - 1 && 1 < in_len) prob = prob + i1;
+  if (2 >= matched - 1 && 2 < in_len) prob = prob + i2;
+  if (3 >= matched - 1 && 3 < in_len) prob = prob + i3;
+  if (4 >= matched - 1 && 4 < in_len) prob = prob + i4;
   const int keep = matched < (int)t.lm_order - 1 ? matched : (int)t.lm_order - 1;
-  LmState o;
-  o.len = keep;
-#pragma unroll
-  for (int k = 0; k < MAX_CTX; ++k) {
-    bool on = k < keep;
-    o.words[k] = on ? (k == 0 ? wid : in.words[k > 0 ? k - 1 : 0]) : 0u;
-    o.backoff[k] = on ? obo[k] : 0.f;
-  }
-  *out = o;
+  // `in` and `out` never alias (out is a fresh node or a local)
+  const uint32_t w0 = in.words[0], w1 = in.words[1], w2 = in.words[2], w3 = in.words[3];
+  out->len = keep;
+  out->words[0] = keep > 0 ? wid : 0u;
+  out->words[1] = keep > 1 ? w0 : 0u;
+  out->words[2] = keep > 2 ? w1 : 0u;
+  out->words[3] = keep > 3 ? w2 : 0u;
+  out->words[4] = keep > 4 ? w3 : 0u;
+  out->backoff[0] = keep > 0 ? b0 : 0.f;
+  out->backoff[1] = keep > 1 ? b1 : 0.f;
+  out->backoff[2] = keep > 2 ? b2 : 0.f;
+  out->backoff[3] = keep > 3 ? b3 : 0.f;
+  out->backoff[4] = keep > 4 ? b4 : 0.f;
   return prob;
 }
 

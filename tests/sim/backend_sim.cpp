@@ -19,6 +19,7 @@ namespace be {
 struct SeqCtx {
   int tid = 0, nt = 1;
   void sync() {}
+  void sync_mem() {}
   uint32_t atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
   void atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
   void atomic_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
@@ -26,6 +27,12 @@ struct SeqCtx {
   void atomic_max64(uint64_t* p, uint64_t v) { if (v > *p) *p = v; }
   uint32_t atomic_cas(uint32_t* p, uint32_t cmp, uint32_t val) { uint32_t o = *p; if (o == cmp) *p = val; return o; }
   unsigned long long clock() { return 0; }
+  void use(double) {}
+  uint64_t wave_max_u64(uint64_t v) { return v; }
+  bool is_wave_leader() { return true; }
+  int wave_width() { return 1; }
+  uint64_t ballot(bool p) { return p ? 1ull : 0ull; }
+  int clz64(uint64_t x) { return __builtin_clzll(x); }
   unsigned long long global_add(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 };
 
