@@ -143,16 +143,18 @@ def main():
     for _ in range(args.warmup):
         step()
         log("warmup step done: prune %.2f ms, beam %.2f ms, native call %.2f ms" % decoder.last_timing_ms)
-    prune_ms, beam_ms = [], []
+    prune_ms, beam_ms, call_ms = [], [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         texts = step()
         prune_ms.append(decoder.last_timing_ms[0])
         beam_ms.append(decoder.last_timing_ms[1])
+        call_ms.append(decoder.last_timing_ms[2])
     fence()
     dt = time.perf_counter() - t0
-    log("timed steps done: %.1f ms/step" % (1000 * dt / args.steps))
+    log("timed steps done: %.1f ms/step (prune %.2f, beam %.2f, native call %.2f)" % (
+        1000 * dt / args.steps, np.mean(prune_ms), np.mean(beam_ms), np.mean(call_ms)))
     if args.phases and rank == 0:
         import ctypes as C
 

@@ -1,11 +1,14 @@
 // api.cpp -- the C ABI of include/ctcdec.h on top of backend.h + host_tables.h.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <chrono>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ctcdec.h"
@@ -44,6 +47,27 @@ struct DevBuf {
   }
 };
 
+struct HostBuf {  // grow-only page-locked staging buffer
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes, std::string* err) {
+    if (bytes <= cap && p) return 0;
+    if (p) be::release_host(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    p = be::alloc_host(want, err);
+    if (!p) return -1;
+    cap = want;
+    return 0;
+  }
+  void drop() {
+    if (p) be::release_host(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 template <class T>
 int upload(DevBuf& b, const std::vector<T>& v, std::string* err) {
   size_t bytes = std::max<size_t>(sizeof(T) * v.size(), 16);
@@ -73,6 +97,7 @@ struct ctcdec_decoder {
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
       w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof;
+  HostBuf h_tok, h_out, h_small;
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
@@ -80,6 +105,9 @@ struct ctcdec_decoder {
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
                      &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof};
     for (DevBuf* b : all) b->drop();
+    h_tok.drop();
+    h_out.drop();
+    h_small.drop();
   }
 };
 
@@ -253,31 +281,36 @@ int ctcdec_set_hotwords(ctcdec_decoder* dec, const char* blob, const int64_t* of
   return CTCDEC_OK;
 }
 
+// Rebuild text + word frames of one beam from its emission list (root -> leaf). The text is written
+// in place: `open` is where the currently open (partial) word starts.
 static void replay(const ctcdec_decoder* d, const EmitNode* toks, uint32_t n, BeamResult* r) {
-  std::string cur;
-  auto close_word = [&](int32_t s, int32_t e) {
-    if (cur.empty()) return;
-    if (!r->text.empty()) r->text.push_back(' ');
-    r->word_off.push_back((int32_t)r->text.size());
-    r->text += cur;
+  std::string& text = r->text;
+  text.clear();
+  text.reserve((size_t)n * 3 + 8);
+  size_t open = 0;
+  auto close_word = [&](int32_t s, int32_t e, bool more) {
+    if (text.size() == open) return;  // empty open word: nothing to close
+    r->word_off.push_back((int32_t)open);
     r->start.push_back(s);
     r->end.push_back(e);
-    cur.clear();
+    if (more) text.push_back(' ');
+    open = text.size();
   };
   for (uint32_t k = 0; k < n; ++k) {
-    uint32_t br = toks[k].tok_branch >> 16, tok = toks[k].tok_branch & 0xFFFFu;
+    const uint32_t br = toks[k].tok_branch >> 16, tok = toks[k].tok_branch & 0xFFFFu;
     if (br == BR_BOUNDARY) {
-      close_word(toks[k].wstart, toks[k].wend);
-      cur = d->alpha.clean[tok];
+      close_word(toks[k].wstart, toks[k].wend, true);
+      text += d->alpha.clean[tok];
     } else if (br == BR_SPACE) {
-      close_word(toks[k].wstart, toks[k].wend);
+      close_word(toks[k].wstart, toks[k].wend, true);
     } else if (br == BR_APPEND) {
-      cur += d->alpha.labels[tok];
+      text += d->alpha.labels[tok];
     } else if (br == BR_FINAL) {
-      close_word(toks[k].wstart, toks[k].wend);
+      close_word(toks[k].wstart, toks[k].wend, false);
     }
   }
-  r->word_off.push_back((int32_t)r->text.size());
+  if (!text.empty() && text.back() == ' ' && open == text.size()) text.pop_back();  // no open word at the end
+  r->word_off.push_back((int32_t)text.size());
 }
 
 int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames,
@@ -355,9 +388,20 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
     pa.surv_id = (uint16_t*)dec->w_sid.p;
     pa.surv_lp = (double*)dec->w_slp.p;
     pa.overflow = (uint32_t*)dec->w_flags.p;
+    pa.pass = 0;
+    pa.rows_aligned16 = 1;
+    for (const void* q : ptrs)
+      if (((uintptr_t)q & 15u) != 0) pa.rows_aligned16 = 0;
     if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    uint32_t ovf = 0;
-    if (be::d2h(&ovf, dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    uint32_t flags[2] = {0, 0};
+    if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    if (flags[1]) {  // some utterance looks like probabilities (decoder.py:760): redo those rows
+      pa.pass = 1;
+      if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
+      if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    }
+    const uint32_t ovf = flags[0];
     if (!ovf) break;
     if (max_surv == V) return fail(CTCDEC_ERR_INTERNAL, "survivor overflow at full vocabulary");
     max_surv = V;  // un-normalised probability rows can exceed the bound: redo at full width
@@ -450,42 +494,77 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
   }
   if (be::launch_beam(ba, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
-  // results back
-  std::vector<uint32_t> n_out((size_t)n_utts), status((size_t)n_utts);
-  std::vector<OutBeam> obs((size_t)n_utts * n_best);
+  // results back (page-locked staging: the token pool is a few MB per batch)
+  const bool host_timing = getenv("CTCDEC_HOST_TIMING") != nullptr;
+  auto t_launch = std::chrono::steady_clock::now();
+  if (dec->h_small.ensure((size_t)n_utts * 8 + 16, &err) ||
+      dec->h_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  uint32_t* n_out = (uint32_t*)dec->h_small.p;
+  uint32_t* status = n_out + n_utts;
   unsigned long long head = 0;
-  if (be::d2h(n_out.data(), dec->w_nout.p, (size_t)n_utts * 4, &err) ||
-      be::d2h(status.data(), dec->w_status.p, (size_t)n_utts * 4, &err) ||
-      be::d2h(&head, dec->w_head.p, 8, &err))
+  if (be::d2h(n_out, dec->w_nout.p, (size_t)n_utts * 4, &err) ||
+      be::d2h(status, dec->w_status.p, (size_t)n_utts * 4, &err) || be::d2h(&head, dec->w_head.p, 8, &err))
     return fail(CTCDEC_ERR_DEVICE, err);
+  auto t_kernel = std::chrono::steady_clock::now();
   for (int32_t u = 0; u < n_utts; ++u)
-    if (status[(size_t)u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[(size_t)u]) +
-                                                                  " for utterance " + std::to_string(u));
-  if (be::d2h(obs.data(), dec->w_out.p, obs.size() * sizeof(OutBeam), &err)) return fail(CTCDEC_ERR_DEVICE, err);
-  std::vector<EmitNode> toks((size_t)head);
-  if (head && be::d2h(toks.data(), dec->w_tok.p, (size_t)head * sizeof(EmitNode), &err))
+    if (status[u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[u]) +
+                                                        " for utterance " + std::to_string(u));
+  const OutBeam* obs = (const OutBeam*)dec->h_out.p;
+  if (be::d2h(dec->h_out.p, dec->w_out.p, (size_t)n_utts * n_best * sizeof(OutBeam), &err))
     return fail(CTCDEC_ERR_DEVICE, err);
+  if (dec->h_tok.ensure((size_t)head * sizeof(EmitNode) + 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  const EmitNode* toks = (const EmitNode*)dec->h_tok.p;
+  if (head && be::d2h(dec->h_tok.p, dec->w_tok.p, (size_t)head * sizeof(EmitNode), &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  auto t_copy = std::chrono::steady_clock::now();
   be::last_timing(&res->ms[0], &res->ms[1]);
   if (dec->profile && be::d2h(dec->prof, dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
-  for (int32_t u = 0; u < n_utts; ++u) {
-    auto& beams = res->utts[(size_t)u];
-    beams.resize(n_out[(size_t)u]);
-    for (uint32_t k = 0; k < n_out[(size_t)u]; ++k) {
+  for (int32_t u = 0; u < n_utts; ++u)
+    for (uint32_t k = 0; k < n_out[u]; ++k) {
       const OutBeam& ob = obs[(size_t)u * n_best + k];
-      BeamResult& r = beams[k];
-      r.logit = ob.logit_score;
-      r.lm = ob.lm_score;
-      r.state.length = ob.state.len;
-      for (int j = 0; j < MAX_CTX; ++j) {
-        r.state.words[j] = ob.state.words[j];
-        r.state.backoff[j] = ob.state.backoff[j];
-      }
       if ((unsigned long long)ob.tok_off + ob.tok_cnt > head) return fail(CTCDEC_ERR_INTERNAL, "token pool range");
-      replay(dec, toks.data() + ob.tok_off, ob.tok_cnt, &r);
     }
+  auto replay_range = [&](int32_t u0, int32_t u1) {
+    for (int32_t u = u0; u < u1; ++u) {
+      auto& beams = res->utts[(size_t)u];
+      beams.resize(n_out[u]);
+      for (uint32_t k = 0; k < n_out[u]; ++k) {
+        const OutBeam& ob = obs[(size_t)u * n_best + k];
+        BeamResult& r = beams[k];
+        r.logit = ob.logit_score;
+        r.lm = ob.lm_score;
+        r.state.length = ob.state.len;
+        for (int j = 0; j < MAX_CTX; ++j) {
+          r.state.words[j] = ob.state.words[j];
+          r.state.backoff[j] = ob.state.backoff[j];
+        }
+        replay(dec, toks + ob.tok_off, ob.tok_cnt, &r);
+      }
+    }
+  };
+  // host replay is independent per utterance: a few threads once there is enough of it
+  int n_thr = (head > 50000 && n_utts >= 16) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+  if (n_thr <= 1) {
+    replay_range(0, n_utts);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_thr; ++t) {
+      int32_t u0 = (int32_t)((int64_t)n_utts * t / n_thr), u1 = (int32_t)((int64_t)n_utts * (t + 1) / n_thr);
+      pool.emplace_back(replay_range, u0, u1);
+    }
+    for (auto& th : pool) th.join();
   }
-  res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  auto t_end = std::chrono::steady_clock::now();
+  res->ms[2] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
+  if (host_timing) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    fprintf(stderr, "[ctcdec host] setup+launch %.3f ms, wait kernels %.3f ms, copy back %.3f ms (%llu tokens), replay %.3f ms\n",
+            ms(t_begin, t_launch), ms(t_launch, t_kernel), ms(t_kernel, t_copy), head, ms(t_copy, t_end));
+  }
   *out = res.release();
   return CTCDEC_OK;
 }

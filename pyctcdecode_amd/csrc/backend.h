@@ -17,6 +17,8 @@ const char* name();
 int init(int device, std::string* err);
 void* alloc(size_t bytes, std::string* err);
 void release(void* p);
+void* alloc_host(size_t bytes, std::string* err);  // page-locked staging memory for result copies
+void release_host(void* p);
 int h2d(void* dst, const void* src, size_t bytes, std::string* err);
 int d2h(void* dst, const void* src, size_t bytes, std::string* err);
 int zero(void* dst, size_t bytes, std::string* err);
@@ -38,7 +40,9 @@ struct PruneArgs {
   uint32_t* surv_cnt;    // [n_rows]
   uint16_t* surv_id;     // [n_rows * max_surv]
   double* surv_lp;       // [n_rows * max_surv]
-  uint32_t* overflow;    // [1] set when a row had more than max_surv survivors
+  uint32_t* overflow;    // [2] [0]: a row had more than max_surv survivors, [1]: a probability-like utterance exists
+  int32_t pass;          // 0: all utterances as logits + row sums + sniff; 1: redo the probability-like ones
+  int32_t rows_aligned16; // every utterance base pointer is 16-byte aligned
 };
 int launch_prune(const PruneArgs& a, std::string* err);
 

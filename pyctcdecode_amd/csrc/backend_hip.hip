@@ -1,10 +1,12 @@
 // backend_hip.hip -- the product backend: HIP kernels for gfx950 (MI355X, CDNA4, wave64).
 //
-//   frame_rowsum / utt_sniff  input sniff of decoder.py:760 (mean row sum ~ 1 => probabilities)
-//   frame_prune               log-softmax + clip (decoder.py:180-197,762-765), token prune and
-//                             argmax (decoder.py:444-445), CPython-set ordering (set_order.h);
-//                             one wave per frame row, fully parallel over all frames of the batch
-//                             -- this is the stage that streams the [T x V] logits from HBM once
+//   frame_prune[_f32x4]       log-softmax + clip (decoder.py:180-197,762-765), token prune and
+//                             argmax (decoder.py:444-445), CPython-set ordering (set_order.h), row
+//                             sums for the input sniff; one wave per frame row, fully parallel over
+//                             all frames of the batch -- the stage that streams the [T x V] logits
+//                             from HBM exactly once (fp32 rows live in registers)
+//   utt_sniff                 decoder.py:760 (mean row sum ~ 1 => probabilities; those utterances
+//                             get a second frame_prune pass with log(clip(p)))
 //   beam_decode               the sequential prefix-beam recursion (beam_core.h); one workgroup
 //                             per utterance, beam table / candidates / merge table in LDS
 #include <hip/hip_runtime.h>
@@ -63,6 +65,16 @@ void* alloc(size_t bytes, std::string* err) {
   return p;
 }
 void release(void* p) { (void)hipFree(p); }
+void* alloc_host(size_t bytes, std::string* err) {
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    if (err) *err = std::string("hipHostMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    return nullptr;
+  }
+  return p;
+}
+void release_host(void* p) { (void)hipHostFree(p); }
 int h2d(void* d, const void* s, size_t n, std::string* err) {
   HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
   HIP_TRY(hipStreamSynchronize(g_stream));  // the source is caller memory that may be reused
@@ -123,19 +135,6 @@ __device__ __forceinline__ int find_utt(const int64_t* row0, int n_utts, int64_t
 
 constexpr int PRUNE_WAVES = 4;  // rows per 256-thread block
 
-template <typename T>
-__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_rowsum(PruneArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + (threadIdx.x >> 6);
-  if (row >= a.n_rows) return;
-  const int u = find_utt(a.utt_row0, a.n_utts, row);
-  const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * a.n_labels;
-  double s = 0.0;
-  for (int v = lane; v < a.n_labels; v += 64) s += ld(x, v);
-  s = wave_sum(s);
-  if (lane == 0) a.row_sum[row] = s;
-}
-
 __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
   const int u = blockIdx.x;
   const int lane = threadIdx.x;
@@ -148,84 +147,41 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
     // math.isclose(mean, 1): |mean - 1| <= 1e-9 * max(|mean|, 1)   (decoder.py:760)
     bool is_prob = fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
+    if (is_prob) a.overflow[1] = 1u;  // flags[1]: some utterance needs the probability pass
   }
 }
 
-// One wave per frame row.  LDS per wave: ascending survivor ids + their log-probs, the two CPython
-// set tables, a resize scratch and the ordered id list.
-template <typename T>
-__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+// per-wave LDS work area of the prune kernels
+struct PruneLds {
+  double* asc_lp;
+  uint16_t *asc_id, *order, *tabA, *tabR, *scratch;
+};
+__host__ __device__ inline size_t prune_lds_bytes(size_t ms, size_t cap) {
+  return (((ms + 1) * 8 + 15) & ~(size_t)15) + (((ms + 2) * 2 * 2 + 15) & ~(size_t)15) +
+         ((cap * 2 * 3 + 15) & ~(size_t)15);
+}
+__device__ __forceinline__ PruneLds prune_lds(char* smem, int wave, uint32_t ms, uint32_t cap) {
+  char* base = smem + prune_lds_bytes(ms, cap) * wave;
+  PruneLds w;
+  w.asc_lp = (double*)base;
+  w.asc_id = (uint16_t*)(base + (((size_t)(ms + 1) * 8 + 15) & ~(size_t)15));
+  w.order = w.asc_id + (ms + 2);
+  w.tabA = (uint16_t*)((char*)w.asc_id + (((size_t)(ms + 2) * 2 * 2 + 15) & ~(size_t)15));
+  w.tabR = w.tabA + cap;
+  w.scratch = w.tabR + cap;
+  return w;
+}
+
+// Common tail: argmax across the wave (first maximum, like numpy), CPython-set ordering on lane 0,
+// coalesced write of the ordered (id, logp) list.
+__device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, int lane, const PruneLds& w, uint32_t n,
+                                             double best, int best_id) {
   const uint32_t ms = (uint32_t)a.max_surv;
-  const size_t per_wave = (((size_t)(ms + 1) * 8 + 15) & ~(size_t)15) + (((size_t)(ms + 2) * 2 * 2 + 15) & ~(size_t)15) +
-                          (((size_t)cap * 2 * 3 + 15) & ~(size_t)15);
-  char* base = smem + per_wave * wave;
-  double* asc_lp = (double*)base;
-  uint16_t* asc_id = (uint16_t*)(base + (((size_t)(ms + 1) * 8 + 15) & ~(size_t)15));
-  uint16_t* order = asc_id + (ms + 2);
-  uint16_t* tabA = (uint16_t*)((char*)asc_id + (((size_t)(ms + 2) * 2 * 2 + 15) & ~(size_t)15));
-  uint16_t* tabR = tabA + cap;
-  uint16_t* scratch = tabR + cap;
-  if (row >= a.n_rows) return;
-  const int V = a.n_labels;
-  const int u = find_utt(a.utt_row0, a.n_utts, row);
-  const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V;
-  const bool is_prob = a.utt_is_prob[u] != 0;
-  const double clip_lo = -34.538776394910684;  // ln(1e-15)
-  double mx = 0.0, lse = 0.0;
-  if (!is_prob) {
-    double m = -INFINITY;
-    for (int v = lane; v < V; v += 64) m = fmax(m, ld(x, v));
-    m = wave_max(m);
-    if (!isfinite(m)) m = 0.0;  // decoder.py:186-189
-    double s = 0.0;
-    for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
-    s = wave_sum(s);
-    mx = m;
-    lse = log(s);
-  }
-  // pass 3: log-probabilities, survivors in ascending id order, argmax (first maximum)
-  uint32_t n = 0;
-  double best = -INFINITY;
-  int best_id = 0x7FFFFFFF;
   bool overflow = false;
-  for (int v0 = 0; v0 < V; v0 += 64) {
-    int v = v0 + lane;
-    double y = -INFINITY;
-    bool in = v < V;
-    if (in) {
-      double xv = ld(x, v);
-      if (is_prob) {
-        double p = xv < 1e-15 ? 1e-15 : (xv > 1.0 ? 1.0 : xv);
-        y = log(p);
-      } else {
-        y = (xv - mx) - lse;
-        y = y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
-      }
-      if (y > best) {
-        best = y;
-        best_id = v;
-      }
-    }
-    bool keep = in && y >= a.token_min_logp;
-    unsigned long long mask = __ballot(keep);
-    if (keep) {
-      uint32_t pos = n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < ms) {
-        asc_id[pos] = (uint16_t)v;
-        asc_lp[pos] = y;
-      }
-    }
-    n += (uint32_t)__popcll(mask);
-  }
   if (n > ms) {
     overflow = true;
     n = ms;
   }
-  // argmax reduce: larger value wins, equal values -> smaller index (numpy argmax)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     double ob = __shfl_xor(best, off, 64);
@@ -238,7 +194,7 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
   uint32_t m = 0;
-  if (lane == 0) m = cpython_set_order(asc_id, n, (uint32_t)best_id, tabA, tabR, scratch, order);
+  if (lane == 0) m = cpython_set_order(w.asc_id, n, (uint32_t)best_id, w.tabA, w.tabR, w.scratch, w.order);
   m = __shfl(m, 0, 64);
   __threadfence_block();
   if (m > ms) {
@@ -247,54 +203,218 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
   }
   if (lane == 0) {
     a.surv_cnt[row] = m;
-    if (overflow) *a.overflow = 1u;
+    if (overflow) a.overflow[0] = 1u;
   }
   uint16_t* out_id = a.surv_id + (size_t)row * ms;
   double* out_lp = a.surv_lp + (size_t)row * ms;
   for (uint32_t k = lane; k < m; k += 64) {
-    uint32_t id = order[k];
+    uint32_t id = w.order[k];
     // binary search the ascending list for the log-prob (the argmax may be absent: below threshold)
     double lp = best;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
       uint32_t mid = (lo + hi) >> 1;
-      if (asc_id[mid] < id) lo = mid + 1; else hi = mid;
+      if (w.asc_id[mid] < id) lo = mid + 1; else hi = mid;
     }
-    if (lo < n && asc_id[lo] == id) lp = asc_lp[lo];
+    if (lo < n && w.asc_id[lo] == id) lp = w.asc_lp[lo];
     out_id[k] = (uint16_t)id;
     out_lp[k] = lp;
   }
 }
 
+__device__ __forceinline__ double to_logp(double xv, bool is_prob, double mx, double lse) {
+  const double clip_lo = -34.538776394910684;  // ln(1e-15)
+  if (is_prob) {
+    double p = xv < 1e-15 ? 1e-15 : (xv > 1.0 ? 1.0 : xv);
+    return log(p);
+  }
+  double y = (xv - mx) - lse;
+  return y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
+}
+
+// Generic frame-prune: one wave per frame row, any V / dtype; the row is swept three times (max and
+// row sum, sum of exponentials, selection) and stays in L1/L2 between sweeps.
+// pass 0: every utterance is treated as logits (the overwhelmingly common case) and the row sums for the
+//         probability sniff are produced on the way; pass 1 (only launched when utt_sniff found
+//         probability-like utterances) redoes just those utterances with log(clip(p)).
+template <typename T>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  if (row >= a.n_rows) return;
+  const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
+  const int V = a.n_labels;
+  const int u = find_utt(a.utt_row0, a.n_utts, row);
+  const bool is_prob = a.pass == 1;
+  if (is_prob && !a.utt_is_prob[u]) return;
+  const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V;
+  double mx = 0.0, lse = 0.0;
+  if (!is_prob) {
+    double m = -INFINITY, rs = 0.0;
+    for (int v = lane; v < V; v += 64) {
+      double xv = ld(x, v);
+      m = fmax(m, xv);
+      rs += xv;
+    }
+    m = wave_max(m);
+    rs = wave_sum(rs);
+    if (lane == 0) a.row_sum[row] = rs;
+    if (!isfinite(m)) m = 0.0;  // decoder.py:186-189
+    double s = 0.0;
+    for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
+    s = wave_sum(s);
+    mx = m;
+    lse = log(s);
+  }
+  uint32_t n = 0;
+  double best = -INFINITY;
+  int best_id = 0x7FFFFFFF;
+  const uint32_t ms = (uint32_t)a.max_surv;
+  for (int v0 = 0; v0 < V; v0 += 64) {
+    int v = v0 + lane;
+    double y = -INFINITY;
+    bool in = v < V;
+    if (in) {
+      y = to_logp(ld(x, v), is_prob, mx, lse);
+      if (y > best) {
+        best = y;
+        best_id = v;
+      }
+    }
+    bool keep = in && y >= a.token_min_logp;
+    unsigned long long mask = __ballot(keep);
+    if (keep) {
+      uint32_t pos = n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < ms) {
+        w.asc_id[pos] = (uint16_t)v;
+        w.asc_lp[pos] = y;
+      }
+    }
+    n += (uint32_t)__popcll(mask);
+  }
+  prune_finish(a, row, lane, w, n, best, best_id);
+}
+
+// Register-resident frame-prune for fp32 rows with V % 4 == 0 and V <= 1024*... (NC chunks of 256
+// labels): each lane pulls its 4*NC logits with 16-byte loads ONCE (1 KiB per wave-instruction, fully
+// coalesced) and all three sweeps run out of registers: the logits cross HBM exactly once.
+template <int NC>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  if (row >= a.n_rows) return;
+  const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
+  const int V = a.n_labels;
+  const int u = find_utt(a.utt_row0, a.n_utts, row);
+  const bool is_prob = a.pass == 1;
+  if (is_prob && !a.utt_is_prob[u]) return;
+  const float4* x4 = (const float4*)((const float*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V);
+  const int n4 = V >> 2;
+  float4 r[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int i4 = k * 64 + lane;
+    r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  }
+  double mx = 0.0, lse = 0.0;
+  if (!is_prob) {
+    float mf = -INFINITY;
+    double rs = 0.0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (k * 64 + lane < n4) {
+        mf = fmaxf(fmaxf(mf, fmaxf(r[k].x, r[k].y)), fmaxf(r[k].z, r[k].w));
+        rs += ((double)r[k].x + (double)r[k].y) + ((double)r[k].z + (double)r[k].w);
+      }
+    }
+    double m = wave_max((double)mf);
+    rs = wave_sum(rs);
+    if (lane == 0) a.row_sum[row] = rs;
+    if (!isfinite(m)) m = 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (k * 64 + lane < n4)
+        s += (exp((double)r[k].x - m) + exp((double)r[k].y - m)) + (exp((double)r[k].z - m) + exp((double)r[k].w - m));
+    }
+    s = wave_sum(s);
+    mx = m;
+    lse = log(s);
+  }
+  uint32_t n = 0;
+  double best = -INFINITY;
+  int best_id = 0x7FFFFFFF;
+  const uint32_t ms = (uint32_t)a.max_surv;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const bool in = k * 64 + lane < n4;
+    const int v0 = (k * 64 + lane) * 4;
+    double y0 = -INFINITY, y1 = -INFINITY, y2 = -INFINITY, y3 = -INFINITY;
+    if (in) {
+      y0 = to_logp((double)r[k].x, is_prob, mx, lse);
+      y1 = to_logp((double)r[k].y, is_prob, mx, lse);
+      y2 = to_logp((double)r[k].z, is_prob, mx, lse);
+      y3 = to_logp((double)r[k].w, is_prob, mx, lse);
+      if (y0 > best) { best = y0; best_id = v0; }
+      if (y1 > best) { best = y1; best_id = v0 + 1; }
+      if (y2 > best) { best = y2; best_id = v0 + 2; }
+      if (y3 > best) { best = y3; best_id = v0 + 3; }
+    }
+    const bool k0 = in && y0 >= a.token_min_logp, k1 = in && y1 >= a.token_min_logp;
+    const bool k2 = in && y2 >= a.token_min_logp, k3 = in && y3 >= a.token_min_logp;
+    const unsigned long long any = __ballot(k0 || k1 || k2 || k3);
+    if (any) {  // ascending id order inside the chunk = (lane, element)
+      const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
+      uint32_t pos = n + (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+      if (k0) { if (pos < ms) { w.asc_id[pos] = (uint16_t)v0; w.asc_lp[pos] = y0; } ++pos; }
+      if (k1) { if (pos < ms) { w.asc_id[pos] = (uint16_t)(v0 + 1); w.asc_lp[pos] = y1; } ++pos; }
+      if (k2) { if (pos < ms) { w.asc_id[pos] = (uint16_t)(v0 + 2); w.asc_lp[pos] = y2; } ++pos; }
+      if (k3) { if (pos < ms) { w.asc_id[pos] = (uint16_t)(v0 + 3); w.asc_lp[pos] = y3; } ++pos; }
+      n += (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+    }
+  }
+  prune_finish(a, row, lane, w, n, best, best_id);
+}
+
 int launch_prune(const PruneArgs& a, std::string* err) {
-  g_timing_valid = false;
-  HIP_TRY(hipEventRecord(g_ev[0], g_stream));
+  if (a.pass == 0) {
+    g_timing_valid = false;
+    HIP_TRY(hipEventRecord(g_ev[0], g_stream));
+  }
   if (a.n_rows > 0) {
     uint32_t cap = set_table_cap((uint32_t)a.max_surv + 1);
-    size_t ms = (size_t)a.max_surv;
-    size_t per_wave = (((ms + 1) * 8 + 15) & ~(size_t)15) + (((ms + 2) * 2 * 2 + 15) & ~(size_t)15) +
-                      (((size_t)cap * 2 * 3 + 15) & ~(size_t)15);
-    size_t lds = per_wave * PRUNE_WAVES;
+    size_t lds = prune_lds_bytes((size_t)a.max_surv, cap) * PRUNE_WAVES;
     if (lds > 160 * 1024) {
       if (err) *err = "token_min_logp admits too many labels per frame for the LDS set tables";
       return -1;
     }
     dim3 grid((unsigned)((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES)), block(PRUNE_WAVES * 64);
-    if (a.dtype == 0) {
-      hipLaunchKernelGGL(frame_rowsum<float>, grid, block, 0, g_stream, a);
+    const bool vec4 = a.dtype == 0 && (a.n_labels % 4) == 0 && a.n_labels <= 1024 && a.rows_aligned16;
+#define CTC_LAUNCH_PRUNE(KERN)                                                                                 \
+  do {                                                                                                         \
+    HIP_TRY(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+    hipLaunchKernelGGL(KERN, grid, block, lds, g_stream, a, cap);                                              \
+  } while (0)
+    if (vec4) {
+      const int nc = (a.n_labels / 4 + 63) / 64;
+      if (nc <= 1) CTC_LAUNCH_PRUNE(frame_prune_f32x4<1>);
+      else if (nc == 2) CTC_LAUNCH_PRUNE(frame_prune_f32x4<2>);
+      else if (nc == 3) CTC_LAUNCH_PRUNE(frame_prune_f32x4<3>);
+      else CTC_LAUNCH_PRUNE(frame_prune_f32x4<4>);
+    } else if (a.dtype == 0) {
+      CTC_LAUNCH_PRUNE(frame_prune<float>);
     } else {
-      hipLaunchKernelGGL(frame_rowsum<double>, grid, block, 0, g_stream, a);
+      CTC_LAUNCH_PRUNE(frame_prune<double>);
     }
-    hipLaunchKernelGGL(utt_sniff, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
-    if (a.dtype == 0) {
-      HIP_TRY(hipFuncSetAttribute((const void*)frame_prune<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(frame_prune<float>, grid, block, lds, g_stream, a, cap);
-    } else {
-      HIP_TRY(hipFuncSetAttribute((const void*)frame_prune<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(frame_prune<double>, grid, block, lds, g_stream, a, cap);
-    }
+#undef CTC_LAUNCH_PRUNE
     HIP_TRY(hipGetLastError());
-  } else if (a.n_utts > 0) {
+  }
+  if (a.pass == 0 && a.n_utts > 0) {
     hipLaunchKernelGGL(utt_sniff, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
     HIP_TRY(hipGetLastError());
   }
@@ -416,10 +536,10 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     return -1;
   }
   if (a.n_utts > 0) {
-    // Threads per utterance: the recursion is latency-bound and a typical frame has ~100 candidates, so
-    // one wave per utterance (no cross-wave barriers) wins as soon as there are enough utterances to
-    // occupy the CUs; few utterances get four waves each. CTCDEC_BEAM_THREADS overrides (tuning only).
-    int nt = a.n_utts >= 128 ? 64 : 256;
+    // Threads per utterance: four waves. Measured on MI355X (512 utterances, beam 100): 256 threads
+    // 16.4 ms, 128 threads 17.6 ms, 64 threads 20.4 ms -- the phases are short but wide enough that the
+    // extra lanes pay for the cross-wave barriers. CTCDEC_BEAM_THREADS overrides (tuning only).
+    int nt = 256;
     if (const char* env = getenv("CTCDEC_BEAM_THREADS")) {
       int v = atoi(env);
       if (v == 64 || v == 128 || v == 256) nt = v;

@@ -561,9 +561,9 @@ struct BeamDecoder {
   // index of rank r for r < min(count, beam_width). Returns the count (may exceed beam_width).
   // Entries are first compacted (typically ~25 of ~100 survive the threshold); small sets are ranked by
   // counting (one LDS sweep, no barriers), large ones by a bitonic network.
-  CTC_HD uint32_t sort_pool(uint32_t pool_n, double thr) {
-    if (ctx.tid == 0) L.scal[5] = 0;
-    ctx.sync();
+  // (scal[5], the compaction counter, is zero on entry: init() and the end of this function see to it.)
+  // with_hist: also leave the history-prune key of rank r in hk_*[r] (decoder.py:250-254).
+  CTC_HD uint32_t sort_pool(uint32_t pool_n, double thr, bool with_hist) {
     tick<17>();
     for (uint32_t k = ctx.tid; k < pool_n; k += ctx.nt) {
       double sc = L.p_score[k];
@@ -594,9 +594,22 @@ struct BeamDecoder {
           uint64_t b0 = L.s_k0[j], b1 = L.s_k1[j];
           rank += ((b0 < a0) || (b0 == a0 && b1 < a1)) ? 1u : 0u;
         }
-        if (rank < want) L.sel[rank] = (uint32_t)(a1 & 0xFFFFFFFFu);
+        if (rank < want) {
+          const uint32_t idx = (uint32_t)(a1 & 0xFFFFFFFFu);
+          L.sel[rank] = idx;
+          L.keep[rank] = 1u;
+          if (with_hist) {
+            uint64_t hh, ph;
+            uint32_t cc;
+            hist_key(idx, &hh, &ph, &cc);
+            L.hk_h[rank] = hh;
+            L.hk_p[rank] = ph;
+            L.hk_c[rank] = cc;
+          }
+        }
       }
       ctx.sync();
+      if (ctx.tid == 0) L.scal[5] = 0;
       return n;
     }
     uint32_t p2 = 512;
@@ -624,8 +637,21 @@ struct BeamDecoder {
         ctx.sync();
       }
     }
-    for (uint32_t r = ctx.tid; r < want && r < n; r += ctx.nt) L.sel[r] = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFull);
+    for (uint32_t r = ctx.tid; r < want && r < n; r += ctx.nt) {
+      const uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFull);
+      L.sel[r] = idx;
+      L.keep[r] = 1u;
+      if (with_hist) {
+        uint64_t hh, ph;
+        uint32_t cc;
+        hist_key(idx, &hh, &ph, &cc);
+        L.hk_h[r] = hh;
+        L.hk_p[r] = ph;
+        L.hk_c[r] = cc;
+      }
+    }
     ctx.sync();
+    if (ctx.tid == 0) L.scal[5] = 0;
     return n;
   }
 
@@ -633,7 +659,7 @@ struct BeamDecoder {
   CTC_HD void prune_pool() {
     uint32_t pool_n = L.scal[0];
     double mx = sortable_to_max();
-    uint32_t n = sort_pool(pool_n, mx + prm.beam_prune_logp);
+    uint32_t n = sort_pool(pool_n, mx + prm.beam_prune_logp, false);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     // gather the survivors through the temp arrays, then rewrite the pool front
     for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
@@ -980,56 +1006,43 @@ struct BeamDecoder {
   CTC_HD void finish_frame(int frame, bool final_stage) {
     uint32_t pool_n = L.scal[0];
     double thr = sortable_to_max() + prm.beam_prune_logp;
-    uint32_t n = sort_pool(pool_n, thr);
+    const bool hist = prm.prune_history && !final_stage;
+    uint32_t n = sort_pool(pool_n, thr, hist);
     tick<7>();
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     const BeamSoA nb = beams_at(cur ^ 1);
     if (final_stage) {
-      if (ctx.tid == 0) L.scal[5] = n;
+      if (ctx.tid == 0) L.scal[9] = n;
       ctx.sync();
       return;
     }
-    if (prm.prune_history) {
-      // first of each (history, partial, last_char) in sorted order wins
-      for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
-        uint32_t idx = L.sel[r];
-        uint64_t hh, ph;
-        uint32_t cc;
-        hist_key(idx, &hh, &ph, &cc);
-        L.hk_h[r] = hh;
-        L.hk_p[r] = ph;
-        L.hk_c[r] = cc;
+    if (hist) {
+      // first of each (history, partial, last_char) in sorted order wins (decoder.py:248-257).
+      // The r2 < r pair space is tiled 16 x 16 over the threads so that no thread walks a whole row.
+      const uint32_t ta = (uint32_t)ctx.tid >> 4, tb = (uint32_t)ctx.tid & 15u;
+      const uint32_t step_a = ctx.nt >= 16 ? (uint32_t)ctx.nt >> 4 : 1u;
+      const uint32_t step_b = ctx.nt >= 16 ? 16u : 1u;
+      for (uint32_t r = (ctx.nt >= 16 ? ta : 0u); r < n; r += step_a) {
+        const uint64_t hh = L.hk_h[r], ph = L.hk_p[r];
+        const uint32_t cc = L.hk_c[r];
+        uint32_t dup = 0;
+        for (uint32_t r2 = (ctx.nt >= 16 ? tb : 0u); r2 < r; r2 += step_b)
+          dup |= (L.hk_h[r2] == hh && L.hk_p[r2] == ph && L.hk_c[r2] == cc) ? 1u : 0u;
+        if (dup) L.keep[r] = 0u;  // keep[] was preset to 1 by the ranking phase
       }
       ctx.sync();
-      tick<19>();
-      for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
-        uint64_t hh = L.hk_h[r], ph = L.hk_p[r];
-        uint32_t cc = L.hk_c[r];
-        uint32_t dup = 0;
-        uint32_t r2 = 0;
-        for (; r2 + 4 <= r; r2 += 4) {  // no early exit: independent LDS reads pipeline
-          uint64_t h0 = L.hk_h[r2], h1 = L.hk_h[r2 + 1], h2 = L.hk_h[r2 + 2], h3 = L.hk_h[r2 + 3];
-          uint64_t p0 = L.hk_p[r2], p1 = L.hk_p[r2 + 1], p2 = L.hk_p[r2 + 2], p3 = L.hk_p[r2 + 3];
-          uint32_t c0 = L.hk_c[r2], c1 = L.hk_c[r2 + 1], c2 = L.hk_c[r2 + 2], c3 = L.hk_c[r2 + 3];
-          dup |= (h0 == hh && p0 == ph && c0 == cc) ? 1u : 0u;
-          dup |= (h1 == hh && p1 == ph && c1 == cc) ? 1u : 0u;
-          dup |= (h2 == hh && p2 == ph && c2 == cc) ? 1u : 0u;
-          dup |= (h3 == hh && p3 == ph && c3 == cc) ? 1u : 0u;
-        }
-        for (; r2 < r; ++r2) dup |= (L.hk_h[r2] == hh && L.hk_p[r2] == ph && L.hk_c[r2] == cc) ? 1u : 0u;
-        L.keep[r] = dup ? 0u : 1u;
-      }
-    } else {
-      for (uint32_t r = ctx.tid; r < n; r += ctx.nt) L.keep[r] = 1u;
     }
-    ctx.sync();
     tick<20>();
     for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
-      uint32_t dst = 0;
-      uint32_t r2 = 0;
-      for (; r2 + 4 <= r; r2 += 4) dst += L.keep[r2] + L.keep[r2 + 1] + L.keep[r2 + 2] + L.keep[r2 + 3];
-      for (; r2 < r; ++r2) dst += L.keep[r2];
-      const uint32_t kept = L.keep[r];
+      uint32_t dst = r;
+      uint32_t kept = 1u;
+      if (hist) {
+        dst = 0;
+        uint32_t r2 = 0;
+        for (; r2 + 4 <= r; r2 += 4) dst += L.keep[r2] + L.keep[r2 + 1] + L.keep[r2 + 2] + L.keep[r2 + 3];
+        for (; r2 < r; ++r2) dst += L.keep[r2];
+        kept = L.keep[r];
+      }
       if (r == n - 1) L.scal[7] = dst + kept;  // size of the next beam table
       if (kept) build_beam(nb, (int)dst, L.sel[r], frame);
     }
@@ -1037,9 +1050,6 @@ struct BeamDecoder {
     ctx.sync();
     N = (int)L.scal[7];
     cur ^= 1;
-    ctx.sync();
-    if (ctx.tid == 0) L.scal[7] = 0;
-    ctx.sync();
     tick<8>();
   }
 
@@ -1169,7 +1179,7 @@ struct BeamDecoder {
       ctx.sync();
     }
     finish_frame(0, true);
-    uint32_t n = L.scal[5];
+    uint32_t n = L.scal[9];
     uint32_t n_out = n;
     if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
     // output records + back-trace of each returned beam's emission chain

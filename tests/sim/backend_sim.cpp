@@ -44,6 +44,8 @@ void* alloc(size_t bytes, std::string* err) {
   return p;
 }
 void release(void* p) { free(p); }
+void* alloc_host(size_t bytes, std::string* err) { return alloc(bytes, err); }
+void release_host(void* p) { free(p); }
 int h2d(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int d2h(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int zero(void* d, size_t n, std::string*) { memset(d, 0, n); return 0; }
@@ -55,6 +57,7 @@ static double load(const void* base, int dtype, size_t idx) {
 }
 
 int launch_prune(const PruneArgs& a, std::string*) {
+  if (a.pass != 0) return 0;  // the sequential reference resolves the input kind exactly in pass 0
   const int V = a.n_labels;
   const double clip_lo = log(1e-15);
   std::vector<double> lp((size_t)V);

@@ -17,7 +17,7 @@ def build(force: bool = False) -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-DCTC_SIM", "-Wall", "-Wno-unused-function",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-DCTC_SIM", "-Wall", "-Wno-unused-function",
            "-o", OUT] + SOURCES
     subprocess.check_call(cmd)
     return OUT
