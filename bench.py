@@ -184,6 +184,17 @@ def main():
         dominant = "beam_decode" if beam_avg >= prune_avg else "frame_prune"
         dom_ms = max(beam_avg, prune_avg)
         achieved = algo_bytes / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
+        traffic = None
+        traffic_src = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(pmc_path) and args.batch == 512 and args.frames == T:
+            # PMC counters cannot be collected from inside this process; they come from the committed
+            # rocprofv3 --pmc passes of this very command (profiles/r01_pmc_hbm_traffic.json)
+            with open(pmc_path) as f:
+                pmc = json.load(f)["kernels"]
+            k = pmc["beam_decode<128,256>"] if dominant == "beam_decode" else pmc["frame_prune_f32x4<4>"]
+            traffic = (k.get("fetch_bytes_corrected") or k.get("fetch_bytes_raw", 0)) + 1024.0 * k["WRITE_SIZE_KiB_raw"]
+            traffic_src = "profiles/r01_pmc_hbm_traffic.json (FETCH_SIZE + WRITE_SIZE per launch)"
         out = {
             "metric": "logit-frames/sec (whole node) at beam=100, V=1024, 4-gram LM",
             "value": value,
@@ -214,7 +225,8 @@ def main():
                 "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": dom_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
             },

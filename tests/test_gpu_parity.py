@@ -158,3 +158,59 @@ def test_hip_oracle_one_full_length_utterance(lm, bpe):
     got = dec.decode_beams(x, hotwords=hot, prune_history=True)
     exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="full")
+
+
+def test_hip_config2_full_size_char_nolm_stress():
+    """BASELINE config 2 at full size (29-char alphabet, no LM, beam 100, batch 256 x T=1000) on the
+    stress distribution D_flat (~2 500 candidates per frame: chunked merge + pool pruning + bitonic
+    path). The oracle needs ~17 s per such utterance, so: size-independent properties at full size, and
+    one T=120 prefix-free utterance against the oracle."""
+    import time
+
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS)
+    xs = [synth.d_flat(2, u, 1000, 29) for u in range(256)]
+    dev = [torch.from_numpy(x).cuda() for x in xs]
+    dec.decode_batch(None, dev[:4])
+    t0 = time.perf_counter()
+    texts = dec.decode_batch(None, dev)
+    dt = time.perf_counter() - t0
+    print("config2 D_flat: %.1f ms for 256x1000 frames (%.2f M frames/s)" % (1e3 * dt, 256e3 / dt / 1e6))
+    assert len(texts) == 256 and all(isinstance(t, str) and len(t) > 0 for t in texts)
+    assert texts == dec.decode_batch(None, dev[::-1])[::-1]          # permutation invariance
+    assert texts[:3] == [dec.decode(x) for x in xs[:3]]               # batch == single, host == device
+    beams = dec.decode_beams(dev[0], prune_history=True)
+    assert beams[0].text == texts[0]
+    assert [b.lm_score for b in beams] == sorted((b.lm_score for b in beams), reverse=True)
+    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe)
+    x = synth.d_flat(2, 999, 120, 29)
+    exp = _oracle_expected(orc, x.astype(np.float64), {})
+    got = dec.decode_beams(x)
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="cfg2")
+
+
+def test_hip_config3_hf_vocab_lm_full_length():
+    """BASELINE config 3 shape (HF Wav2Vec2 char vocab V=32, 4-gram, alpha 0.5 beta 1.0, beam 100):
+    a ragged batch incl. one T=1000 utterance against the oracle."""
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    lm_u = synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2, upper=True)
+    kw = {"alpha": 0.5, "beta": 1.0}
+    dec = build_ctcdecoder(synth.HF_W2V2_LABELS, lm_u.path, **kw)
+    alpha = Alphabet.build_alphabet(synth.HF_W2V2_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm_u.path, None, **kw)
+    xs = [synth.d_words(3, u, T, synth.HF_W2V2_LABELS, False, lm_u.words, lm_u.sentences, 0, boost=6.0,
+                        space_label="|") for u, T in enumerate([1000, 130, 77])]
+    got = dec.decode_batch(None, xs)
+    assert got == [orc.decode(x.astype(np.float64)) for x in xs]
+    beams = dec.decode_beams(xs[1])
+    exp = _oracle_expected(orc, xs[1].astype(np.float64), {})
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in beams], exp, tol=TOL, what="cfg3")
