@@ -124,6 +124,32 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits,
                         const ctcdec_params* params, const ctcdec_lm_state* start_states,
                         ctcdec_result** out);
 
+/* ---- streaming: replaces partial_decode_beams (decoder.py:681-728) for a batch of streams -------
+ * Every stream hands back the beams the previous call returned (rank order). Strings travel as
+ * byte ranges of text_blob: `text` = completed words separated by single spaces, `partial` = the
+ * open partial_word. raw_lm_score / lm_state are the memo values of the text
+ * (cached_lm_scores[(text, False)], decoder.py:121-126); (0, LM start state) for the empty text.
+ * force_next_word / is_end as in decoder.py:693-694. Results: the packed view incl. its streaming
+ * extras; word frames there are only the words closed during THIS call. */
+typedef struct ctcdec_beam_in {
+  double logit_score;
+  double raw_lm_score;
+  ctcdec_lm_state lm_state;
+  int32_t last_char;          /* label index, -1 = None */
+  int32_t partial_start;      /* partial_frames */
+  int32_t partial_end_frame;
+  int32_t reserved;
+  int64_t text_begin, text_end;        /* byte range in text_blob */
+  int64_t partial_begin, partial_end;  /* byte range in text_blob */
+} ctcdec_beam_in;
+int ctcdec_decode_stream_batch(ctcdec_decoder* dec, const void* const* utt_logits,
+                               const int32_t* utt_frames, int32_t n_streams, int32_t dtype,
+                               int32_t is_device, const ctcdec_params* params,
+                               const int32_t* first_frame /* [n_streams] processed_frames */,
+                               const ctcdec_beam_in* beams, const int64_t* beam_off /* [n_streams+1] */,
+                               const char* text_blob, int32_t force_next_word, int32_t is_end,
+                               ctcdec_result** out);
+
 /* ---- results (OutputBeam fields, decoder.py:102-110, assembled as decoder.py:653-667) --------- */
 int32_t ctcdec_result_num_utts(const ctcdec_result* r);
 int32_t ctcdec_result_num_beams(const ctcdec_result* r, int32_t utt);
@@ -154,6 +180,14 @@ typedef struct ctcdec_packed {
   const int32_t* word_start;    /* [n_words]     */
   const int32_t* word_end;      /* [n_words]     */
   const ctcdec_lm_state* lm_state; /* [n_beams]  */
+  /* streaming extras (LMBeam fields of partial_decode_beams, decoder.py:69-99) */
+  const char* partial_blob;        /* still open partial_word of every beam */
+  const int64_t* partial_off;      /* [n_beams + 1] */
+  const int32_t* src_beam;         /* [n_beams] index of the carried-in beam this beam descends from */
+  const int32_t* last_char;        /* [n_beams] label index, -1 = None */
+  const int32_t* partial_start;    /* [n_beams] partial_frames */
+  const int32_t* partial_end;      /* [n_beams] */
+  const double* raw_lm_score;      /* [n_beams] LM score sum of the beam's text (memo value) */
 } ctcdec_packed;
 int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out);
 

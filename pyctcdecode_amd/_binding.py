@@ -55,6 +55,29 @@ class Packed(C.Structure):
         ("word_start", C.POINTER(C.c_int32)),
         ("word_end", C.POINTER(C.c_int32)),
         ("lm_state", C.POINTER(LmState)),
+        ("partial_blob", C.c_void_p),
+        ("partial_off", C.POINTER(C.c_int64)),
+        ("src_beam", C.POINTER(C.c_int32)),
+        ("last_char", C.POINTER(C.c_int32)),
+        ("partial_start", C.POINTER(C.c_int32)),
+        ("partial_end", C.POINTER(C.c_int32)),
+        ("raw_lm_score", C.POINTER(C.c_double)),
+    ]
+
+
+class BeamIn(C.Structure):
+    _fields_ = [
+        ("logit_score", C.c_double),
+        ("raw_lm_score", C.c_double),
+        ("lm_state", LmState),
+        ("last_char", C.c_int32),
+        ("partial_start", C.c_int32),
+        ("partial_end_frame", C.c_int32),
+        ("reserved", C.c_int32),
+        ("text_begin", C.c_int64),
+        ("text_end", C.c_int64),
+        ("partial_begin", C.c_int64),
+        ("partial_end", C.c_int64),
     ]
 
 
@@ -76,6 +99,9 @@ _PROTOS = {
     "ctcdec_set_hotwords": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64), C.c_int64]),
     "ctcdec_decode_batch": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(Params), C.POINTER(LmState), C.POINTER(_VP)]),
+    "ctcdec_decode_stream_batch": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                             C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(BeamIn),
+                                             C.POINTER(C.c_int64), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "ctcdec_result_num_utts": (C.c_int32, [_VP]),
     "ctcdec_result_num_beams": (C.c_int32, [_VP, C.c_int32]),
     "ctcdec_result_text": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_int64)]),

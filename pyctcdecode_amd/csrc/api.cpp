@@ -81,6 +81,19 @@ struct BeamResult {
   std::vector<int32_t> word_off, start, end;
   double logit = 0, lm = 0;
   ctcdec_lm_state state;
+  // streaming extras (decoder.py:69-79 fields of the returned LMBeam)
+  std::string partial;
+  int32_t src = -1, last_char = -1, pstart = -1, pend = -1;
+  double raw_lm = 0;
+};
+
+// what a streaming call adds to a plain batch decode
+struct StreamIn {
+  const int32_t* first_frame;
+  const ctcdec_beam_in* beams;
+  const int64_t* beam_off;
+  const char* text_blob;
+  int32_t fold, eos;
 };
 
 }  // namespace
@@ -96,14 +109,14 @@ struct ctcdec_decoder {
   DevBuf d_tok, d_tok_hot, d_uni, d_ngr, d_pref, d_hot;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
-      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof;
+      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff;
   HostBuf h_tok, h_out, h_small;
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
-                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof};
+                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff};
     for (DevBuf* b : all) b->drop();
     h_tok.drop();
     h_out.drop();
@@ -121,6 +134,10 @@ struct ctcdec_result {
   std::vector<double> logit, lm;
   std::vector<int32_t> word_byte_off, word_start, word_end;
   std::vector<ctcdec_lm_state> states;
+  std::string partial_blob;
+  std::vector<int64_t> partial_off;
+  std::vector<int32_t> src_beam, last_char, pstart, pend;
+  std::vector<double> raw_lm;
 };
 
 static int sync_tables(ctcdec_decoder* d, std::string* err) {
@@ -282,8 +299,10 @@ int ctcdec_set_hotwords(ctcdec_decoder* dec, const char* blob, const int64_t* of
 }
 
 // Rebuild text + word frames of one beam from its emission list (root -> leaf). The text is written
-// in place: `open` is where the currently open (partial) word starts.
-static void replay(const ctcdec_decoder* d, const EmitNode* toks, uint32_t n, BeamResult* r) {
+// in place: `open` is where the currently open (partial) word starts. A streaming beam starts from the
+// caller's beam named by its BR_IMPORT root (text so far + open partial word).
+static void replay(const ctcdec_decoder* d, const EmitNode* toks, uint32_t n, const StreamIn* st, int64_t imp0,
+                   BeamResult* r) {
   std::string& text = r->text;
   text.clear();
   text.reserve((size_t)n * 3 + 8);
@@ -307,15 +326,119 @@ static void replay(const ctcdec_decoder* d, const EmitNode* toks, uint32_t n, Be
       text += d->alpha.labels[tok];
     } else if (br == BR_FINAL) {
       close_word(toks[k].wstart, toks[k].wend, false);
+    } else if (br == BR_IMPORT && st) {
+      const ctcdec_beam_in& in = st->beams[imp0 + tok];
+      r->src = (int32_t)tok;
+      text.assign(st->text_blob + in.text_begin, (size_t)(in.text_end - in.text_begin));
+      if (!text.empty()) text.push_back(' ');
+      open = text.size();
+      text.append(st->text_blob + in.partial_begin, (size_t)(in.partial_end - in.partial_begin));
     }
   }
-  if (!text.empty() && text.back() == ' ' && open == text.size()) text.pop_back();  // no open word at the end
+  // split off the still open word (streaming without force_next_word / is_end)
+  r->partial.assign(text, open, std::string::npos);
+  text.resize(open);
+  if (!text.empty() && text.back() == ' ') text.pop_back();
   r->word_off.push_back((int32_t)text.size());
 }
+
+static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
+                       int32_t dtype, int32_t is_device, const ctcdec_params* p, const ctcdec_lm_state* start_states,
+                       const StreamIn* stream, ctcdec_result** out);
 
 int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames,
                         int32_t n_utts, int32_t dtype, int32_t is_device, const ctcdec_params* p,
                         const ctcdec_lm_state* start_states, ctcdec_result** out) {
+  return decode_impl(dec, utt_logits, utt_frames, n_utts, dtype, is_device, p, start_states, nullptr, out);
+}
+
+int ctcdec_decode_stream_batch(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames,
+                               int32_t n_streams, int32_t dtype, int32_t is_device, const ctcdec_params* p,
+                               const int32_t* first_frame, const ctcdec_beam_in* beams, const int64_t* beam_off,
+                               const char* text_blob, int32_t force_next_word, int32_t is_end, ctcdec_result** out) {
+  if (!first_frame || !beams || !beam_off || !text_blob) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  StreamIn st;
+  st.first_frame = first_frame;
+  st.beams = beams;
+  st.beam_off = beam_off;
+  st.text_blob = text_blob;
+  st.fold = (force_next_word || is_end) ? 1 : 0;
+  st.eos = is_end ? 1 : 0;
+  return decode_impl(dec, utt_logits, utt_frames, n_streams, dtype, is_device, p, nullptr, &st, out);
+}
+
+// host side of a streaming import: strings -> hashes, table views, history ring (the kernel rebuilds
+// the beam row and its TextNode from this)
+static int64_t shape_bw_limit(int beam_width) { return beam_bucket(beam_width); }
+
+static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, int64_t k, int beam_width, ImportBeam* m) {
+  const ctcdec_beam_in& in = st.beams[k];
+  memset(m, 0, sizeof(*m));
+  if (in.text_end < in.text_begin || in.partial_end < in.partial_begin) return "bad beam text range";
+  const char* t = st.text_blob + in.text_begin;
+  const size_t tn = (size_t)(in.text_end - in.text_begin);
+  const uint32_t n_hist = dec->has_lm ? (uint32_t)std::max(1, dec->lm_ref().order - 1) : 1u;
+  uint64_t th = 0;
+  std::vector<uint64_t> wh;
+  uint32_t hw = 0;
+  size_t a = 0;
+  while (a < tn) {
+    while (a < tn && t[a] == ' ') ++a;
+    size_t b = a;
+    while (b < tn && t[b] != ' ') ++b;
+    if (b > a) {
+      uint64_t h = hash_bytes(t + a, b - a);
+      th = text_push(th, h);
+      wh.push_back(h);
+      uint32_t ml = 0, cp = 0;
+      if (!dec->hot.table.empty() && hot_lookup(dec->hot.table.data(), dec->hot.mask, h, &ml, &cp) && cp) ++hw;
+    }
+    a = b;
+  }
+  m->text_h = th;
+  m->hw_cnt = hw;
+  m->ring_cnt = (uint32_t)std::min<size_t>(n_hist, wh.size());
+  for (uint32_t j = 0; j < m->ring_cnt; ++j) m->ring[j] = wh[wh.size() - 1 - j];
+  const char* pp = st.text_blob + in.partial_begin;
+  const size_t pn = (size_t)(in.partial_end - in.partial_begin);
+  m->part_h = hash_bytes(pp, pn);
+  m->plen = utf8_length(pp, pn);
+  if (m->plen > 0xFFFF) return "partial word too long";
+  uint32_t m2 = 0, wid = 0;
+  if (pn > 0) {
+    uint32_t fl = 0, w = 0;
+    if (dec->has_lm && prefix_lookup(dec->lm_ref().prefix_table.data(), dec->lm_ref().prefix_mask, m->part_h, &w, &fl)) {
+      m2 |= PF_ON_TABLE | (fl & 7u);
+      wid = w;
+    }
+    uint32_t ml = 0, cp = 0;
+    if (!dec->hot.table.empty() && hot_lookup(dec->hot.table.data(), dec->hot.mask, m->part_h, &ml, &cp))
+      m2 |= M2_HOT_ON | (cp ? M2_HOT_COMPLETE : 0u) | (ml << 8);
+  }
+  m->m2 = m2;
+  m->word_id = wid;
+  if (in.last_char >= (int32_t)dec->alpha.labels.size()) return "last_char out of range";
+  m->last_char = in.last_char < 0 ? NO_CHAR : (uint32_t)in.last_char;
+  m->pstart = in.partial_start;
+  m->pend = in.partial_end_frame;
+  m->logit_score = in.logit_score;
+  m->raw_lm = dec->has_lm ? in.raw_lm_score : 0.0;
+  if (dec->has_lm) {
+    if (in.lm_state.length < 0 || in.lm_state.length > MAX_CTX) return "bad LM state in beam";
+    m->state.len = in.lm_state.length;
+    for (int j = 0; j < m->state.len; ++j) {
+      if (in.lm_state.words[j] >= dec->lm_ref().words.size()) return "bad LM state word in beam";
+      m->state.words[j] = in.lm_state.words[j];
+      m->state.backoff[j] = in.lm_state.backoff[j];
+    }
+  }
+  (void)beam_width;
+  return "";
+}
+
+static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
+                       int32_t dtype, int32_t is_device, const ctcdec_params* p, const ctcdec_lm_state* start_states,
+                       const StreamIn* stream, ctcdec_result** out) {
   if (!dec || !p || !out || n_utts < 0 || (n_utts > 0 && (!utt_logits || !utt_frames)))
     return fail(CTCDEC_ERR_ARG, "bad arguments");
   if (dtype != CTCDEC_F32 && dtype != CTCDEC_F64) return fail(CTCDEC_ERR_ARG, "dtype must be f32 or f64");
@@ -411,11 +534,33 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
   std::vector<uint64_t> toff((size_t)n_utts + 1, 0), eoff((size_t)n_utts + 1, 0);
   for (int32_t u = 0; u < n_utts; ++u) {
     uint64_t T = (uint64_t)utt_frames[u];
-    toff[(size_t)u + 1] = toff[(size_t)u] + (T + 1) * (uint64_t)B + 2;
-    eoff[(size_t)u + 1] = eoff[(size_t)u] + T * (uint64_t)B + 2;
+    uint64_t n_imp = stream ? (uint64_t)(stream->beam_off[u + 1] - stream->beam_off[u]) : 0;
+    toff[(size_t)u + 1] = toff[(size_t)u] + (T + 1) * (uint64_t)B + 2 + n_imp;
+    eoff[(size_t)u + 1] = eoff[(size_t)u] + T * (uint64_t)B + 2 + n_imp;
   }
   int n_best = p->n_best > 0 ? std::min(p->n_best, B) : B;
-  unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + n_utts);
+  // emission lists: at most one entry per frame plus the import root and the closing entry
+  unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + 2 * (int64_t)n_utts);
+  // streaming: carried-over beams of every stream
+  const ImportBeam* d_imports = nullptr;
+  if (stream) {
+    const int64_t n_imp_total = stream->beam_off[n_utts];
+    std::vector<ImportBeam> imps((size_t)std::max<int64_t>(n_imp_total, 1));
+    std::vector<int64_t> ioff(stream->beam_off, stream->beam_off + n_utts + 1);
+    std::vector<int32_t> ff(stream->first_frame, stream->first_frame + n_utts);
+    for (int32_t u = 0; u < n_utts; ++u) {
+      int64_t cnt = ioff[(size_t)u + 1] - ioff[(size_t)u];
+      if (cnt < 1 || cnt > shape_bw_limit(B))
+        return fail(CTCDEC_ERR_ARG, "a stream must carry between 1 and beam-capacity beams");
+      for (int64_t k = ioff[(size_t)u]; k < ioff[(size_t)u + 1]; ++k) {
+        std::string e = build_import(dec, *stream, k, B, &imps[(size_t)k]);
+        if (!e.empty()) return fail(CTCDEC_ERR_ARG, e);
+      }
+    }
+    if (upload(dec->w_imp, imps, &err) || upload(dec->w_impoff, ioff, &err) || upload(dec->w_ff, ff, &err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    d_imports = (const ImportBeam*)dec->w_imp.p;
+  }
   if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
       dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_toff, toff, &err) ||
       upload(dec->w_eoff, eoff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
@@ -425,7 +570,9 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
     return fail(CTCDEC_ERR_DEVICE, err);
   if (be::zero(dec->w_head.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const LmState* d_start = nullptr;
-  if (start_states && dec->has_lm) {
+  if (stream) {
+    d_start = nullptr;  // every imported beam carries its own LM state
+  } else if (start_states && dec->has_lm) {
     std::vector<LmState> st((size_t)n_utts);
     for (int32_t u = 0; u < n_utts; ++u) {
       LmState& s = st[(size_t)u];
@@ -470,6 +617,8 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
   dp.log_base_change = p->log_base_change;
   dp.score_boundary = p->lm_score_boundary ? 1 : 0;
   dp.max_surv = max_surv;
+  dp.fold = stream ? stream->fold : 1;
+  dp.eos = stream ? stream->eos : 1;
   ba.n_utts = n_utts;
   ba.utt_row0 = (const int64_t*)dec->w_row0.p;
   ba.surv_cnt = (const uint32_t*)dec->w_scnt.p;
@@ -488,6 +637,9 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
   ba.tok_pool_head = (unsigned long long*)dec->w_head.p;
   ba.tok_pool_cap = tok_cap;
   ba.prof = nullptr;
+  ba.imports = d_imports;
+  ba.import_off = stream ? (const int64_t*)dec->w_impoff.p : nullptr;
+  ba.first_frames = stream ? (const int32_t*)dec->w_ff.p : nullptr;
   if (dec->profile) {
     if (dec->w_prof.ensure(N_PROF * 8, &err) || be::zero(dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     ba.prof = (unsigned long long*)dec->w_prof.p;
@@ -540,7 +692,11 @@ int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, cons
           r.state.words[j] = ob.state.words[j];
           r.state.backoff[j] = ob.state.backoff[j];
         }
-        replay(dec, toks + ob.tok_off, ob.tok_cnt, &r);
+        r.last_char = ob.last_char == NO_CHAR ? -1 : (int32_t)ob.last_char;
+        r.pstart = ob.pstart;
+        r.pend = ob.pend;
+        r.raw_lm = ob.raw_lm;
+        replay(dec, toks + ob.tok_off, ob.tok_cnt, stream, stream ? stream->beam_off[u] : 0, &r);
       }
     }
   };
@@ -616,6 +772,7 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {
     r->beam_off.assign(1, 0);
     r->text_off.assign(1, 0);
     r->word_cnt_off.assign(1, 0);
+    r->partial_off.assign(1, 0);
     for (const auto& beams : r->utts) {
       for (const BeamResult& b : beams) {
         r->text_blob += b.text;
@@ -623,6 +780,13 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {
         r->logit.push_back(b.logit);
         r->lm.push_back(b.lm);
         r->states.push_back(b.state);
+        r->partial_blob += b.partial;
+        r->partial_off.push_back((int64_t)r->partial_blob.size());
+        r->src_beam.push_back(b.src);
+        r->last_char.push_back(b.last_char);
+        r->pstart.push_back(b.pstart);
+        r->pend.push_back(b.pend);
+        r->raw_lm.push_back(b.raw_lm);
         for (size_t k = 0; k < b.start.size(); ++k) {
           r->word_byte_off.push_back(b.word_off[k]);
           r->word_start.push_back(b.start[k]);
@@ -647,6 +811,13 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {
   out->word_start = r->word_start.data();
   out->word_end = r->word_end.data();
   out->lm_state = r->states.data();
+  out->partial_blob = r->partial_blob.data();
+  out->partial_off = r->partial_off.data();
+  out->src_beam = r->src_beam.data();
+  out->last_char = r->last_char.data();
+  out->partial_start = r->pstart.data();
+  out->partial_end = r->pend.data();
+  out->raw_lm_score = r->raw_lm.data();
   return CTCDEC_OK;
 }
 

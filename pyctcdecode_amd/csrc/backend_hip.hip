@@ -506,6 +506,9 @@ __global__ __launch_bounds__(NT) void beam_decode(BeamArgs a, int surv_cap) {
   io.tok_pool_head = a.tok_pool_head;
   io.tok_pool_cap = a.tok_pool_cap;
   io.prof = (u == 0) ? a.prof : nullptr;
+  io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+  io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   GpuCtx ctx{(int)threadIdx.x, NT};
   BeamDecoder<GpuCtx> dec(ctx, view, shape, a.tables, a.params, io);
   dec.run();

@@ -210,6 +210,9 @@ struct UttIO {
   unsigned long long* tok_pool_head;
   unsigned long long tok_pool_cap;
   unsigned long long* prof;  // optional per-phase cycle accumulators (diagnostics), else nullptr
+  const ImportBeam* imports;  // streaming: the caller's live beams (rank order), else nullptr
+  int32_t n_import;
+  int32_t first_frame;        // processed_frames of this utterance (decoder.py:443)
 };
 constexpr int N_PROF = 24;
 
@@ -969,7 +972,7 @@ struct BeamDecoder {
   }
 
   CTC_HD void step(int t) {
-    int frame = prm.first_frame + t;
+    int frame = io.first_frame + t;
     if (ctx.tid == 0) {
       L.scal[0] = 0;
       L.scal[4] = 0;
@@ -1107,29 +1110,91 @@ struct BeamDecoder {
     ctx.sync_mem();
     cur = 0;
     N = 1;
+    if (io.imports && io.n_import > 0) import_beams();
   }
 
-  // _finalize_beams(force_next_word=True, is_end=True) + output records (decoder.py:558-602,653-667)
+  // streaming: rebuild the beam table from the caller's beams (their order is the rank order)
+  CTC_HD void import_beams() {
+    const BeamSoA b = beams_at(0);
+    const int n = io.n_import;
+    for (int i = ctx.tid; i < n; i += ctx.nt) {
+      const ImportBeam& m = io.imports[i];
+      TextNode& tn = io.text_nodes[1 + i];
+      tn.text_h = m.text_h;
+      tn.raw_lm = m.raw_lm;
+      const double lmhw = m.raw_lm + prm.hot_weight * (double)m.hw_cnt;
+      tn.lm_hw = lmhw;
+      uint64_t hh = 0x9E3779B97F4A7C15ull + m.ring_cnt;
+#pragma unroll
+      for (int k = MAX_CTX - 1; k >= 0; --k) {
+        tn.ring[k] = m.ring[k];
+        if ((uint32_t)k < m.ring_cnt) hh = mix64(hh ^ m.ring[k]) + 0x632BE59BD9B4E019ull;
+      }
+      tn.hist_h = hh;
+      tn.hw_cnt = m.hw_cnt;
+      tn.ring_cnt = m.ring_cnt;
+      tn.pad0 = 0;
+      tn.state.len = m.state.len;
+#pragma unroll
+      for (int k = 0; k < MAX_CTX; ++k) {
+        tn.state.words[k] = m.state.words[k];
+        tn.state.backoff[k] = m.state.backoff[k];
+      }
+      EmitNode en;
+      en.parent = 0;
+      en.tok_branch = (uint32_t)i | (BR_IMPORT << 16);
+      en.wstart = -1;
+      en.wend = -1;
+      io.emit_nodes[1 + i] = en;
+      b.logit[i] = m.logit_score;
+      b.lm_hw[i] = lmhw;
+      b.pscore[i] = m.plen > 0 ? partial_score(tab, prm, m.m2 & 7u, (m.m2 & M2_HOT_ON) ? (m.m2 >> 8) : 0u, m.plen) : 0.0;
+      b.c_lm_hw[i] = 0.0;
+      b.text_h[i] = m.text_h;
+      b.part_h[i] = m.part_h;
+      b.hist_h[i] = hh;
+      b.c_text_h[i] = 0;
+      b.c_hist_h[i] = 0;
+      b.text_node[i] = 1 + i;
+      b.comp_node[i] = 0;
+      b.emit_node[i] = 1 + i;
+      b.word_id[i] = m.word_id;
+      b.meta1[i] = (m.last_char & 0xFFFFu) | (m.plen << 16);
+      b.meta2[i] = m.plen > 0 ? m.m2 : EMPTY_PARTIAL_M2;
+      b.depth[i] = 1;
+      b.pstart[i] = m.pstart;
+      b.pend[i] = m.pend;
+    }
+    if (ctx.tid == 0) {
+      L.scal[1] = 1 + (uint32_t)n;
+      L.scal[2] = 1 + (uint32_t)n;
+    }
+    ctx.sync_mem();
+    N = n;
+  }
+
+  // _finalize_beams(force_next_word, is_end) + output records (decoder.py:558-602,653-667).
+  // prm.fold: close the open word of every beam and merge equal texts; prm.eos: score end of sentence.
   CTC_HD void finalise() {
     const BeamSoA b = beams_at(cur);
+    const bool fold = prm.fold != 0, eos = prm.eos != 0;
     if (ctx.tid == 0) {
       L.scal[0] = 0;
       L.smax[0] = asc_key(-INFINITY);
     }
     ctx.sync_mem();
-    for (int i = ctx.tid; i < N; i += ctx.nt)
-      if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
+    if (fold) {
+      for (int i = ctx.tid; i < N; i += ctx.nt)
+        if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
+    }
     ctx.sync_mem();
-    ctx.sync();
-    // candidates: one per beam, key (text (+) partial, "", None)
-    for (int base = 0; base < N; base += shape.cand) {
-      int Q = N - base < shape.cand ? N - base : shape.cand;
-      // (N <= beam capacity <= cand is enforced by the host, so this loop runs once)
+    const int Q = N;  // N <= beam capacity <= candidate chunk
+    if (fold) {
+      // candidates: one per beam, key (text (+) partial, "", None)
       for (int q = ctx.tid; q < Q; q += ctx.nt) {
-        int i = base + q;
-        L.ck_text[q] = plen(b, i) > 0 ? b.c_text_h[i] : b.text_h[i];
+        L.ck_text[q] = plen(b, q) > 0 ? b.c_text_h[q] : b.text_h[q];
         L.ck_part[q] = 0;
-        L.c_logit[q] = b.logit[i];
+        L.c_logit[q] = b.logit[q];
         L.rmin[q] = 0xFFFFFFFFu;
         L.rmax[q] = 0;
         L.rcnt[q] = 0;
@@ -1143,41 +1208,53 @@ struct BeamDecoder {
         L.keep[q] = r;  // keep[] doubles as the representative map here (capacity bw >= N)
       }
       ctx.sync();
-      for (int q = ctx.tid; q < Q; q += ctx.nt) {
+    }
+    for (int q = ctx.tid; q < Q; q += ctx.nt) {
+      double lg, score;
+      uint32_t donor = (uint32_t)q;
+      if (fold) {
         uint32_t r = L.keep[q];
         if (L.rmin[r] != (uint32_t)q) continue;
         uint32_t qmax = L.rmax[r];
-        double lg = L.c_logit[q];
+        lg = L.c_logit[q];
         for (uint32_t q2 = (uint32_t)q + 1; q2 <= qmax; ++q2)
           if (L.keep[q2] == r) lg = lse2(lg, L.c_logit[q2]);
-        // EOS score through the donor's (text, next_word) split (decoder.py:387-395 with is_eos)
-        int d = base + (int)qmax;
-        const TextNode& src = io.text_nodes[b.text_node[d]];
-        uint32_t m2 = b.meta2[d];
-        uint32_t pl = plen(b, d);
-        uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
+        // scored through the donor's (text, next_word) split (decoder.py:387-395)
+        const int d = (int)qmax;
+        donor = qmax;
+        const uint32_t m2 = b.meta2[d];
+        const uint32_t pl = plen(b, d);
         double lmhw;
-        if (tab.has_lm) {
-          LmState end;
-          uint32_t wid = pl > 0 ? b.word_id[d] : 0u;
-          uint32_t wfl = pl > 0 ? m2 : 0u;
-          float base_s = lm_base_score(tab, src.state, wid, &end);
-          double end_score = 0.0;
-          if (prm.score_boundary) {
-            LmState tmp;
-            end_score = (double)lm_base_score(tab, end, tab.eos_id, &tmp);
+        if (eos) {
+          const TextNode& src = io.text_nodes[b.text_node[d]];
+          uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
+          if (tab.has_lm) {
+            LmState end;
+            uint32_t wid = pl > 0 ? b.word_id[d] : 0u;
+            uint32_t wfl = pl > 0 ? m2 : 0u;
+            float base_s = lm_base_score(tab, src.state, wid, &end);
+            double end_score = 0.0;
+            if (prm.score_boundary) {
+              LmState tmp;
+              end_score = (double)lm_base_score(tab, end, tab.eos_id, &tmp);
+            }
+            double raw = src.raw_lm + lm_word_score(tab, prm, base_s, wfl, end_score, true);
+            lmhw = raw + prm.hot_weight * (double)cnt;
+          } else {
+            lmhw = prm.hot_weight * (double)cnt;
           }
-          double raw = src.raw_lm + lm_word_score(tab, prm, base_s, wfl, end_score, true);
-          lmhw = raw + prm.hot_weight * (double)cnt;
         } else {
-          lmhw = prm.hot_weight * (double)cnt;
+          lmhw = pl > 0 ? b.c_lm_hw[d] : b.lm_hw[d];  // memo entry (text (+) word, False)
         }
-        double score = tab.has_lm ? lg + lmhw : lg + lmhw + 0.0;
-        ctx.atomic_max64(&L.smax[0], asc_key(score));
-        pool_push(score, lg, (uint32_t)q, (uint32_t)qmax);
+        score = tab.has_lm ? lg + lmhw : lg + lmhw + 0.0;
+      } else {
+        lg = b.logit[q];
+        score = total_score(tab, lg, b.lm_hw[q], b.pscore[q], plen(b, q));
       }
-      ctx.sync();
+      ctx.atomic_max64(&L.smax[0], asc_key(score));
+      pool_push(score, lg, (uint32_t)q, donor);
     }
+    ctx.sync();
     finish_frame(0, true);
     uint32_t n = L.scal[9];
     uint32_t n_out = n;
@@ -1188,7 +1265,7 @@ struct BeamDecoder {
     for (uint32_t r = ctx.tid; r < n_out; r += ctx.nt) {
       uint32_t idx = L.sel[r];
       int d = (int)L.p_don[idx];
-      uint32_t len = b.depth[d] + (plen(b, d) > 0 ? 1u : 0u);
+      uint32_t len = b.depth[d] + ((fold && plen(b, d) > 0) ? 1u : 0u);
       L.keep[r] = ctx.atomic_add(&L.scal[8], len);  // offset inside this utterance's block
     }
     ctx.sync();
@@ -1205,28 +1282,46 @@ struct BeamDecoder {
     for (uint32_t r = ctx.tid; r < n_out; r += ctx.nt) {
       uint32_t idx = L.sel[r];
       int d = (int)L.p_don[idx];
-      OutBeam ob;
+      OutBeam& ob = io.out[r];
       ob.logit_score = L.p_logit[idx];
       ob.lm_score = L.p_score[idx];
-      uint32_t pl = plen(b, d);
-      uint32_t len = b.depth[d] + (pl > 0 ? 1u : 0u);
+      const uint32_t pl = plen(b, d);
+      const bool closes = fold && pl > 0;
+      uint32_t len = b.depth[d] + (closes ? 1u : 0u);
       uint32_t off = (uint32_t)(L.smax[1] + L.keep[r]);
       ob.tok_off = off;
       ob.tok_cnt = tok_ok ? len : 0;
-      ob.pad = 0;
-      // last_lm_state: state after the last word, before </s> (language_model.py:357)
-      const TextNode& src = io.text_nodes[b.text_node[d]];
-      if (tab.has_lm) {
-        uint32_t wid = pl > 0 ? b.word_id[d] : 0u;
-        lm_base_score(tab, src.state, wid, &ob.state);
-      } else {
-        ob.state = src.state;
+      ob.pad[0] = 0;
+      ob.pad[1] = 0;
+      ob.last_char = fold ? NO_CHAR : last_char(b, d);
+      ob.pstart = fold ? -1 : b.pstart[d];
+      ob.pend = fold ? -1 : b.pend[d];
+      // the text's memo entry: raw LM sum and the state after its last word
+      const TextNode& node = io.text_nodes[closes ? b.comp_node[d] : b.text_node[d]];
+      ob.raw_lm = node.raw_lm;
+      if (!tab.has_lm) {
         ob.state.len = -1;
+#pragma unroll
+        for (int k = 0; k < MAX_CTX; ++k) {
+          ob.state.words[k] = 0;
+          ob.state.backoff[k] = 0.f;
+        }
+      } else if (eos) {
+        // last_lm_state: state after the last word, before </s> (language_model.py:357); an empty
+        // last word is still scored as a word (decoder.py:387-395)
+        const TextNode& src = io.text_nodes[b.text_node[d]];
+        lm_base_score(tab, src.state, pl > 0 ? b.word_id[d] : 0u, &ob.state);
+      } else {
+        ob.state.len = node.state.len;
+#pragma unroll
+        for (int k = 0; k < MAX_CTX; ++k) {
+          ob.state.words[k] = node.state.words[k];
+          ob.state.backoff[k] = node.state.backoff[k];
+        }
       }
-      io.out[r] = ob;
       if (tok_ok) {
         uint32_t pos = off + len;
-        if (pl > 0) {
+        if (closes) {
           EmitNode fin;
           fin.parent = 0;
           fin.tok_branch = BR_FINAL << 16;

@@ -152,7 +152,7 @@ struct TextNode {  // 128 B
 };
 
 // one non-blank, non-repeat emission on a beam's path; host replays the chain into words+frames
-enum : uint32_t { BR_BOUNDARY = 1u, BR_SPACE = 2u, BR_APPEND = 3u, BR_FINAL = 4u };
+enum : uint32_t { BR_BOUNDARY = 1u, BR_SPACE = 2u, BR_APPEND = 3u, BR_FINAL = 4u, BR_IMPORT = 5u };
 struct EmitNode {  // 16 B
   uint32_t parent;
   uint32_t tok_branch;  // token | branch << 16
@@ -160,12 +160,28 @@ struct EmitNode {  // 16 B
 };
 
 // per-beam result record written by the beam kernel
-struct OutBeam {  // 80 B
+struct OutBeam {  // 104 B
   double logit_score;
   double lm_score;
+  double raw_lm;      // LM score sum of the beam's text (memo value a streaming caller carries on)
   uint32_t tok_off;   // offset of this beam's emission list in the token pool
   uint32_t tok_cnt;
   LmState state;      // last_lm_state
+  uint32_t last_char; // label of the last frame (NO_CHAR=0xFFFF: None)
+  int32_t pstart, pend;  // partial_frames of the still open word
+  uint32_t pad[2];
+};
+
+// a live beam handed back in by a streaming caller (partial_decode_beams, decoder.py:681-728):
+// the host resolves strings to hashes / table views, the kernel rebuilds its LDS row from this
+struct ImportBeam {  // 160 B
+  double logit_score;
+  double raw_lm;
+  uint64_t text_h, part_h;
+  uint64_t ring[MAX_CTX];
+  uint32_t ring_cnt, hw_cnt, plen, last_char, m2, word_id;
+  int32_t pstart, pend;
+  LmState state;
   uint32_t pad;
 };
 
@@ -200,6 +216,8 @@ struct DecodeParams {
   double alpha, beta, unk, log_base_change;
   int32_t score_boundary;
   int32_t max_surv;  // stride of the survivor arrays
+  int32_t fold;      // finalisation closes the open word (force_next_word or is_end, decoder.py:570)
+  int32_t eos;       // finalisation scores end of sentence (is_end, decoder.py:597)
 };
 
 // ---------------------------------------------------------------------------------------------

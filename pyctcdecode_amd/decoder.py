@@ -166,6 +166,7 @@ class BeamSearchDecoderCTC:
     def __init__(self, alphabet: Alphabet, language_model: Optional[AbstractLanguageModel] = None) -> None:
         self._alphabet = alphabet
         self._idx2vocab = {n: c for n, c in enumerate(self._alphabet.labels)}
+        self._vocab2idx = {c: n for n, c in enumerate(self._alphabet.labels)}
         self._is_bpe = alphabet.is_bpe
         self._model_key = os.urandom(16)
         BeamSearchDecoderCTC.model_container[self._model_key] = language_model
@@ -420,12 +421,188 @@ class BeamSearchDecoderCTC:
         finally:
             self._lib.dll.ctcdec_result_free(res)
 
-    # -- streaming (decoder.py:669-728): SURVEY 8(f) rank 3, not built yet -----------------------
+    # -- streaming (decoder.py:669-728) ----------------------------------------------------------
     def get_starting_state(self):
-        raise NotImplementedError("partial_decode_beams streaming state is not implemented on the device path yet")
+        """decoder.py:669-679: (beams, cached_lm_scores, cached_p_lm_scores) to start a stream with."""
+        start_beam = [EMPTY_START_BEAM]
+        language_model = self._language_model
+        if language_model is None:
+            cached_lm_scores: Dict[Any, Any] = {}
+        else:
+            cached_lm_scores = {("", False): (0.0, 0.0, language_model.get_start_state())}
+        cached_p_lm_scores: Dict[str, float] = {}
+        return start_beam, cached_lm_scores, cached_p_lm_scores
 
-    def partial_decode_beams(self, *args, **kwargs):
-        raise NotImplementedError("partial_decode_beams streaming state is not implemented on the device path yet")
+    def _memo_entry(self, cached_lm_scores, text: str):
+        """(raw LM score, KenlmState) of a completed-words text; the device returns these for every beam it
+        hands out, so a miss only happens for beams the caller built by hand (scored word by word here)."""
+        hit = cached_lm_scores.get((text, False))
+        if hit is not None:
+            return hit[1], hit[2]
+        lm = self._language_model
+        if ("", False) not in cached_lm_scores:
+            cached_lm_scores[("", False)] = (0.0, 0.0, lm.get_start_state())
+        _, raw, state = cached_lm_scores[("", False)]
+        so_far = ""
+        for word in text.split():
+            so_far = word if not so_far else so_far + " " + word
+            nxt = cached_lm_scores.get((so_far, False))
+            if nxt is None:
+                score, st = lm.score(state, word)
+                nxt = (raw + score, raw + score, st)
+                cached_lm_scores[(so_far, False)] = nxt
+            _, raw, state = nxt
+        return raw, state
+
+    def partial_decode_beams_batch(
+        self,
+        logits_list: Sequence[Any],
+        cached_lm_scores_list: Sequence[Dict[Any, Any]],
+        cached_p_lm_scores_list: Sequence[Dict[str, float]],
+        beams_list: Sequence[List[Beam]],
+        processed_frames_list: Sequence[int],
+        beam_width: int = DEFAULT_BEAM_WIDTH,
+        beam_prune_logp: float = DEFAULT_PRUNE_LOGP,
+        token_min_logp: float = DEFAULT_MIN_TOKEN_LOGP,
+        prune_history: bool = DEFAULT_PRUNE_BEAMS,
+        hotword_scorer: Optional[HotwordScorer] = None,
+        force_next_word: bool = False,
+        is_end: bool = False,
+    ) -> List[List[LMBeam]]:
+        """Many independent streams advanced by one chunk each in ONE device launch (extension of
+        partial_decode_beams, decoder.py:681-728; one workgroup per stream)."""
+        n = len(logits_list)
+        for logits in logits_list:
+            self._check_logits_dimension(logits)
+        if hotword_scorer is not None and not isinstance(hotword_scorer, HotwordScorer):
+            raise TypeError("hotword_scorer must be a pyctcdecode_amd HotwordScorer")
+        weight = hotword_scorer.weight if hotword_scorer is not None else 0.0
+        unigrams = hotword_scorer.unigrams if hotword_scorer is not None else []
+        key = tuple(unigrams)
+        if key != self._hot_key:
+            blob, off = B.pack_strings(unigrams)
+            self._lib.check(self._lib.dll.ctcdec_set_hotwords(self._handle, blob, B.off_ptr(off), len(unigrams)))
+            self._hot_key = key
+        has_lm = self._language_model is not None
+        vocab2idx = self._vocab2idx
+        pieces: List[bytes] = []
+        pos = 0
+        total = sum(len(b) for b in beams_list)
+        arr = (B.BeamIn * max(total, 1))()
+        beam_off = np.zeros(n + 1, dtype=np.int64)
+        texts: List[List[str]] = []
+        k = 0
+        for u in range(n):
+            beams = beams_list[u]
+            if len(beams) == 0:
+                raise ValueError("a stream needs at least one beam (use get_starting_state())")
+            utt_texts = []
+            for beam in beams:
+                text = beam.text if not beam.next_word else (beam.text + " " + beam.next_word if beam.text else beam.next_word)
+                text = " ".join(text.split())
+                utt_texts.append(text)
+                e = arr[k]
+                e.logit_score = float(beam.logit_score)
+                if has_lm:
+                    raw, state = self._memo_entry(cached_lm_scores_list[u], text)
+                    if not isinstance(state, KenlmState):
+                        raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(state)}")
+                    e.raw_lm_score = float(raw)
+                    e.lm_state = state.state.to_c()
+                if beam.last_char is None:
+                    e.last_char = -1
+                else:
+                    if beam.last_char not in vocab2idx:
+                        raise ValueError("beam.last_char %r is not a label of this decoder" % (beam.last_char,))
+                    e.last_char = vocab2idx[beam.last_char]
+                e.partial_start = int(beam.partial_frames[0])
+                e.partial_end_frame = int(beam.partial_frames[1])
+                tb = text.encode("utf-8")
+                pb = beam.partial_word.encode("utf-8")
+                e.text_begin, e.text_end = pos, pos + len(tb)
+                pos += len(tb)
+                e.partial_begin, e.partial_end = pos, pos + len(pb)
+                pos += len(pb)
+                pieces.append(tb)
+                pieces.append(pb)
+                k += 1
+            texts.append(utt_texts)
+            beam_off[u + 1] = k
+        blob = b"".join(pieces) or b"\0"
+        params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, weight, 0)
+        batch = _Batch(logits_list, len(self._idx2vocab))
+        ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
+        frames = (C.c_int32 * max(n, 1))(*batch.frames)
+        first = (C.c_int32 * max(n, 1))(*[int(p) for p in processed_frames_list])
+        res = C.c_void_p()
+        self._lib.check(
+            self._lib.dll.ctcdec_decode_stream_batch(
+                self._handle, ptrs, frames, n, batch.dtype, int(batch.is_device), C.byref(params), first, arr,
+                B.off_ptr(beam_off), blob, int(bool(force_next_word)), int(bool(is_end)), C.byref(res))
+        )
+        try:
+            pk = B.Packed()
+            self._lib.check(self._lib.dll.ctcdec_result_pack(res, C.byref(pk)))
+            nb, nw = int(pk.n_beams), int(pk.n_words)
+            out: List[List[LMBeam]] = []
+            if nb == 0:
+                return [[] for _ in range(n)]
+            b_off = np.ctypeslib.as_array(pk.beam_off, shape=(n + 1,))
+            t_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
+            tblob = C.string_at(pk.text_blob, int(t_off[nb])) if t_off[nb] else b""
+            p_off = np.ctypeslib.as_array(pk.partial_off, shape=(nb + 1,))
+            pblob = C.string_at(pk.partial_blob, int(p_off[nb])) if p_off[nb] else b""
+            logit = np.ctypeslib.as_array(pk.logit_score, shape=(nb,))
+            lms = np.ctypeslib.as_array(pk.lm_score, shape=(nb,))
+            raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,))
+            src = np.ctypeslib.as_array(pk.src_beam, shape=(nb,))
+            lch = np.ctypeslib.as_array(pk.last_char, shape=(nb,))
+            ps = np.ctypeslib.as_array(pk.partial_start, shape=(nb,))
+            pe = np.ctypeslib.as_array(pk.partial_end, shape=(nb,))
+            wco = np.ctypeslib.as_array(pk.word_cnt_off, shape=(nb + 1,))
+            if nw:
+                wstart = np.ctypeslib.as_array(pk.word_start, shape=(nw,))
+                wend = np.ctypeslib.as_array(pk.word_end, shape=(nw,))
+            for u in range(n):
+                outs = []
+                memo = cached_lm_scores_list[u]
+                for j in range(int(b_off[u]), int(b_off[u + 1])):
+                    text = tblob[int(t_off[j]) : int(t_off[j + 1])].decode("utf-8")
+                    partial = pblob[int(p_off[j]) : int(p_off[j + 1])].decode("utf-8")
+                    parent = beams_list[u][int(src[j])]
+                    new_frames = [(int(wstart[w]), int(wend[w])) for w in range(int(wco[j]), int(wco[j + 1]))]
+                    last = None if lch[j] < 0 else self._idx2vocab[int(lch[j])]
+                    outs.append(
+                        LMBeam(text, "", partial, last, list(parent.text_frames) + new_frames,
+                               (int(ps[j]), int(pe[j])), float(logit[j]), float(lms[j]))
+                    )
+                    if has_lm and (text, False) not in memo:
+                        memo[(text, False)] = (float(raw[j]), float(raw[j]), KenlmState(NgramState.from_c(pk.lm_state[j])))
+                out.append(outs)
+            return out
+        finally:
+            self._lib.dll.ctcdec_result_free(res)
+
+    def partial_decode_beams(
+        self,
+        logits: Any,
+        cached_lm_scores: Dict[Any, Any],
+        cached_p_lm_scores: Dict[str, float],
+        beams: List[Beam],
+        processed_frames: int,
+        beam_width: int = DEFAULT_BEAM_WIDTH,
+        beam_prune_logp: float = DEFAULT_PRUNE_LOGP,
+        token_min_logp: float = DEFAULT_MIN_TOKEN_LOGP,
+        prune_history: bool = DEFAULT_PRUNE_BEAMS,
+        hotword_scorer: Optional[HotwordScorer] = None,
+        force_next_word: bool = False,
+        is_end: bool = False,
+    ) -> List[LMBeam]:
+        """decoder.py:681-728: advance one stream by one chunk; feed the returned beams back in."""
+        return self.partial_decode_beams_batch(
+            [logits], [cached_lm_scores], [cached_p_lm_scores], [beams], [processed_frames], beam_width,
+            beam_prune_logp, token_min_logp, prune_history, hotword_scorer, force_next_word, is_end,
+        )[0]
 
 
 def build_ctcdecoder(

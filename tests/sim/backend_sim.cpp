@@ -144,6 +144,9 @@ int launch_beam(const BeamArgs& a, std::string*) {
     io.tok_pool_head = a.tok_pool_head;
     io.tok_pool_cap = a.tok_pool_cap;
     io.prof = nullptr;
+    io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
+    io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+    io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
     SeqCtx ctx;
     BeamDecoder<SeqCtx> dec(ctx, view, shape, a.tables, a.params, io);
     dec.run();

@@ -214,3 +214,67 @@ def test_hip_config3_hf_vocab_lm_full_length():
     beams = dec.decode_beams(xs[1])
     exp = _oracle_expected(orc, xs[1].astype(np.float64), {})
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in beams], exp, tol=TOL, what="cfg3")
+
+
+def test_hip_streaming_matches_reference_scenarios():
+    """partial_decode_beams on the device: chunked == unchunked == decode_beams on the reference's
+    fixture (tests/test_decoder.py:515-584), with and without LM."""
+    from pyctcdecode_amd import build_ctcdecoder
+    from tests.golden_util import TOY_ARPA
+
+    by_name = {c["name"]: c for c in CASES}
+    labels = by_name["toy_nolm_16beams"]["labels"]
+    x = INPUTS[by_name["toy_nolm_16beams"]["input"]]
+    for lm_path_ in (None, TOY_ARPA):
+        dec = build_ctcdecoder(labels, lm_path_)
+        beams, c1, c2 = dec.get_starting_state()
+        whole = dec.partial_decode_beams(x, c1, c2, beams, 0, is_end=True)
+        beams, c1, c2 = dec.get_starting_state()
+        beams = dec.partial_decode_beams(x[:3], c1, c2, beams, 0)
+        beams = dec.partial_decode_beams(x[3:8], c1, c2, beams, 3)
+        parts = dec.partial_decode_beams(x[8:], c1, c2, beams, 8, is_end=True)
+        full = dec.decode_beams(x)
+        assert len(whole) == len(parts) == len(full)
+        assert parts[0].text == ("bunny bunny" if lm_path_ is None else "bugs bunny")
+        assert sorted((p.text, tuple(p.text_frames)) for p in parts) == sorted(
+            (f.text, tuple(t[1] for t in f.text_frames)) for f in full)
+        assert abs(parts[0].logit_score - full[0].logit_score) < 1e-9
+
+
+def test_hip_config5_streaming_64_streams(lm, bpe):
+    """BASELINE config 5: V=1024, 4-gram LM, beam=200, 64 concurrent streams x 50-frame chunks, one
+    launch per chunk. Streams 0-1 are checked against the oracle's chunked decode; every stream must
+    equal the unchunked device decode."""
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    dec = build_ctcdecoder(bpe, lm.path)
+    n_streams, n_chunks, chunk = 64, 4, 50
+    xs = [synth.d_words(5, u, n_chunks * chunk, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0)
+          for u in range(n_streams)]
+    states = [dec.get_starting_state() for _ in range(n_streams)]
+    beams = [s[0] for s in states]
+    for k in range(n_chunks):
+        dev = [torch.from_numpy(x[k * chunk:(k + 1) * chunk]).cuda() for x in xs]
+        beams = dec.partial_decode_beams_batch(dev, [s[1] for s in states], [s[2] for s in states], beams,
+                                               [k * chunk] * n_streams, beam_width=200,
+                                               is_end=(k == n_chunks - 1))
+    whole = dec.decode_beams_batch(None, xs, beam_width=200)
+    for u in range(n_streams):
+        assert [b.text for b in beams[u]] == [w.text for w in whole[u]]
+        assert [b.text_frames for b in beams[u]] == [[f[1] for f in w.text_frames] for w in whole[u]]
+        assert all(abs(b.lm_score - w.lm_score) < 1e-9 for b, w in zip(beams[u], whole[u]))
+    alpha = Alphabet.build_alphabet(bpe)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    for u in range(2):
+        st = orc.get_starting_state()
+        exp = None
+        for k in range(n_chunks):
+            exp = orc.partial_decode_beams(xs[u][k * chunk:(k + 1) * chunk].astype(np.float64), st, k * chunk,
+                                           beam_width=200, is_end=(k == n_chunks - 1))
+        assert [b.text for b in beams[u]] == [e.text for e in exp]
+        assert [[tuple(f) for f in b.text_frames] for b in beams[u]] == [[tuple(f) for f in e.tframes] for e in exp]
+        assert all(abs(b.lm_score - e.lm) < TOL * max(1.0, abs(e.lm)) for b, e in zip(beams[u], exp))

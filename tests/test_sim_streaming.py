@@ -1,0 +1,151 @@
+"""CPU: partial_decode_beams / get_starting_state (decoder.py:669-728) through the shell +
+beam_core.h (sequential sim backend) -- the reference's own streaming scenarios
+(tests/test_decoder.py:515-698) and chunked-vs-oracle differentials."""
+import numpy as np
+import pytest
+
+import synth
+from oracle.ctc_oracle import build_oracle
+from pyctcdecode_amd.alphabet import Alphabet
+from pyctcdecode_amd.language_model import HotwordScorer
+from tests.golden_util import LM_DIR, TOY_ARPA, load_cases
+from tests.sim_util import sim_library  # noqa: F401
+
+CASES, INPUTS = load_cases()
+BY_NAME = {c["name"]: c for c in CASES}
+SAMPLE_LABELS = BY_NAME["toy_nolm_16beams"]["labels"]
+TEST_LOGITS = INPUTS[BY_NAME["toy_nolm_16beams"]["input"]]
+
+
+def _chunked(dec, chunks, is_end_last=True, **kw):
+    beams, c1, c2 = dec.get_starting_state()
+    done = 0
+    for k, x in enumerate(chunks):
+        beams = dec.partial_decode_beams(x, c1, c2, beams, done, is_end=(is_end_last and k == len(chunks) - 1), **kw)
+        done += x.shape[0]
+    return beams
+
+
+def _check_same(final, partial, frames_with_words):
+    assert len(final) == len(partial)
+    for f, p in zip(final, partial):
+        assert f.text == p.text
+        ff = [t[1] for t in f.text_frames] if frames_with_words else f.text_frames
+        assert ff == p.text_frames
+        assert abs(f.logit_score - p.logit_score) < 1e-9
+        assert abs(f.lm_score - p.lm_score) < 1e-9
+
+
+@pytest.mark.parametrize("lm", [None, TOY_ARPA])
+def test_partial_decode_equals_whole(lm, sim_library):  # noqa: F811
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(SAMPLE_LABELS, lm)
+    whole = _chunked(dec, [TEST_LOGITS])
+    parts = _chunked(dec, [TEST_LOGITS[:3], TEST_LOGITS[3:8], TEST_LOGITS[8:]])
+    _check_same(whole, parts, False)
+    if lm is None:
+        assert parts[0].text == "bunny bunny" and parts[0].text_frames == [(0, 6), (7, 13)]
+        assert abs(parts[0].logit_score - (-2.6933782130551505)) < 1e-9
+    else:
+        assert parts[0].text == "bugs bunny"
+    _check_same(dec.decode_beams(TEST_LOGITS), parts, True)
+
+
+def test_partial_decode_with_hotwords(sim_library):  # noqa: F811
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(SAMPLE_LABELS)
+    hw = HotwordScorer.build_scorer(["bugs"], weight=25.0)
+    parts = _chunked(dec, [TEST_LOGITS[:3], TEST_LOGITS[3:8], TEST_LOGITS[8:]], hotword_scorer=hw)
+    assert parts[0].text == "bugs bunny"
+    _check_same(dec.decode_beams(TEST_LOGITS, hotwords=["bugs"], hotword_weight=25.0), parts, True)
+
+
+def test_partial_decode_with_multiple_hotword_scorers(sim_library):  # noqa: F811
+    """tests/test_decoder.py:631-698 of the reference."""
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(SAMPLE_LABELS)
+    hw1 = HotwordScorer.build_scorer(["bugs"], weight=15.0)
+    hw2 = HotwordScorer.build_scorer(["bunny"], weight=15.0)
+    l1, l2, l3 = TEST_LOGITS[:3], TEST_LOGITS[3:8], TEST_LOGITS[8:]
+    beams, c1, c2 = dec.get_starting_state()
+    beams = dec.partial_decode_beams(l1, c1, c2, beams, 0, hotword_scorer=hw1)
+    beams = dec.partial_decode_beams(l2, c1, c2, beams, 3, hotword_scorer=hw2)
+    out = dec.partial_decode_beams(l3, c1, c2, beams, 8, hotword_scorer=None, is_end=True)
+    assert out[0].text == "bugny bunny"
+    beams, c1, c2 = dec.get_starting_state()
+    beams = dec.partial_decode_beams(l1, c1, c2, beams, 0, hotword_scorer=hw1)
+    beams = dec.partial_decode_beams(l2, c1, c2, beams, 3, hotword_scorer=hw1)
+    out = dec.partial_decode_beams(l3, c1, c2, beams, 8, hotword_scorer=hw2, is_end=True)
+    assert out[0].text == "bugs bunny"
+
+
+def _oracle_chunked(orc, chunks, kw, hot, weight, force_last=False):
+    st = orc.get_starting_state()
+    done = 0
+    outs = None
+    for k, x in enumerate(chunks):
+        last = k == len(chunks) - 1
+        outs = orc.partial_decode_beams(x, st, done, hotwords=hot, hotword_weight=weight,
+                                        force_next_word=(force_last and last), is_end=(not force_last and last), **kw)
+        done += x.shape[0]
+    return outs
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_streaming_vs_oracle_random(seed, sim_library):  # noqa: F811
+    from pyctcdecode_amd import build_ctcdecoder
+
+    rng = np.random.default_rng(100 + seed)
+    lm = synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2)
+    words = synth.make_words(300, seed=2)
+    use_bpe = seed % 2 == 1
+    labels = synth.make_bpe_vocab(words, size=127) if use_bpe else synth.LIBRI_LABELS
+    arpa = lm.path if seed % 4 < 2 else None
+    dec = build_ctcdecoder(labels, arpa)
+    alpha = Alphabet.build_alphabet(labels)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, arpa, None)
+    blank = len(labels)
+    x = synth.d_words(5, seed, 48, labels, use_bpe, lm.words, lm.sentences, blank, boost=5.0).astype(np.float64)
+    cuts = sorted(rng.choice(np.arange(1, 48), size=3, replace=False).tolist())
+    chunks = [x[a:b] for a, b in zip([0] + cuts, cuts + [48])]
+    hot = lm.hotwords(3, 1) if seed % 3 == 0 else None
+    kw = dict(beam_width=int(rng.choice([8, 30, 100])), prune_history=bool(seed % 2))
+    force_last = seed % 5 == 4
+    hw = HotwordScorer.build_scorer(hot, weight=10.0) if hot else None
+    beams, c1, c2 = dec.get_starting_state()
+    done = 0
+    for k, ch in enumerate(chunks):
+        last = k == len(chunks) - 1
+        beams = dec.partial_decode_beams(ch, c1, c2, beams, done, hotword_scorer=hw,
+                                         force_next_word=(force_last and last), is_end=(not force_last and last), **kw)
+        done += ch.shape[0]
+    exp = _oracle_chunked(orc, chunks, kw, hot, 10.0 if hot else 0.0, force_last)
+    assert len(beams) == len(exp)
+    for g, e in zip(beams, exp):
+        assert (g.text, g.partial_word, g.last_char) == (e.text, e.partial, e.last)
+        assert [tuple(f) for f in g.text_frames] == [tuple(f) for f in e.tframes]
+        assert tuple(g.partial_frames) == tuple(e.pframes)
+        assert abs(g.logit_score - e.logit) < 1e-9 * max(1, abs(e.logit))
+        assert abs(g.lm_score - e.lm) < 1e-9 * max(1, abs(e.lm))
+
+
+def test_streaming_intermediate_beams_and_batch(sim_library):  # noqa: F811
+    """Intermediate (not finalised) beams expose the open partial word; two streams in one call."""
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(SAMPLE_LABELS, TOY_ARPA)
+    alpha = Alphabet.build_alphabet(SAMPLE_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, TOY_ARPA, None)
+    s1 = dec.get_starting_state()
+    s2 = dec.get_starting_state()
+    outs = dec.partial_decode_beams_batch([TEST_LOGITS[:3], TEST_LOGITS[:5]], [s1[1], s2[1]], [s1[2], s2[2]],
+                                          [s1[0], s2[0]], [0, 0])
+    for got, T in zip(outs, (3, 5)):
+        st = orc.get_starting_state()
+        exp = orc.partial_decode_beams(TEST_LOGITS[:T], st, 0)
+        assert [(g.text, g.partial_word, g.last_char, tuple(g.partial_frames)) for g in got] == [
+            (e.text, e.partial, e.last, tuple(e.pframes)) for e in exp]
+    assert outs[0][0].partial_word == "bug" or outs[0][0].partial_word == "bun"
