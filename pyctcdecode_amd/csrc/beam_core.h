@@ -102,9 +102,10 @@ struct LdsView {
   LPtr<uint64_t> s_k0, s_k1;
   // scalars
   LPtr<uint32_t> scal;  // [0] pool_n [1] text_next [2] emit_next [3] flag [4] need_comp [5] n_sel [6] status [7] n_new [8] tok_len
-  LPtr<uint64_t> smax;  // [0] sortable max score [1] token pool base
+  LPtr<uint64_t> smax;  // [0] sortable max score [1] token pool base [2] sortable score of the beam_width-th best so far
   LPtr<uint32_t> keep;  // per selected beam: kept by history prune
   LPtr<uint32_t> sel;   // pool indices of the selected candidates in (score desc, arrival asc) order
+  LPtr<uint32_t> part;  // 64 partial sums of the bucket histogram (large-set selection)
   LPtr<uint64_t> hk_h, hk_p;  // history-prune keys of the selected beams
   LPtr<uint32_t> hk_c;
   // gather temp used when the pool is compacted (aliases the tail of the candidate arrays)
@@ -156,9 +157,10 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.p_wid = lds_take<uint32_t>(p, 4 * s.pool);
   o.p_m2 = lds_take<uint32_t>(p, 4 * s.pool);
   o.scal = lds_take<uint32_t>(p, 4 * 16);
-  o.smax = lds_take<uint64_t>(p, 8 * 2);
+  o.smax = lds_take<uint64_t>(p, 8 * 4);
   o.keep = lds_take<uint32_t>(p, 4 * s.bw);
   o.sel = lds_take<uint32_t>(p, 4 * s.bw);
+  o.part = lds_take<uint32_t>(p, 4 * 64);
   o.hk_h = lds_take<uint64_t>(p, 8 * s.bw);
   o.hk_p = lds_take<uint64_t>(p, 8 * s.bw);
   o.hk_c = lds_take<uint32_t>(p, 4 * s.bw);
@@ -615,42 +617,101 @@ struct BeamDecoder {
       if (ctx.tid == 0) L.scal[5] = 0;
       return n;
     }
-    uint32_t p2 = 512;
-    while (p2 < n) p2 <<= 1;
-    for (uint32_t k = n + ctx.tid; k < p2; k += ctx.nt) {
-      L.s_k0[k] = ~0ull;
-      L.s_k1[k] = ~0ull;
-    }
-    ctx.sync();
-    for (uint32_t size = 2; size <= p2; size <<= 1) {
-      for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-        for (uint32_t k = ctx.tid; k < (p2 >> 1); k += ctx.nt) {
-          uint32_t lo = ((k / stride) * stride * 2) + (k % stride);
-          uint32_t hi = lo + stride;
-          bool up = ((lo & size) == 0);
-          uint64_t a0 = L.s_k0[lo], a1 = L.s_k1[lo], b0 = L.s_k0[hi], b1 = L.s_k1[hi];
-          bool a_gt_b = (a0 > b0) || (a0 == b0 && a1 > b1);
-          if (a_gt_b == up) {
-            L.s_k0[lo] = b0;
-            L.s_k1[lo] = b1;
-            L.s_k0[hi] = a0;
-            L.s_k1[hi] = a1;
+    // Large sets (stress inputs, n > 256 > want): exact top-`want` selection by a bucket histogram.
+    // Scores are cut into 1024 monotone buckets over [max - width, max]; whole buckets above the one
+    // holding the want-th entry are taken, that boundary bucket is resolved by counting, and only the
+    // `want` chosen entries are ranked. The (all-zero) merge table is the histogram and is handed back
+    // zeroed; the compact index lists live in the idle rmax/rcnt arrays.
+    {
+      const double mx = sortable_to_max();
+      double lo = thr;
+      if (!(lo > mx - 64.0)) lo = mx - 64.0;  // clamp (keeps the map monotone; also covers thr = -inf)
+      const double scale = mx > lo ? 1023.0 / (mx - lo) : 0.0;
+      auto bucket_of = [&](uint32_t e) -> uint32_t {
+        const double sc = L.p_score[(uint32_t)(L.s_k1[e] & 0xFFFFFFFFull)];
+        double x = (mx - sc) * scale;
+        uint32_t bkt = x >= 1023.0 ? 1023u : (uint32_t)x;
+        return bkt;
+      };
+      LPtr<uint32_t> slist = L.rmax;  // chosen entries (compact indices): rmax[0 .. 256)
+      LPtr<uint32_t> blist;           // boundary-bucket entries: rmax[256 ..) running on into rcnt (768 slots)
+      blist.p = L.rmax.p + 256;
+      if (ctx.tid == 0) {
+        L.scal[10] = 0;  // chosen so far
+        L.scal[11] = 0;  // boundary entries listed
+        L.scal[12] = 0;  // boundary bucket
+        L.scal[13] = 0;  // entries in the buckets above it
+      }
+      for (uint32_t e = ctx.tid; e < n; e += ctx.nt) ctx.atomic_add(&L.table[bucket_of(e)], 1u);
+      ctx.sync();
+      // 64 partial sums of 16 buckets each, then the boundary bucket
+      for (uint32_t t = ctx.tid; t < 64u; t += ctx.nt) {
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < 16u; ++k) c += L.table[t * 16u + k];
+        L.part[t] = c;
+      }
+      ctx.sync();
+      for (uint32_t t = ctx.tid; t < 64u; t += ctx.nt) {
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < t; ++k) before += L.part[k];
+        const uint32_t mine = L.part[t];
+        if (before < want && want <= before + mine) {  // the want-th entry lies in my 16 buckets
+          uint32_t cum = before;
+          for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t h = L.table[t * 16u + k];
+            if (cum + h >= want) {
+              L.scal[12] = t * 16u + k;
+              L.scal[13] = cum;
+              break;
+            }
+            cum += h;
           }
         }
-        ctx.sync();
       }
-    }
-    for (uint32_t r = ctx.tid; r < want && r < n; r += ctx.nt) {
-      const uint32_t idx = (uint32_t)(L.s_k1[r] & 0xFFFFFFFFull);
-      L.sel[r] = idx;
-      L.keep[r] = 1u;
-      if (with_hist) {
-        uint64_t hh, ph;
-        uint32_t cc;
-        hist_key(idx, &hh, &ph, &cc);
-        L.hk_h[r] = hh;
-        L.hk_p[r] = ph;
-        L.hk_c[r] = cc;
+      ctx.sync();
+      const uint32_t bstar = L.scal[12], above = L.scal[13];
+      const uint32_t need = want - above;  // entries still to take from the boundary bucket (>= 1)
+      for (uint32_t e = ctx.tid; e < n; e += ctx.nt) {
+        const uint32_t bkt = bucket_of(e);
+        if (bkt < bstar) slist[ctx.atomic_add(&L.scal[10], 1u)] = e;
+        else if (bkt == bstar) blist[ctx.atomic_add(&L.scal[11], 1u)] = e;
+      }
+      ctx.sync();
+      const uint32_t m = L.scal[11];
+      for (uint32_t i = ctx.tid; i < m; i += ctx.nt) {  // rank inside the boundary bucket
+        const uint32_t e = blist[i];
+        const uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+          const uint32_t e2 = blist[j];
+          const uint64_t b0 = L.s_k0[e2], b1 = L.s_k1[e2];
+          rank += ((b0 < a0) || (b0 == a0 && b1 < a1)) ? 1u : 0u;
+        }
+        if (rank < need) slist[ctx.atomic_add(&L.scal[10], 1u)] = e;
+      }
+      ctx.sync();
+      for (uint32_t k = ctx.tid; k < 1024u; k += ctx.nt) L.table[k] = 0;  // hand the table back zeroed
+      // rank the `want` chosen entries among themselves
+      for (uint32_t i = ctx.tid; i < want; i += ctx.nt) {
+        const uint32_t e = slist[i];
+        const uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < want; ++j) {
+          const uint32_t e2 = slist[j];
+          const uint64_t b0 = L.s_k0[e2], b1 = L.s_k1[e2];
+          rank += ((b0 < a0) || (b0 == a0 && b1 < a1)) ? 1u : 0u;
+        }
+        const uint32_t idx = (uint32_t)(a1 & 0xFFFFFFFFull);
+        L.sel[rank] = idx;
+        L.keep[rank] = 1u;
+        if (with_hist) {
+          uint64_t hh, ph;
+          uint32_t cc;
+          hist_key(idx, &hh, &ph, &cc);
+          L.hk_h[rank] = hh;
+          L.hk_p[rank] = ph;
+          L.hk_c[rank] = cc;
+        }
       }
     }
     ctx.sync();
@@ -660,6 +721,7 @@ struct BeamDecoder {
 
   // keep only the best `beam_width` pool entries (exact: pruning is monotone)
   CTC_HD void prune_pool() {
+    tick<6>();
     uint32_t pool_n = L.scal[0];
     double mx = sortable_to_max();
     uint32_t n = sort_pool(pool_n, mx + prm.beam_prune_logp, false);
@@ -683,10 +745,16 @@ struct BeamDecoder {
       L.p_wid[k] = L.g_wid[k];
       L.p_m2[k] = L.g_m2[k];
     }
-    if (ctx.tid == 0) L.scal[0] = n;
+    if (ctx.tid == 0) {
+      L.scal[0] = n;
+      // from now on only a candidate that beats the current beam_width-th best can still matter: later
+      // candidates arrive later, so an equal score ranks behind the beam_width entries kept here
+      if (n >= (uint32_t)prm.beam_width) L.smax[2] = asc_key(L.g_score[n - 1]);
+    }
     ctx.sync();
     clear_table();  // the gather temp may overlap the (all-zero between chunks) merge table
     ctx.sync();
+    tick<23>();
   }
 
   CTC_HD double sortable_to_max() const {
@@ -777,6 +845,7 @@ struct BeamDecoder {
     uint32_t Q = (s1 - s0) * (uint32_t)N;
     // conservative running threshold from the chunks already seen (nobody writes smax here)
     double thr_prev = sortable_to_max() + prm.beam_prune_logp;
+    const uint64_t kth_key = L.smax[2];  // 0 until a pool prune has fixed a beam_width-th best
     // G1: keys
     for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
       uint32_t s = s0 + q / (uint32_t)N;
@@ -848,7 +917,7 @@ struct BeamDecoder {
         }
         double score = total_score(tab, lg, lmhw, pv.ps, pv.pl);
         my_key = asc_key(score);
-        if (score >= thr_prev) {
+        if (score >= thr_prev && my_key > kth_key) {
           uint32_t imax = qmax % (uint32_t)N;
           pool_push(score, lg, s * (uint32_t)N + (uint32_t)i, (s << 8) | imax, pv.wid, pv.m2);
         }
@@ -977,6 +1046,7 @@ struct BeamDecoder {
       L.scal[0] = 0;
       L.scal[4] = 0;
       L.smax[0] = asc_key(-INFINITY);
+      L.smax[2] = 0;
     }
     tick<9>();
     uint32_t ns = load_survivors(t);
@@ -995,6 +1065,9 @@ struct BeamDecoder {
     ctx.sync();
     prefetch(t + 1);  // lands while this frame's candidates are processed
     tick<2>();
+    // Labels are taken in chunks of whole labels (<= cand candidates). Before a chunk that might not fit
+    // the pool, the pool is compacted to its best beam_width entries; that also fixes the score a later
+    // candidate has to beat (smax[2]), so the following chunks add little to the pool.
     uint32_t per = (uint32_t)shape.cand / (uint32_t)N;
     if (per == 0) per = 1;
     for (uint32_t s0 = 0; s0 < ns; s0 += per) {
