@@ -93,10 +93,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CTC_BENCH_FORCE_DIST") == "1"  # the latter: 1-GPU rehearsal of the N>1 path
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        args.no_cpu_baseline = True  # the CPU leg runs at N=1 only (and must not fork after HIP is up)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     os.environ["CTCDEC_DEVICE"] = str(local_rank)
 
@@ -112,7 +117,7 @@ def main():
     else:
         if rank == 0:
             lm, labels, hot = build_assets(cache, args.lm_words, args.lm_sentences)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         if rank != 0:
             lm, labels, hot = build_assets(cache, args.lm_words, args.lm_sentences)
@@ -127,7 +132,7 @@ def main():
         ref_texts, cpu_fps, cpu_dt = cpu_baseline(lm, labels, hot, xs[:n_s], cores)
         cpu = (cores, n_s, ref_texts, cpu_fps, cpu_dt)
         log("cpu baseline: %.0f frames/s on %d cores (%d utterances, %.1f s)" % (cpu_fps, cores, n_s, cpu_dt))
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.set_device(local_rank)
     decoder = build_ctcdecoder(labels, lm.path if lm is not None else None)
@@ -138,12 +143,12 @@ def main():
 
     def step():
         texts = decoder.decode_batch(None, dev, beam_width=BEAM, hotwords=hot)
-        if world > 1:
+        if use_dist:
             texts = gather_texts(texts)
         return texts
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -176,7 +181,7 @@ def main():
         tot = float(sum(ticks)) or 1.0
         log("phase ticks (utterance 0, 100 MHz): " + ", ".join(
             "%s %.0f us (%.0f%%)" % (n, t / 100.0, 100.0 * t / tot) for n, t in zip(names, ticks) if t))
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -252,8 +257,15 @@ def main():
                 "texts_match_gpu": ref_texts == texts[:n_s],
             }
             out["speedup_vs_cpu_port"] = value / cpu_fps if cpu_fps > 0 else None
-        print(json.dumps(out))
-    if world > 1:
+        if use_dist:
+            # RCCL prints its NCCL_DEBUG=VERSION banner through C stdio: push it out first so that the JSON
+            # line is the last thing on stdout
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

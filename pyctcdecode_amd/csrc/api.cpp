@@ -441,7 +441,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
                        const StreamIn* stream, ctcdec_result** out) {
   if (!dec || !p || !out || n_utts < 0 || (n_utts > 0 && (!utt_logits || !utt_frames)))
     return fail(CTCDEC_ERR_ARG, "bad arguments");
-  if (dtype != CTCDEC_F32 && dtype != CTCDEC_F64) return fail(CTCDEC_ERR_ARG, "dtype must be f32 or f64");
+  if (dtype < CTCDEC_F32 || dtype > CTCDEC_BF16) return fail(CTCDEC_ERR_ARG, "dtype must be f32, f64, f16 or bf16");
   if (p->beam_width < 1) return fail(CTCDEC_ERR_ARG, "beam_width must be >= 1");
   if (p->beam_width > CTCDEC_MAX_BEAM_WIDTH)
     return fail(CTCDEC_ERR_LIMIT, "beam_width above the supported maximum of 256");
@@ -455,7 +455,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   }
   if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
-  const size_t esz = dtype == CTCDEC_F32 ? 4 : 8;
+  const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
 
   std::vector<int64_t> row0((size_t)n_utts + 1, 0);
   for (int32_t u = 0; u < n_utts; ++u) {

@@ -10,6 +10,7 @@
 //   beam_decode               the sequential prefix-beam recursion (beam_core.h); one workgroup
 //                             per utterance, beam table / candidates / merge table in LDS
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -121,6 +122,17 @@ __device__ __forceinline__ double wave_max(double v) {
 template <typename T>
 __device__ __forceinline__ double ld(const T* p, size_t i) {
   return (double)p[i];
+}
+// 16-bit logits straight from the acoustic model: exact widening to fp64 (no intermediate fp32 copy)
+struct half_bits { uint16_t u; };
+struct bf16_bits { uint16_t u; };
+template <>
+__device__ __forceinline__ double ld<half_bits>(const half_bits* p, size_t i) {
+  return (double)__half2float(__ushort_as_half(p[i].u));
+}
+template <>
+__device__ __forceinline__ double ld<bf16_bits>(const bf16_bits* p, size_t i) {
+  return (double)__uint_as_float(((uint32_t)p[i].u) << 16);
 }
 
 // row -> utterance (binary search over the prefix sums)
@@ -408,8 +420,12 @@ int launch_prune(const PruneArgs& a, std::string* err) {
       else CTC_LAUNCH_PRUNE(frame_prune_f32x4<4>);
     } else if (a.dtype == 0) {
       CTC_LAUNCH_PRUNE(frame_prune<float>);
-    } else {
+    } else if (a.dtype == 1) {
       CTC_LAUNCH_PRUNE(frame_prune<double>);
+    } else if (a.dtype == 2) {
+      CTC_LAUNCH_PRUNE(frame_prune<half_bits>);
+    } else {
+      CTC_LAUNCH_PRUNE(frame_prune<bf16_bits>);
     }
 #undef CTC_LAUNCH_PRUNE
     HIP_TRY(hipGetLastError());

@@ -134,18 +134,20 @@ class _Batch:
 
             # our kernels run on their own stream: make sure the producer of the logits is done
             torch.cuda.current_stream().synchronize()
-            want64 = any(x.dtype == torch.float64 for x in logits_list)
+            dtypes = {x.dtype for x in logits_list}
+            native = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
+            if len(dtypes) == 1 and next(iter(dtypes)) in native:
+                target = next(iter(dtypes))  # fp16 / bf16 / fp32 / fp64 tensors are read in place
+            else:
+                target = torch.float64 if torch.float64 in dtypes or any(not d.is_floating_point for d in dtypes) \
+                    else torch.float32
             for x in logits_list:
-                t = x
-                if want64:
-                    t = t.to(torch.float64)
-                elif t.dtype != torch.float32:
-                    t = t.to(torch.float32)
+                t = x if x.dtype == target else x.to(target)
                 t = t.contiguous()
                 self.keep.append(t)
                 self.ptrs.append(int(t.data_ptr()))
                 self.frames.append(int(t.shape[0]))
-            self.dtype = 1 if want64 else 0
+            self.dtype = native[target]
         else:
             arrs = [x.detach().cpu().numpy() if _is_device_tensor(x) else np.asarray(x) for x in logits_list]
             want32 = len(arrs) > 0 and all(a.dtype == np.float32 or a.dtype == np.float16 for a in arrs)

@@ -53,7 +53,19 @@ int sync(std::string*) { return 0; }
 void last_timing(double* a, double* b) { *a = 0; *b = 0; }
 
 static double load(const void* base, int dtype, size_t idx) {
-  return dtype == 0 ? (double)((const float*)base)[idx] : ((const double*)base)[idx];
+  if (dtype == 0) return (double)((const float*)base)[idx];
+  if (dtype == 1) return ((const double*)base)[idx];
+  uint16_t h = ((const uint16_t*)base)[idx];
+  if (dtype == 3) {  // bf16
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return (double)f;
+  }
+  // fp16 -> double
+  int sign = h >> 15, ex = (h >> 10) & 31, man = h & 1023;
+  double v = ex == 0 ? ldexp((double)man, -24) : ex == 31 ? (man ? NAN : INFINITY) : ldexp((double)(man | 1024), ex - 25);
+  return sign ? -v : v;
 }
 
 int launch_prune(const PruneArgs& a, std::string*) {

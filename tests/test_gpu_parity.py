@@ -278,3 +278,20 @@ def test_hip_config5_streaming_64_streams(lm, bpe):
         assert [b.text for b in beams[u]] == [e.text for e in exp]
         assert [[tuple(f) for f in b.text_frames] for b in beams[u]] == [[tuple(f) for f in e.tframes] for e in exp]
         assert all(abs(b.lm_score - e.lm) < TOL * max(1.0, abs(e.lm)) for b, e in zip(beams[u], exp))
+
+
+def test_hip_half_precision_logits_in_place(lm, bpe):
+    """fp16 / bf16 device logits are read in place (exact widening); the result must equal decoding the
+    same values handed over as fp32."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(bpe, lm.path)
+    x = synth.d_words(4, 21, 300, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0)
+    for dt in (torch.float16, torch.bfloat16):
+        xh = torch.from_numpy(x).cuda().to(dt)
+        a = dec.decode_beams(xh, prune_history=True)
+        b = dec.decode_beams(xh.to(torch.float32), prune_history=True)
+        assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a] == [
+            (o.text, o.text_frames, o.logit_score, o.lm_score) for o in b]
