@@ -423,6 +423,66 @@ class BeamSearchDecoderCTC:
         finally:
             self._lib.dll.ctcdec_result_free(res)
 
+    # -- serialisation (decoder.py:947-1043): alphabet.json + language_model/ --------------------------
+    _ALPHABET_SERIALIZED_FILENAME = "alphabet.json"
+    _LANGUAGE_MODEL_SERIALIZED_DIRECTORY = "language_model"
+
+    def save_to_dir(self, filepath: str) -> None:
+        with open(os.path.join(filepath, self._ALPHABET_SERIALIZED_FILENAME), "w") as fi:
+            fi.write(self._alphabet.dumps())
+        lm = self._language_model
+        if lm is None:
+            logger.info("decoder has no language model.")
+        else:
+            lm_path = os.path.join(filepath, self._LANGUAGE_MODEL_SERIALIZED_DIRECTORY)
+            os.makedirs(lm_path)
+            logger.info("Saving language model to %s", lm_path)
+            lm.save_to_dir(lm_path)
+
+    @staticmethod
+    def parse_directory_contents(filepath: str) -> Dict[str, Optional[str]]:
+        contents = [c for c in os.listdir(filepath) if not c.startswith(".") and not c.startswith("__")]
+        if BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME not in contents:
+            raise ValueError(
+                f"Could not find alphabet file {BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME}. Found {contents}"
+            )
+        alphabet_filepath = os.path.join(filepath, BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME)
+        contents.remove(BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME)
+        lm_directory: Optional[str] = None
+        if contents:
+            if BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY not in contents:
+                raise ValueError(
+                    f"Count not find language model directory. Looking for "
+                    f"{BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY}, found {contents}"
+                )
+            lm_directory = os.path.join(filepath, BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY)
+        return {"alphabet": alphabet_filepath, "language_model": lm_directory}
+
+    @classmethod
+    def load_from_dir(cls, filepath: str, unigram_encoding: Optional[str] = None) -> "BeamSearchDecoderCTC":
+        filenames = cls.parse_directory_contents(filepath)
+        with open(filenames["alphabet"], "r") as fi:
+            alphabet = Alphabet.loads(fi.read())
+        language_model = None
+        if filenames["language_model"] is not None:
+            language_model = LanguageModel.load_from_dir(filenames["language_model"], unigram_encoding=unigram_encoding)
+        return cls(alphabet, language_model=language_model)
+
+    @classmethod
+    def load_from_hf_hub(cls, model_id: str, cache_dir: Optional[str] = None, **kwargs: Any) -> "BeamSearchDecoderCTC":
+        """decoder.py:1007-1043: snapshot-download a decoder directory from the Hugging Face hub."""
+        from pathlib import Path
+
+        cache_dir = cache_dir or os.path.join(Path.home(), ".cache", "pyctcdecode")
+        try:
+            from huggingface_hub import snapshot_download
+        except ImportError:
+            raise ImportError(
+                "You need to install huggingface_hub to use `load_from_hf_hub`. "
+                "See https://pypi.org/project/huggingface-hub/ for installation."
+            )
+        return cls.load_from_dir(snapshot_download(model_id, cache_dir=cache_dir, **kwargs))
+
     # -- streaming (decoder.py:669-728) ----------------------------------------------------------
     def get_starting_state(self):
         """decoder.py:669-679: (beams, cached_lm_scores, cached_p_lm_scores) to start a stream with."""

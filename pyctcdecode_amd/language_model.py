@@ -296,6 +296,7 @@ class LanguageModel(AbstractLanguageModel):
         if unigrams is None:
             logger.warning("No known unigrams provided, decoding results might be a lot worse.")
             self._has_trie = False
+            self._given_unigrams = set()
             self._n_unigrams = kenlm_model.set_unigrams(None)
         else:
             if len(unigrams) < 1000:
@@ -303,7 +304,8 @@ class LanguageModel(AbstractLanguageModel):
                     "Only %s unigrams passed as vocabulary. Is this small or artificial data?", len(unigrams)
                 )
             self._has_trie = True
-            self._n_unigrams = kenlm_model.set_unigrams(set(unigrams))
+            self._given_unigrams = set(unigrams)
+            self._n_unigrams = kenlm_model.set_unigrams(self._given_unigrams)
             retained = 1.0 if len(unigrams) == 0 else self._n_unigrams / len(unigrams)
             if retained < 0.1:
                 logger.warning(
@@ -315,6 +317,75 @@ class LanguageModel(AbstractLanguageModel):
         self.beta = beta
         self.unk_score_offset = unk_score_offset
         self.score_boundary = score_boundary
+
+    # -- serialisation (language_model.py:362-452): a directory with exactly three files --------------
+    JSON_ATTRS = ("alpha", "beta", "unk_score_offset", "score_boundary")
+    _ATTRS_SERIALIZED_FILENAME = "attrs.json"
+    _UNIGRAMS_SERIALIZED_FILENAME = "unigrams.txt"
+
+    @property
+    def _unigram_set(self) -> Set[str]:
+        """Unigrams that survived the filter to the LM vocabulary (language_model.py:95)."""
+        return {w for w in self._given_unigrams if w in self._kenlm_model}
+
+    @property
+    def serializable_attrs(self) -> Dict[str, Any]:
+        attrs = {}
+        for name in LanguageModel.JSON_ATTRS:
+            val = getattr(self, name)
+            if val is None:
+                raise ValueError(f"attribute {name} not found. Cannot serialize")
+            attrs[name] = val
+        return attrs
+
+    def save_to_dir(self, filepath: str, unigram_encoding: Optional[str] = None) -> None:
+        import json
+        import os
+        import shutil
+
+        with open(os.path.join(filepath, self._ATTRS_SERIALIZED_FILENAME), "w") as fi:
+            json.dump(self.serializable_attrs, fi)
+        with open(os.path.join(filepath, self._UNIGRAMS_SERIALIZED_FILENAME), "w", encoding=unigram_encoding) as fi:
+            for unigram in sorted(self._unigram_set):
+                fi.write(unigram + "\n")
+        src = self._kenlm_model.path.decode("utf-8")
+        shutil.copy2(src, os.path.join(filepath, os.path.split(src)[1]))
+
+    @staticmethod
+    def parse_directory_contents(filepath: str) -> Dict[str, str]:
+        import os
+
+        contents = [c for c in os.listdir(filepath) if not c.startswith(".") and not c.startswith("__")]
+        if len(contents) != 3:
+            raise ValueError(f"Found wrong number of files in directory. Expected 3 files, found {contents}")
+        for needed, what in ((LanguageModel._ATTRS_SERIALIZED_FILENAME, "attributes"),
+                             (LanguageModel._UNIGRAMS_SERIALIZED_FILENAME, "unigrams")):
+            if needed not in contents:
+                raise ValueError(f"did not find {what} file in files: {contents}")
+            contents.remove(needed)
+        kenlm_file = contents[0]
+        if os.path.splitext(kenlm_file)[1] not in {".arpa", ".bin", ".binary"}:
+            raise ValueError(f"Explected kenlm file to end in `.arpa` or `.bin(ary)`. Found {kenlm_file}")
+        return {
+            "json_attrs": os.path.join(filepath, LanguageModel._ATTRS_SERIALIZED_FILENAME),
+            "unigrams": os.path.join(filepath, LanguageModel._UNIGRAMS_SERIALIZED_FILENAME),
+            "kenlm": os.path.join(filepath, kenlm_file),
+        }
+
+    @classmethod
+    def load_from_dir(cls, filepath: str, unigram_encoding: Optional[str] = None) -> "LanguageModel":
+        import json
+
+        filenames = cls.parse_directory_contents(filepath)
+        with open(filenames["json_attrs"], "r") as fi:
+            json_attrs = json.load(fi)
+        if set(json_attrs.keys()) != set(cls.JSON_ATTRS):
+            raise ValueError(
+                f"Expected json serialized attributes to be {cls.JSON_ATTRS} but found {json_attrs.keys()}"
+            )
+        with open(filenames["unigrams"], "r", encoding=unigram_encoding) as fi:
+            unigrams = fi.read().splitlines()
+        return cls(NgramModel(filenames["kenlm"]), unigrams, **json_attrs)
 
     def reset_params(self, **params: Dict[str, Any]) -> None:
         """language_model.py:271-301."""
