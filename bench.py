@@ -137,7 +137,8 @@ def main():
     torch.cuda.set_device(local_rank)
     decoder = build_ctcdecoder(labels, lm.path if lm is not None else None)
     log("decoder built")
-    dev = [torch.from_numpy(x).cuda() for x in xs]
+    # one padded [B, T, V] tensor, the way an acoustic model hands its logits over
+    dev = torch.from_numpy(np.stack(xs)).cuda()
     log("logits on device")
     total_frames = args.batch * args.frames * world
 

@@ -489,47 +489,6 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
 
   const int B = p->beam_width;
 
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    size_t rows = (size_t)std::max<int64_t>(R, 1);
-    if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
-        dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
-        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err))
-      return fail(CTCDEC_ERR_DEVICE, err);
-    if (be::zero(dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    be::PruneArgs pa;
-    pa.utt_logits = (const void* const*)dec->w_ptrs.p;
-    pa.utt_row0 = (const int64_t*)dec->w_row0.p;
-    pa.n_utts = n_utts;
-    pa.n_rows = R;
-    pa.n_labels = V;
-    pa.dtype = dtype;
-    pa.token_min_logp = p->token_min_logp;
-    pa.max_surv = max_surv;
-    pa.row_sum = (double*)dec->w_rowsum.p;
-    pa.utt_is_prob = (uint32_t*)dec->w_isprob.p;
-    pa.surv_cnt = (uint32_t*)dec->w_scnt.p;
-    pa.surv_id = (uint16_t*)dec->w_sid.p;
-    pa.surv_lp = (double*)dec->w_slp.p;
-    pa.overflow = (uint32_t*)dec->w_flags.p;
-    pa.pass = 0;
-    pa.rows_aligned16 = 1;
-    for (const void* q : ptrs)
-      if (((uintptr_t)q & 15u) != 0) pa.rows_aligned16 = 0;
-    if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    uint32_t flags[2] = {0, 0};
-    if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    if (flags[1]) {  // some utterance looks like probabilities (decoder.py:760): redo those rows
-      pa.pass = 1;
-      if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
-      if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-      if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    }
-    const uint32_t ovf = flags[0];
-    if (!ovf) break;
-    if (max_surv == V) return fail(CTCDEC_ERR_INTERNAL, "survivor overflow at full vocabulary");
-    max_surv = V;  // un-normalised probability rows can exceed the bound: redo at full width
-  }
-
   // arenas
   std::vector<uint64_t> toff((size_t)n_utts + 1, 0), eoff((size_t)n_utts + 1, 0);
   for (int32_t u = 0; u < n_utts; ++u) {
@@ -568,7 +527,6 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       dec->w_tok.ensure((size_t)std::max<unsigned long long>(tok_cap, 1) * sizeof(EmitNode), &err) ||
       dec->w_head.ensure(16, &err))
     return fail(CTCDEC_ERR_DEVICE, err);
-  if (be::zero(dec->w_head.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const LmState* d_start = nullptr;
   if (stream) {
     d_start = nullptr;  // every imported beam carries its own LM state
@@ -616,7 +574,6 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   dp.unk = p->unk_score_offset;
   dp.log_base_change = p->log_base_change;
   dp.score_boundary = p->lm_score_boundary ? 1 : 0;
-  dp.max_surv = max_surv;
   dp.fold = stream ? stream->fold : 1;
   dp.eos = stream ? stream->eos : 1;
   ba.n_utts = n_utts;
@@ -644,7 +601,58 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     if (dec->w_prof.ensure(N_PROF * 8, &err) || be::zero(dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     ba.prof = (unsigned long long*)dec->w_prof.p;
   }
-  if (be::launch_beam(ba, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  // Everything the beam stage needs is staged BEFORE the prune stage is launched, and the beam kernel is
+  // queued right behind it on the same stream: the host never sits between the two kernels. The two
+  // rare events the prune stage can report (probability-like input, survivor overflow) are read back
+  // afterwards and simply redo the affected stage(s).
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    size_t rows = (size_t)std::max<int64_t>(R, 1);
+    if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
+        dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
+        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    if (be::zero(dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    be::PruneArgs pa;
+    pa.utt_logits = (const void* const*)dec->w_ptrs.p;
+    pa.utt_row0 = (const int64_t*)dec->w_row0.p;
+    pa.n_utts = n_utts;
+    pa.n_rows = R;
+    pa.n_labels = V;
+    pa.dtype = dtype;
+    pa.token_min_logp = p->token_min_logp;
+    pa.max_surv = max_surv;
+    pa.row_sum = (double*)dec->w_rowsum.p;
+    pa.utt_is_prob = (uint32_t*)dec->w_isprob.p;
+    pa.surv_cnt = (uint32_t*)dec->w_scnt.p;
+    pa.surv_id = (uint16_t*)dec->w_sid.p;
+    pa.surv_lp = (double*)dec->w_slp.p;
+    pa.overflow = (uint32_t*)dec->w_flags.p;
+    pa.pass = 0;
+    pa.rows_aligned16 = 1;
+    for (const void* q : ptrs)
+      if (((uintptr_t)q & 15u) != 0) pa.rows_aligned16 = 0;
+    ba.surv_cnt = (const uint32_t*)dec->w_scnt.p;
+    ba.surv_id = (const uint16_t*)dec->w_sid.p;
+    ba.surv_lp = (const double*)dec->w_slp.p;
+    dp.max_surv = max_surv;
+    auto run_beam = [&]() -> int {
+      if (be::zero(dec->w_head.p, 16, &err)) return -1;
+      return be::launch_beam(ba, &err);
+    };
+    if (be::launch_prune(pa, &err) || run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
+    uint32_t flags[2] = {0, 0};
+    if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    if (flags[1]) {  // some utterance looks like probabilities (decoder.py:760): redo those rows, then the beams
+      pa.pass = 1;
+      if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
+      if (be::launch_prune(pa, &err) || run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
+      if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    }
+    const uint32_t ovf = flags[0];
+    if (!ovf) break;
+    if (max_surv == V) return fail(CTCDEC_ERR_INTERNAL, "survivor overflow at full vocabulary");
+    max_surv = V;  // un-normalised probability rows can exceed the bound: redo at full width
+  }
 
   // results back (page-locked staging: the token pool is a few MB per batch)
   const bool host_timing = getenv("CTCDEC_HOST_TIMING") != nullptr;

@@ -232,7 +232,7 @@ std::string HostLM::load_arpa(const std::string& path) {
   if (order > MAX_CTX + 1) return "LM order " + std::to_string(order) + " exceeds the supported maximum";
   n_ngrams = raw.size();
   uint64_t size = 16;
-  while (size < 2 * raw.size() + 1) size <<= 1;
+  while (size < 4 * raw.size() + 1) size <<= 1;  // load <= 1/4: a miss (the common case when backing off) costs ~1.2 probes
   ngram_table.assign(size, NgramEntry{0, 0.f, 0.f});
   ngram_mask = size - 1;
   for (const RawGram& g : raw) table_put(ngram_table, ngram_mask, g.key, g.prob, g.backoff);
@@ -288,7 +288,7 @@ void HostLM::build_prefix_table() {
     }
   }
   uint64_t size = 16;
-  while (size < 2 * m.size() + 1) size <<= 1;
+  while (size < 4 * m.size() + 1) size <<= 1;  // load <= 1/4: most probes are misses, keep them at ~1.2 slots
   prefix_table.assign(size, PrefixEntry{0, 0, 0});
   prefix_mask = size - 1;
   for (auto& kv : m) {
@@ -361,7 +361,7 @@ void HostHotwords::build(const std::vector<std::string>& uni, const HostAlphabet
   mask = 0;
   if (!m.empty()) {
     uint64_t size = 16;
-    while (size < 2 * m.size() + 1) size <<= 1;
+    while (size < 4 * m.size() + 1) size <<= 1;  // load <= 1/4: most probes are misses, keep them at ~1.2 slots
     table.assign(size, HotEntry{0, 0, 0});
     mask = size - 1;
     for (auto& kv : m) {

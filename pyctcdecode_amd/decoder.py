@@ -107,7 +107,8 @@ def _is_device_tensor(x: Any) -> bool:
 
 
 class _Batch:
-    """Logit matrices of one call, normalised to what the C ABI takes."""
+    """Logit matrices of one call, normalised to what the C ABI takes (and shape-checked like
+    _check_logits_dimension, decoder.py:330-344)."""
 
     def __init__(self, logits_list: Sequence[Any], n_labels: int):
         self.keep: List[Any] = []  # keeps buffers alive during the call
@@ -115,27 +116,31 @@ class _Batch:
         self.frames: List[int] = []
         self.is_device = False
         self.dtype = 0
-        kinds = set()
+        if getattr(logits_list, "ndim", 0) == 3 and self._from_3d(logits_list, n_labels):
+            return
+        n_dev = 0
         for x in logits_list:
-            shape = tuple(x.shape)
+            shape = x.shape
             if len(shape) != 2:
                 raise ValueError("Input logits have %s dimensions, but need 2: (time, vocabulary)" % len(shape))
-            if shape[-1] != n_labels:
+            if shape[1] != n_labels:
                 raise ValueError(
                     "Input logits shape is %s, but vocabulary is size %s. "
-                    "Need logits of shape: (time, vocabulary)" % (shape, n_labels)
+                    "Need logits of shape: (time, vocabulary)" % (tuple(shape), n_labels)
                 )
-            kinds.add(_is_device_tensor(x) and bool(x.is_cuda))
-        if len(kinds) > 1:
+            if getattr(x, "is_cuda", False):
+                n_dev += 1
+        if n_dev not in (0, len(logits_list)):
             raise ValueError("cannot mix host arrays and device tensors in one batch")
-        self.is_device = bool(kinds.pop()) if kinds else False
+        self.is_device = n_dev > 0
+        keep, ptrs, frames = self.keep, self.ptrs, self.frames
         if self.is_device:
             import torch
 
             # our kernels run on their own stream: make sure the producer of the logits is done
             torch.cuda.current_stream().synchronize()
-            dtypes = {x.dtype for x in logits_list}
             native = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
+            dtypes = {x.dtype for x in logits_list}
             if len(dtypes) == 1 and next(iter(dtypes)) in native:
                 target = next(iter(dtypes))  # fp16 / bf16 / fp32 / fp64 tensors are read in place
             else:
@@ -143,20 +148,54 @@ class _Batch:
                     else torch.float32
             for x in logits_list:
                 t = x if x.dtype == target else x.to(target)
-                t = t.contiguous()
-                self.keep.append(t)
-                self.ptrs.append(int(t.data_ptr()))
-                self.frames.append(int(t.shape[0]))
+                if not t.is_contiguous():
+                    t = t.contiguous()
+                keep.append(t)
+                ptrs.append(t.data_ptr())
+                frames.append(t.shape[0])
             self.dtype = native[target]
         else:
             arrs = [x.detach().cpu().numpy() if _is_device_tensor(x) else np.asarray(x) for x in logits_list]
             want32 = len(arrs) > 0 and all(a.dtype == np.float32 or a.dtype == np.float16 for a in arrs)
             for a in arrs:
                 a = np.ascontiguousarray(a, dtype=np.float32 if want32 else np.float64)
-                self.keep.append(a)
-                self.ptrs.append(a.ctypes.data if a.size else 0)
-                self.frames.append(int(a.shape[0]))
+                keep.append(a)
+                ptrs.append(a.ctypes.data if a.size else 0)
+                frames.append(int(a.shape[0]))
             self.dtype = 0 if want32 else 1
+
+
+    def _from_3d(self, batch: Any, n_labels: int) -> bool:
+        """A padded [B, T, V] batch straight from the acoustic model: one pointer + strides instead of B
+        per-utterance objects.  Returns False when the generic path has to take over."""
+        if batch.shape[2] != n_labels:
+            raise ValueError(
+                "Input logits shape is %s, but vocabulary is size %s. "
+                "Need logits of shape: (time, vocabulary)" % (tuple(batch.shape[1:]), n_labels)
+            )
+        if getattr(batch, "is_cuda", False):
+            import torch
+
+            native = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
+            if batch.dtype not in native:
+                return False
+            torch.cuda.current_stream().synchronize()
+            t = batch if batch.is_contiguous() else batch.contiguous()
+            base, step = t.data_ptr(), t.stride(0) * t.element_size()
+            self.dtype = native[batch.dtype]
+            self.is_device = True
+        elif isinstance(batch, np.ndarray):
+            want32 = batch.dtype in (np.float32, np.float16)
+            t = np.ascontiguousarray(batch, dtype=np.float32 if want32 else np.float64)
+            base, step = t.ctypes.data, t.strides[0]
+            self.dtype = 0 if want32 else 1
+        else:
+            return False
+        n, frames = int(t.shape[0]), int(t.shape[1])
+        self.keep.append(t)
+        self.ptrs = [base + k * step for k in range(n)]
+        self.frames = [frames] * n
+        return True
 
 
 class BeamSearchDecoderCTC:
@@ -382,9 +421,8 @@ class BeamSearchDecoderCTC:
         hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
     ) -> List[str]:
         """decoder.py:895-945. ``pool`` is ignored (one device launch decodes the whole batch)."""
-        logits_list = list(logits_list)
-        for logits in logits_list:
-            self._check_logits_dimension(logits)
+        if getattr(logits_list, "ndim", 0) != 3:
+            logits_list = list(logits_list)
         if len(logits_list) == 0:
             return []
         params = self._params(beam_width, beam_prune_logp, token_min_logp, True, hotword_weight, 1)
@@ -395,7 +433,11 @@ class BeamSearchDecoderCTC:
             nb = int(pk.n_beams)
             text_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
             blob = C.string_at(pk.text_blob, int(text_off[nb])) if text_off[nb] else b""
-            return [blob[int(text_off[k]) : int(text_off[k + 1])].decode("utf-8") for k in range(nb)]
+            off = text_off.tolist()
+            if blob.isascii():  # byte offsets == character offsets: decode once, slice the str
+                text = blob.decode("ascii")
+                return [text[off[k] : off[k + 1]] for k in range(nb)]
+            return [blob[off[k] : off[k + 1]].decode("utf-8") for k in range(nb)]
         finally:
             self._lib.dll.ctcdec_result_free(res)
 

@@ -295,3 +295,21 @@ def test_hip_half_precision_logits_in_place(lm, bpe):
         b = dec.decode_beams(xh.to(torch.float32), prune_history=True)
         assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a] == [
             (o.text, o.text_frames, o.logit_score, o.lm_score) for o in b]
+
+
+def test_hip_probability_rows_overflowing_the_survivor_bound():
+    """Rows read as probabilities (mean row sum 1) whose single rows exceed the e^5 survivor bound: the
+    prune stage reports the overflow and both stages are redone at full width."""
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+    from tests.test_sim_vs_oracle import _unnormalised_prob_rows
+
+    labels = ["t%d" % i for i in range(199)] + [" "]
+    x = _unnormalised_prob_rows(V=201)
+    dec = build_ctcdecoder(labels)
+    alpha = Alphabet.build_alphabet(labels)
+    orc = build_oracle(alpha.labels, alpha.is_bpe)
+    got = dec.decode_beams(x, beam_width=20)
+    exp = _oracle_expected(orc, x, {"beam_width": 20})
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="overflow")

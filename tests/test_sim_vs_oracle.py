@@ -81,3 +81,69 @@ def test_decode_and_batch_api(sim_library):  # noqa: F811
         dec.decode(np.zeros((3, 30)))
     with pytest.raises(ValueError):
         dec.decode(np.zeros((3,)))
+
+
+def _unnormalised_prob_rows(V=200, T=6, seed=3):
+    """Rows whose MEAN sum is 1 (=> read as probabilities, decoder.py:760) although single rows hold far
+    more than e^5 labels above token_min_logp: exercises the survivor-overflow retry at full width."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((T, V)) + 0.5
+    sums = np.array([0.2, 1.8] * (T // 2))
+    x = x / x.sum(axis=1, keepdims=True) * sums[:, None]
+    assert abs(x.sum(axis=1).mean() - 1.0) < 1e-12
+    return x
+
+
+def test_probability_rows_overflowing_the_survivor_bound(sim_library):  # noqa: F811
+    labels = ["t%d" % i for i in range(199)] + [" "]
+    x = _unnormalised_prob_rows(V=201)
+    _compare(labels, None, x, dkw={"beam_width": 20}, what="overflow")
+
+
+def test_three_dimensional_batch_input(sim_library):  # noqa: F811
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, LM.path)
+    xs = [synth.d_words(2, u, 30, synth.LIBRI_LABELS, False, LM.words, LM.sentences, 28, boost=6.0) for u in range(4)]
+    assert dec.decode_batch(None, np.stack(xs)) == dec.decode_batch(None, xs)
+    with pytest.raises(ValueError):
+        dec.decode_batch(None, np.zeros((2, 5, 7), dtype=np.float32))
+
+
+def test_lm_start_state_carry_over(sim_library):  # noqa: F811
+    """decode_beams(lm_start_state=prev.last_lm_state) (reference tests/test_decoder.py:426-456)."""
+    from pyctcdecode_amd import build_ctcdecoder
+    from tests.golden_util import TOY_ARPA, load_cases, load_known
+
+    cases, inputs = load_cases()
+    case = {c["name"]: c for c in cases}["toy_lm_default"]
+    x = inputs[case["input"]]
+    known = load_known()["stateful"]
+    dec = build_ctcdecoder(case["labels"], TOY_ARPA, ["bugs", "bunny"])
+    first = dec.decode_beams(x[:5])
+    assert first[0].text == known["first"]["text"]
+    st = first[0].last_lm_state
+    lm = dec._language_model._kenlm_model
+    assert [lm.word(i) for i in st.state.words] == known["first"]["state"]["words"]
+    second = dec.decode_beams(x[7:], lm_start_state=st)
+    assert second[0].text == known["second"]["text"]
+    assert abs(second[0].lm_score - known["second"]["lm"]) < 1e-12
+    assert abs(second[0].logit_score - known["second"]["logit"]) < 1e-12
+    # public scorer methods (language_model.py:326-360) against the reference's known answers
+    ka = load_known()
+    lmod = dec._language_model
+    s0 = lmod.get_start_state()
+    sc, s1 = lmod.score(s0, "bugs")
+    assert sc == ka["lm_score"]["<s>->bugs"]
+    assert lmod.score(s1, "bunny", is_last_word=True)[0] == ka["lm_score"]["bugs->bunny(eos)"]
+    assert lmod.score(s1, "zzz")[0] == ka["lm_score"]["bugs->zzz"]
+    assert lmod.score(s0, "bunny")[0] == ka["lm_score"]["<s>->bunny"]
+    for part, val in ka["score_partial"].items():
+        assert lmod.score_partial_token(part) == val
+    from pyctcdecode_amd.language_model import HotwordScorer
+
+    hs = HotwordScorer.build_scorer(["bugs bunny", "bun"], 10.0)
+    for part, val in ka["hotword_partial"].items():
+        assert hs.score_partial_token(part) == val
+    for text, val in ka["hotword_text"].items():
+        assert hs.score(text) == val
