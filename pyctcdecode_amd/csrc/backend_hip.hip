@@ -484,6 +484,7 @@ struct GpuCtx {
   __device__ __forceinline__ int wave_width() { return 64; }
   __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
   __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
+  __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
   __device__ __forceinline__ void use(double x) { asm volatile("" ::"v"(x)); }
   __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)wall_clock64(); }
   __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {

@@ -329,13 +329,49 @@ struct BeamDecoder {
   CTC_HD uint32_t plen(const BeamSoA& b, int i) const { return b.meta1[i] >> 16; }
 
   // ---- completion of beam i's open word: the (text (+) partial) prefix ----------------------
+  // The LM state of the text node this thread will complete (beam tid), fetched at the start of the frame:
+  // the n-gram probes of the completion phase depend on it, so having it in registers by then turns two
+  // dependent memory round trips (node, then probes) into one (probes + the rest of the node together).
+  LmState pre_state;
+  bool pre_valid = false;
+
+  CTC_HD void prefetch_node(const BeamSoA& b) {
+    pre_valid = false;
+    const int i = ctx.tid;
+    if (tab.has_lm && i < N && plen(b, i) > 0 && b.comp_node[i] == 0) {
+      const TextNode& src = io.text_nodes[b.text_node[i]];
+      pre_state.len = src.state.len;
+#pragma unroll
+      for (int k = 0; k < MAX_CTX; ++k) {
+        pre_state.words[k] = src.state.words[k];
+        pre_state.backoff[k] = src.state.backoff[k];
+      }
+      pre_valid = true;
+    }
+  }
+
   CTC_HD void make_completion(const BeamSoA& b, int i) {
+    const TextNode& src = io.text_nodes[b.text_node[i]];
+    LmState st;
+    if (i == ctx.tid && pre_valid) {
+      st = pre_state;
+    } else {
+      st.len = src.state.len;
+#pragma unroll
+      for (int k = 0; k < MAX_CTX; ++k) {
+        st.words[k] = src.state.words[k];
+        st.backoff[k] = src.state.backoff[k];
+      }
+    }
+    make_completion_from(b, i, src, st);
+  }
+
+  CTC_HD void make_completion_from(const BeamSoA& b, int i, const TextNode& src, const LmState& src_state) {
     uint32_t idx = ctx.atomic_add(&L.scal[1], 1u);
     if (idx >= io.text_cap) {
       ctx.atomic_or(&L.scal[6], ST_TEXT_OVERFLOW);
       idx = io.text_cap - 1;
     }
-    const TextNode& src = io.text_nodes[b.text_node[i]];
     TextNode& dst = io.text_nodes[idx];
     const uint32_t m2 = b.meta2[i];
     double raw = src.raw_lm;
@@ -344,7 +380,7 @@ struct BeamDecoder {
       tick<11>();
     }
     if (tab.has_lm) {
-      float base = lm_base_score(tab, src.state, b.word_id[i], &dst.state);
+      float base = lm_base_score(tab, src_state, b.word_id[i], &dst.state);
       if (io.prof) {
         ctx.use((double)base);
         tick<12>();
@@ -548,14 +584,17 @@ struct BeamDecoder {
 
   // insert candidate q (keys already in ck_*); candidates of one label occupy `group` consecutive
   // indices and only merge with each other (the key contains last_char). Returns the representative.
-  CTC_HD uint32_t table_insert(uint32_t q, uint32_t group) {
+  CTC_HD uint32_t table_insert(uint32_t q, uint32_t group, uint32_t* my_slot = nullptr) {
     uint32_t mask = (uint32_t)(2 * shape.cand - 1);
     uint64_t kt = L.ck_text[q], kp = L.ck_part[q];
     uint32_t g = q / group;
     uint32_t slot = key_slot_hash(kt, kp, g) & mask;
     for (;;) {
       uint32_t old = ctx.atomic_cas(&L.table[slot], 0u, q + 1);
-      if (old == 0) return q;
+      if (old == 0) {
+        if (my_slot) *my_slot = slot;
+        return q;
+      }
       uint32_t r = old - 1;
       if (L.ck_text[r] == kt && L.ck_part[r] == kp && r / group == g) return r;
       slot = (slot + 1) & mask;
@@ -584,20 +623,21 @@ struct BeamDecoder {
     const uint32_t want = (uint32_t)prm.beam_width;
     if (n <= 256u) {
       for (uint32_t e = ctx.tid; e < n; e += ctx.nt) {
-        uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
-        uint32_t rank = 0;
+        const uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
+        uint32_t rank = 0, same = 0;
         uint32_t j = 0;
         for (; j + 4 <= n; j += 4) {  // four independent LDS reads in flight per step
           uint64_t x0 = L.s_k0[j], x1 = L.s_k0[j + 1], x2 = L.s_k0[j + 2], x3 = L.s_k0[j + 3];
-          uint64_t y0 = L.s_k1[j], y1 = L.s_k1[j + 1], y2 = L.s_k1[j + 2], y3 = L.s_k1[j + 3];
-          rank += ((x0 < a0) || (x0 == a0 && y0 < a1)) ? 1u : 0u;
-          rank += ((x1 < a0) || (x1 == a0 && y1 < a1)) ? 1u : 0u;
-          rank += ((x2 < a0) || (x2 == a0 && y2 < a1)) ? 1u : 0u;
-          rank += ((x3 < a0) || (x3 == a0 && y3 < a1)) ? 1u : 0u;
+          rank += (x0 < a0 ? 1u : 0u) + (x1 < a0 ? 1u : 0u) + (x2 < a0 ? 1u : 0u) + (x3 < a0 ? 1u : 0u);
+          same += (x0 == a0 ? 1u : 0u) + (x1 == a0 ? 1u : 0u) + (x2 == a0 ? 1u : 0u) + (x3 == a0 ? 1u : 0u);
         }
         for (; j < n; ++j) {
-          uint64_t b0 = L.s_k0[j], b1 = L.s_k1[j];
-          rank += ((b0 < a0) || (b0 == a0 && b1 < a1)) ? 1u : 0u;
+          const uint64_t x = L.s_k0[j];
+          rank += x < a0 ? 1u : 0u;
+          same += x == a0 ? 1u : 0u;
+        }
+        if (same > 1u) {  // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
+          for (j = 0; j < n; ++j) rank += (L.s_k0[j] == a0 && L.s_k1[j] < a1) ? 1u : 0u;
         }
         if (rank < want) {
           const uint32_t idx = (uint32_t)(a1 & 0xFFFFFFFFu);
@@ -780,7 +820,8 @@ struct BeamDecoder {
     double ps;
   };
   CTC_HD PartView new_partial(const BeamSoA& b, int i, uint32_t c, const TkView& tk, uint32_t br,
-                              uint64_t new_part_h) const {
+                              uint64_t new_part_h, bool have_pre, const PrefixEntry& pre_p,
+                              const HotEntry& pre_h) const {
     PartView v;
     if (br == 0) {  // blank / repeat: unchanged
       v.pl = plen(b, i);
@@ -804,8 +845,8 @@ struct BeamDecoder {
       uint64_t sp = hk & tab.prefix_mask, sh = hk & tab.hot_mask;
       PrefixEntry ep = {0, 0, 0};
       HotEntry eh = {0, 0, 0};
-      if (want_p) ep = tab.prefixes[sp];
-      if (want_h) eh = tab.hot[sh];
+      if (want_p) ep = have_pre ? pre_p : tab.prefixes[sp];
+      if (want_h) eh = have_pre ? pre_h : tab.hot[sh];
       bool on = false, hon = false;
       if (want_p) {
         while (ep.key != new_part_h && ep.key != 0) {
@@ -846,6 +887,11 @@ struct BeamDecoder {
     // conservative running threshold from the chunks already seen (nobody writes smax here)
     double thr_prev = sortable_to_max() + prm.beam_prune_logp;
     const uint64_t kth_key = L.smax[2];  // 0 until a pool prune has fixed a beam_width-th best
+    // first table probes of this thread's first candidate (the one it scores in S), issued here so that
+    // they are in flight across the merge phase
+    PrefixEntry pre_p = {0, 0, 0};
+    HotEntry pre_h = {0, 0, 0};
+    bool have_pre = false;
     // G1: keys
     for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
       uint32_t s = s0 + q / (uint32_t)N;
@@ -859,6 +905,13 @@ struct BeamDecoder {
         kp = br == BR_BOUNDARY ? tk.h_clean() : 0;
       } else if (br == BR_APPEND) {
         kp = str_concat(kp, tk.pow_raw(), tk.h_raw());
+        if (q == (uint32_t)ctx.tid && kp != 0) {
+          const uint32_t m2 = b.meta2[i];
+          const uint64_t hk = mix64(kp);
+          if ((m2 & PF_ON_TABLE) && tab.prefixes) pre_p = tab.prefixes[hk & tab.prefix_mask];
+          if ((m2 & M2_HOT_ON) && tab.hot) pre_h = tab.hot[hk & tab.hot_mask];
+          have_pre = true;
+        }
       }
       L.ck_text[q] = kt;
       L.ck_part[q] = kp;
@@ -870,8 +923,12 @@ struct BeamDecoder {
     ctx.sync();
     tick<3>();
     // G2: merge table (candidates of one label only ever merge with each other)
+    // (a chunk of at most one candidate per thread -- the usual case -- hands the table back clean without
+    // a sweep: each thread remembers the slot it filled and zeroes it once the merge phase is over)
+    const bool one_pass = Q <= (uint32_t)ctx.nt;
+    uint32_t my_slot = 0xFFFFFFFFu;
     for (uint32_t q = ctx.tid; q < Q; q += ctx.nt) {
-      uint32_t r = table_insert(q, (uint32_t)N);
+      uint32_t r = table_insert(q, (uint32_t)N, &my_slot);
       L.crep[q] = r;
       ctx.atomic_min(&L.rmin[r], q);
       ctx.atomic_max(&L.rmax[r], q);
@@ -881,6 +938,7 @@ struct BeamDecoder {
     tick<4>();
     // S: owners fold, score, push. The loop keeps every wave converged (uniform trip count) so the
     // running maximum is reduced inside the wave and published with ONE LDS atomic per wave.
+    if (one_pass && my_slot != 0xFFFFFFFFu) L.table[my_slot] = 0;
     for (uint32_t base = 0; base < Q; base += (uint32_t)ctx.nt) {
       const uint32_t q = base + (uint32_t)ctx.tid;
       uint64_t my_key = 0;  // below every real key
@@ -910,7 +968,7 @@ struct BeamDecoder {
           ctx.use(lg + lmhw);
           tick<14>();
         }
-        PartView pv = new_partial(b, i, c, tk, br, L.ck_part[q]);
+        PartView pv = new_partial(b, i, c, tk, br, L.ck_part[q], have_pre && base == 0, pre_p, pre_h);
         if (io.prof) {
           ctx.use(pv.ps);
           tick<15>();
@@ -928,8 +986,10 @@ struct BeamDecoder {
     }
     ctx.sync();
     tick<5>();
-    clear_table();
-    ctx.sync();
+    if (!one_pass) {
+      clear_table();
+      ctx.sync();
+    }
     tick<6>();
   }
 
@@ -1049,20 +1109,23 @@ struct BeamDecoder {
       L.smax[2] = 0;
     }
     tick<9>();
+    const BeamSoA b = beams_at(cur);
     uint32_t ns = load_survivors(t);
     ctx.sync();
+    prefetch_node(b);  // in flight while the first wave works out the branch modes
     tick<0>();
     compute_modes(ns);
     tick<1>();
-    const BeamSoA b = beams_at(cur);
     if (L.scal[4]) {
-      // TextNodes written in earlier frames are read here by other threads: make them visible
-      ctx.sync_mem();
-      tick<22>();
       for (int i = ctx.tid; i < N; i += ctx.nt)
         if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
+      // the TextNodes written here are read by other threads in later frames: the full barrier waits
+      // for the stores (the LDS-only one does not)
+      ctx.sync_mem();
+      tick<22>();
+    } else {
+      ctx.sync();
     }
-    ctx.sync();
     prefetch(t + 1);  // lands while this frame's candidates are processed
     tick<2>();
     // Labels are taken in chunks of whole labels (<= cand candidates). Before a chunk that might not fit
@@ -1109,15 +1172,21 @@ struct BeamDecoder {
       ctx.sync();
     }
     tick<20>();
-    for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
+    const uint32_t W = (uint32_t)ctx.wave_width();
+    const uint32_t lane = (uint32_t)ctx.tid & (W - 1u);
+    for (uint32_t base = 0; base < n; base += (uint32_t)ctx.nt) {  // uniform trip count: ballots inside
+      const uint32_t r = base + (uint32_t)ctx.tid;
       uint32_t dst = r;
-      uint32_t kept = 1u;
+      uint32_t kept = r < n ? 1u : 0u;
       if (hist) {
+        // position = kept entries before r: whole 64-blocks by ballot + popcount, own block by lane mask
+        const uint32_t wave0 = r - lane;
         dst = 0;
-        uint32_t r2 = 0;
-        for (; r2 + 4 <= r; r2 += 4) dst += L.keep[r2] + L.keep[r2 + 1] + L.keep[r2 + 2] + L.keep[r2 + 3];
-        for (; r2 < r; ++r2) dst += L.keep[r2];
-        kept = L.keep[r];
+        for (uint32_t j0 = 0; j0 < wave0; j0 += W)
+          dst += (uint32_t)ctx.popc64(ctx.ballot(j0 + lane < n && L.keep[j0 + lane] != 0u));
+        kept = (r < n && L.keep[r] != 0u) ? 1u : 0u;
+        const uint64_t mine = ctx.ballot(kept != 0u);
+        dst += (uint32_t)ctx.popc64(mine & ((1ull << lane) - 1ull));
       }
       if (r == n - 1) L.scal[7] = dst + kept;  // size of the next beam table
       if (kept) build_beam(nb, (int)dst, L.sel[r], frame);
@@ -1256,6 +1325,7 @@ struct BeamDecoder {
       L.smax[0] = asc_key(-INFINITY);
     }
     ctx.sync_mem();
+    pre_valid = false;
     if (fold) {
       for (int i = ctx.tid; i < N; i += ctx.nt)
         if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);

@@ -33,6 +33,7 @@ struct SeqCtx {
   int wave_width() { return 1; }
   uint64_t ballot(bool p) { return p ? 1ull : 0ull; }
   int clz64(uint64_t x) { return __builtin_clzll(x); }
+  int popc64(uint64_t x) { return __builtin_popcountll(x); }
   unsigned long long global_add(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 };
 
