@@ -40,6 +40,7 @@ enum ctcdec_dtype { CTCDEC_F32 = 0, CTCDEC_F64 = 1, CTCDEC_F16 = 2, CTCDEC_BF16 
 #define CTCDEC_MAX_BEAM_WIDTH 256
 #define CTCDEC_MAX_LM_ORDER 6
 #define CTCDEC_MAX_VOCAB 65535
+#define CTCDEC_MAX_LMS 4 /* language models in one MultiLanguageModel */
 
 /* Decode-time parameters: the keyword arguments of decode_beams (decoder.py:730-740) plus the
  * LM parameters that reset_params may change between calls (decoder.py:292-313,
@@ -90,6 +91,21 @@ int ctcdec_lm_set_unigrams(ctcdec_decoder* dec, int32_t has_unigrams, const char
  * LanguageModel object constructed on its own (language_model.py:237-269) and later handed to
  * BeamSearchDecoderCTC(alphabet, language_model) (decoder.py:275-290) is parsed only once. */
 int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src);
+
+/* Replaces MultiLanguageModel (language_model.py:455-502): `dst` scores every word with the n
+ * (2..CTCDEC_MAX_LMS) language models loaded into srcs[0..n) -- each from its own state, the scores
+ * averaged (language_model.py:483-502), partial words by the mean of the models' unigram-trie scores
+ * (:477-481), history pruning by the largest order (:467-469). Model 0 takes alpha / beta /
+ * unk_score_offset / lm_score_boundary from ctcdec_params like a single model; models 1.. take theirs
+ * from ctcdec_lm_set_params (each reference LanguageModel carries its own, language_model.py:266-269).
+ * With several models every "LM state" of the decode calls is n consecutive ctcdec_lm_state entries
+ * in model order: start_states holds n per utterance, ctcdec_result_lm_state_of reads model k's.
+ * Streaming (ctcdec_decode_stream_batch) is not available with several models (CTCDEC_ERR_LIMIT). */
+int ctcdec_lm_share_multi(ctcdec_decoder* dst, const ctcdec_decoder* const* srcs, int32_t n);
+int ctcdec_lm_set_params(ctcdec_decoder* dec, int32_t k /* 1..n-1 */, double alpha, double beta,
+                         double unk_score_offset, int32_t lm_score_boundary);
+/* number of language models behind the decoder (0: none) */
+int ctcdec_lm_count(const ctcdec_decoder* dec, int32_t* n_out);
 
 /* Unigram char-trie query: CharTrie.has_node (language_model.py:331) and set membership
  * (language_model.py:351).  flags_out: bit0 prefix of a unigram, bit1 LM vocabulary word,
@@ -163,6 +179,9 @@ int ctcdec_result_scores(const ctcdec_result* r, int32_t utt, int32_t beam, doub
 int ctcdec_result_frames(const ctcdec_result* r, int32_t utt, int32_t beam, int32_t* n_words,
                          const int32_t** word_off, const int32_t** start, const int32_t** end);
 int ctcdec_result_lm_state(const ctcdec_result* r, int32_t utt, int32_t beam, ctcdec_lm_state* out);
+/* several language models: the state of model k (k = 0 is ctcdec_result_lm_state) */
+int ctcdec_result_lm_state_of(const ctcdec_result* r, int32_t utt, int32_t beam, int32_t k,
+                              ctcdec_lm_state* out);
 /* Bulk view of a whole result (one call instead of four per beam): beams of utterance u are
  * [beam_off[u], beam_off[u+1]); beam k's text is text_blob[text_off[k] .. text_off[k+1]); its words
  * are [word_cnt_off[k], word_cnt_off[k+1]) in word_byte_off / word_start / word_end, where

@@ -235,6 +235,34 @@ class LMOracle:
         return self.alpha * lm * LOG_BASE_CHANGE_FACTOR + self.beta, end
 
 
+class MultiLMOracle:
+    """language_model.py:455-502: several LMOracles side by side; a state is the list of their states."""
+
+    def __init__(self, lms: Sequence[LMOracle]):
+        if len(lms) < 2:
+            raise ValueError("This class is meant to contain at least 2 language models.")
+        self.lms = list(lms)
+
+    @property
+    def order(self) -> int:
+        return max(lm.order for lm in self.lms)  # language_model.py:467-469
+
+    def start_state(self) -> List[ArpaState]:
+        return [lm.start_state() for lm in self.lms]
+
+    def score_partial(self, partial: str) -> float:
+        return float(np.mean([lm.score_partial(partial) for lm in self.lms]))  # language_model.py:477-481
+
+    def score(self, prev: List[ArpaState], word: str, is_last_word: bool) -> Tuple[float, List[ArpaState]]:
+        score = 0.0
+        end = []
+        for st, lm in zip(prev, self.lms):  # language_model.py:495-501
+            sc, e = lm.score(st, word, is_last_word)
+            score += sc
+            end.append(e)
+        return score / len(self.lms), end
+
+
 # --------------------------------------------------------------------------------------------
 # helpers
 # --------------------------------------------------------------------------------------------

@@ -90,6 +90,9 @@ _PROTOS = {
     "ctcdec_lm_set_unigrams": (C.c_int, [_VP, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
                                          C.POINTER(C.c_int64)]),
     "ctcdec_lm_share": (C.c_int, [_VP, _VP]),
+    "ctcdec_lm_share_multi": (C.c_int, [_VP, C.POINTER(_VP), C.c_int32]),
+    "ctcdec_lm_set_params": (C.c_int, [_VP, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32]),
+    "ctcdec_lm_count": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "ctcdec_lm_prefix_flags": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(C.c_uint32)]),
     "ctcdec_lm_word_index": (C.c_int, [_VP, C.c_char_p, C.c_int64, C.POINTER(C.c_uint32)]),
     "ctcdec_lm_word_string": (C.c_int, [_VP, C.c_uint32, C.POINTER(_VP), C.POINTER(C.c_int64)]),
@@ -110,6 +113,7 @@ _PROTOS = {
                                        C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
                                        C.POINTER(C.POINTER(C.c_int32))]),
     "ctcdec_result_lm_state": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(LmState)]),
+    "ctcdec_result_lm_state_of": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LmState)]),
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "ctcdec_result_free": (None, [_VP]),

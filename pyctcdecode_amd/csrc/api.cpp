@@ -81,6 +81,7 @@ struct BeamResult {
   std::vector<int32_t> word_off, start, end;
   double logit = 0, lm = 0;
   ctcdec_lm_state state;
+  std::vector<ctcdec_lm_state> xstates;  // MultiLanguageModel: states of model 1..
   // streaming extras (decoder.py:69-79 fields of the returned LMBeam)
   std::string partial;
   int32_t src = -1, last_char = -1, pstart = -1, pend = -1;
@@ -104,9 +105,17 @@ struct ctcdec_decoder {
   HostLM& lm_ref() { return *lm_ptr; }
   const HostLM& lm_ref() const { return *lm_ptr; }
   bool has_lm = false;
+  // MultiLanguageModel: lm_ptr is model 0, multi holds all of them plus the union tables
+  std::unique_ptr<HostMulti> multi;
+  double x_alpha[MAX_LMS] = {0}, x_beta[MAX_LMS] = {0}, x_unk[MAX_LMS] = {0};
+  int32_t x_boundary[MAX_LMS] = {0};
+  int n_lms() const { return multi ? (int)multi->lms.size() : 1; }
+  int hist_order() const { return multi ? multi->order : lm_ptr->order; }
   HostHotwords hot;
   bool tables_dirty = true, hot_dirty = true;
   DevBuf d_tok, d_tok_hot, d_uni, d_ngr, d_pref, d_hot;
+  DevBuf d_xuni[MAX_LMS - 1], d_xngr[MAX_LMS - 1], d_winfo[MAX_LMS], w_xstate;
+  HostBuf h_xstate;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
       w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff;
@@ -118,6 +127,13 @@ struct ctcdec_decoder {
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
                      &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff};
     for (DevBuf* b : all) b->drop();
+    for (int k = 0; k < MAX_LMS - 1; ++k) {
+      d_xuni[k].drop();
+      d_xngr[k].drop();
+    }
+    for (int k = 0; k < MAX_LMS; ++k) d_winfo[k].drop();
+    w_xstate.drop();
+    h_xstate.drop();
     h_tok.drop();
     h_out.drop();
     h_small.drop();
@@ -142,12 +158,21 @@ struct ctcdec_result {
 
 static int sync_tables(ctcdec_decoder* d, std::string* err) {
   if (d->tables_dirty) {
-    if (d->has_lm) d->lm_ref().fill_token_starts(&d->alpha);
+    if (d->multi) fill_token_starts_from(d->multi->prefix_table, d->multi->prefix_mask, &d->alpha);
+    else if (d->has_lm) d->lm_ref().fill_token_starts(&d->alpha);
     if (upload(d->d_tok, d->alpha.tok, err)) return -1;
     if (d->has_lm) {
       if (upload(d->d_uni, d->lm_ref().unigrams, err)) return -1;
       if (upload(d->d_ngr, d->lm_ref().ngram_table, err)) return -1;
-      if (upload(d->d_pref, d->lm_ref().prefix_table, err)) return -1;
+      if (upload(d->d_pref, d->multi ? d->multi->prefix_table : d->lm_ref().prefix_table, err)) return -1;
+    }
+    if (d->multi) {
+      for (int k = 0; k < d->n_lms(); ++k) {
+        if (upload(d->d_winfo[k], d->multi->winfo[(size_t)k], err)) return -1;
+        if (k > 0 && (upload(d->d_xuni[k - 1], d->multi->lms[(size_t)k]->unigrams, err) ||
+                      upload(d->d_xngr[k - 1], d->multi->lms[(size_t)k]->ngram_table, err)))
+          return -1;
+      }
     }
     d->tables_dirty = false;
     d->hot_dirty = true;
@@ -170,6 +195,28 @@ static void device_tables(const ctcdec_decoder* d, DeviceTables* t) {
     t->unigrams = (const UnigramEntry*)d->d_uni.p;
     t->ngrams = (const NgramEntry*)d->d_ngr.p;
     t->prefixes = (const PrefixEntry*)d->d_pref.p;
+    if (d->multi) {
+      t->prefix_mask = d->multi->prefix_mask;
+      t->n_lms = (uint32_t)d->n_lms();
+      t->n_hist = (uint32_t)std::max(1, d->multi->order - 1);
+      t->winfo0 = (const uint32_t*)d->d_winfo[0].p;
+      for (int k = 1; k < d->n_lms(); ++k) {
+        const HostLM& lm = *d->multi->lms[(size_t)k];
+        LmExtra& x = t->x[k - 1];
+        x.unigrams = (const UnigramEntry*)d->d_xuni[k - 1].p;
+        x.ngrams = (const NgramEntry*)d->d_xngr[k - 1].p;
+        x.ngram_mask = lm.ngram_mask;
+        x.winfo = (const uint32_t*)d->d_winfo[k].p;
+        x.lm_order = (uint32_t)lm.order;
+        x.has_trie = lm.has_trie ? 1u : 0u;
+        x.uniset_nonempty = lm.uniset_size > 0 ? 1u : 0u;
+        x.eos_id = lm.eos_id;
+        x.alpha = d->x_alpha[k];
+        x.beta = d->x_beta[k];
+        x.unk = d->x_unk[k];
+        x.score_boundary = d->x_boundary[k];
+      }
+    }
   } else {
     t->n_hist = 1;  // lm_order 1 without an LM (decoder.py:551)
   }
@@ -226,9 +273,44 @@ int ctcdec_lm_set_unigrams(ctcdec_decoder* dec, int32_t has_unigrams, const char
 
 int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src) {
   if (!dst || !src || !src->has_lm) return fail(CTCDEC_ERR_ARG, "source has no language model");
+  if (src->multi) return fail(CTCDEC_ERR_ARG, "source holds several language models");
   dst->lm_ptr = src->lm_ptr;
+  dst->multi.reset();
   dst->has_lm = true;
   dst->tables_dirty = true;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_share_multi(ctcdec_decoder* dst, const ctcdec_decoder* const* srcs, int32_t n) {
+  if (!dst || !srcs || n < 2) return fail(CTCDEC_ERR_ARG, "a MultiLanguageModel holds at least 2 language models");
+  if (n > CTCDEC_MAX_LMS) return fail(CTCDEC_ERR_LIMIT, "more language models than CTCDEC_MAX_LMS");
+  std::unique_ptr<HostMulti> m(new HostMulti());
+  for (int32_t k = 0; k < n; ++k) {
+    if (!srcs[k] || !srcs[k]->has_lm || srcs[k]->multi) return fail(CTCDEC_ERR_ARG, "source has no (single) language model");
+    m->lms.push_back(srcs[k]->lm_ptr);
+  }
+  m->build();
+  if (m->words.size() > WI_ID_MASK) return fail(CTCDEC_ERR_LIMIT, "union vocabulary too large");
+  dst->lm_ptr = m->lms[0];
+  dst->multi = std::move(m);
+  dst->has_lm = true;
+  dst->tables_dirty = true;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_set_params(ctcdec_decoder* dec, int32_t k, double alpha, double beta, double unk_score_offset,
+                         int32_t lm_score_boundary) {
+  if (!dec || !dec->multi || k < 1 || k >= dec->n_lms()) return fail(CTCDEC_ERR_ARG, "no such additional language model");
+  dec->x_alpha[k] = alpha;
+  dec->x_beta[k] = beta;
+  dec->x_unk[k] = unk_score_offset;
+  dec->x_boundary[k] = lm_score_boundary ? 1 : 0;
+  return CTCDEC_OK;
+}
+
+int ctcdec_lm_count(const ctcdec_decoder* dec, int32_t* n_out) {
+  if (!dec || !n_out) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  *n_out = dec->has_lm ? dec->n_lms() : 0;
   return CTCDEC_OK;
 }
 
@@ -377,7 +459,7 @@ static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, i
   if (in.text_end < in.text_begin || in.partial_end < in.partial_begin) return "bad beam text range";
   const char* t = st.text_blob + in.text_begin;
   const size_t tn = (size_t)(in.text_end - in.text_begin);
-  const uint32_t n_hist = dec->has_lm ? (uint32_t)std::max(1, dec->lm_ref().order - 1) : 1u;
+  const uint32_t n_hist = dec->has_lm ? (uint32_t)std::max(1, dec->hist_order() - 1) : 1u;
   uint64_t th = 0;
   std::vector<uint64_t> wh;
   uint32_t hw = 0;
@@ -408,12 +490,12 @@ static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, i
   if (pn > 0) {
     uint32_t fl = 0, w = 0;
     if (dec->has_lm && prefix_lookup(dec->lm_ref().prefix_table.data(), dec->lm_ref().prefix_mask, m->part_h, &w, &fl)) {
-      m2 |= PF_ON_TABLE | (fl & 7u);
+      m2 |= PF_ON_TABLE | (fl & PF_PARTIAL_MASK);
       wid = w;
     }
     uint32_t ml = 0, cp = 0;
     if (!dec->hot.table.empty() && hot_lookup(dec->hot.table.data(), dec->hot.mask, m->part_h, &ml, &cp))
-      m2 |= M2_HOT_ON | (cp ? M2_HOT_COMPLETE : 0u) | (ml << 8);
+      m2 |= M2_HOT_ON | (cp ? M2_HOT_COMPLETE : 0u) | ((ml & 0xFFFFu) << 8);
   }
   m->m2 = m2;
   m->word_id = wid;
@@ -453,6 +535,9 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     *out = res.release();
     return CTCDEC_OK;
   }
+  const int K = dec->has_lm ? dec->n_lms() : 1;
+  if (stream && K > 1)
+    return fail(CTCDEC_ERR_LIMIT, "streaming decode with a MultiLanguageModel is not supported");
   if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
@@ -494,7 +579,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   for (int32_t u = 0; u < n_utts; ++u) {
     uint64_t T = (uint64_t)utt_frames[u];
     uint64_t n_imp = stream ? (uint64_t)(stream->beam_off[u + 1] - stream->beam_off[u]) : 0;
-    toff[(size_t)u + 1] = toff[(size_t)u] + (T + 1) * (uint64_t)B + 2 + n_imp;
+    toff[(size_t)u + 1] = toff[(size_t)u] + ((T + 1) * (uint64_t)B + 2 + n_imp) * (uint64_t)K;
     eoff[(size_t)u + 1] = eoff[(size_t)u] + T * (uint64_t)B + 2 + n_imp;
   }
   int n_best = p->n_best > 0 ? std::min(p->n_best, B) : B;
@@ -530,33 +615,34 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   const LmState* d_start = nullptr;
   if (stream) {
     d_start = nullptr;  // every imported beam carries its own LM state
-  } else if (start_states && dec->has_lm) {
-    std::vector<LmState> st((size_t)n_utts);
+  } else if (dec->has_lm) {
+    // per utterance one state per model; a negative length (or no array) asks for the model's own default
+    std::vector<LmState> st((size_t)n_utts * K);
     for (int32_t u = 0; u < n_utts; ++u) {
-      LmState& s = st[(size_t)u];
-      memset(&s, 0, sizeof(s));
-      if (start_states[u].length < 0) {
-        dec->lm_ref().start_state(p->lm_score_boundary != 0, &s);
-      } else {
-        if (start_states[u].length > MAX_CTX) return fail(CTCDEC_ERR_ARG, "LM start state too long");
-        s.len = start_states[u].length;
-        for (int k = 0; k < s.len; ++k) {
-          if (start_states[u].words[k] >= dec->lm_ref().words.size()) return fail(CTCDEC_ERR_ARG, "bad LM state word");
-          s.words[k] = start_states[u].words[k];
-          s.backoff[k] = start_states[u].backoff[k];
+      for (int k = 0; k < K; ++k) {
+        LmState& s = st[(size_t)u * K + k];
+        memset(&s, 0, sizeof(s));
+        const HostLM& lm = K > 1 ? *dec->multi->lms[(size_t)k] : dec->lm_ref();
+        const ctcdec_lm_state* given = start_states ? &start_states[(size_t)u * K + k] : nullptr;
+        if (!given || given->length < 0) {
+          const bool boundary = k == 0 ? p->lm_score_boundary != 0 : dec->x_boundary[k] != 0;
+          lm.start_state(boundary, &s);
+        } else {
+          if (given->length > MAX_CTX) return fail(CTCDEC_ERR_ARG, "LM start state too long");
+          s.len = given->length;
+          for (int j = 0; j < s.len; ++j) {
+            if (given->words[j] >= lm.words.size()) return fail(CTCDEC_ERR_ARG, "bad LM state word");
+            s.words[j] = given->words[j];
+            s.backoff[j] = given->backoff[j];
+          }
         }
       }
     }
     if (upload(dec->w_start, st, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     d_start = (const LmState*)dec->w_start.p;
-  } else if (dec->has_lm) {
-    std::vector<LmState> st((size_t)n_utts);
-    LmState s0;
-    dec->lm_ref().start_state(p->lm_score_boundary != 0, &s0);
-    for (auto& s : st) s = s0;
-    if (upload(dec->w_start, st, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    d_start = (const LmState*)dec->w_start.p;
   }
+  const size_t xstate_bytes = K > 1 ? (size_t)n_utts * n_best * (size_t)(K - 1) * sizeof(LmState) : 0;
+  if (xstate_bytes && dec->w_xstate.ensure(xstate_bytes, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
   be::BeamArgs ba;
   device_tables(dec, &ba.tables);
@@ -586,6 +672,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.text_off = (const uint64_t*)dec->w_toff.p;
   ba.emit_off = (const uint64_t*)dec->w_eoff.p;
   ba.start_states = d_start;
+  ba.out_xstates = xstate_bytes ? (LmState*)dec->w_xstate.p : nullptr;
   ba.out = (OutBeam*)dec->w_out.p;
   ba.out_stride = n_best;
   ba.n_out = (uint32_t*)dec->w_nout.p;
@@ -677,6 +764,12 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   const EmitNode* toks = (const EmitNode*)dec->h_tok.p;
   if (head && be::d2h(dec->h_tok.p, dec->w_tok.p, (size_t)head * sizeof(EmitNode), &err))
     return fail(CTCDEC_ERR_DEVICE, err);
+  const LmState* xst = nullptr;
+  if (xstate_bytes) {
+    if (dec->h_xstate.ensure(xstate_bytes, &err) || be::d2h(dec->h_xstate.p, dec->w_xstate.p, xstate_bytes, &err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    xst = (const LmState*)dec->h_xstate.p;
+  }
   auto t_copy = std::chrono::steady_clock::now();
   be::last_timing(&res->ms[0], &res->ms[1]);
   if (dec->profile && be::d2h(dec->prof, dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
@@ -699,6 +792,17 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
         for (int j = 0; j < MAX_CTX; ++j) {
           r.state.words[j] = ob.state.words[j];
           r.state.backoff[j] = ob.state.backoff[j];
+        }
+        if (xst) {
+          r.xstates.resize((size_t)(K - 1));
+          for (int x = 0; x < K - 1; ++x) {
+            const LmState& xs = xst[((size_t)u * n_best + k) * (size_t)(K - 1) + x];
+            r.xstates[(size_t)x].length = xs.len;
+            for (int j = 0; j < MAX_CTX; ++j) {
+              r.xstates[(size_t)x].words[j] = xs.words[j];
+              r.xstates[(size_t)x].backoff[j] = xs.backoff[j];
+            }
+          }
         }
         r.last_char = ob.last_char == NO_CHAR ? -1 : (int32_t)ob.last_char;
         r.pstart = ob.pstart;
@@ -772,6 +876,17 @@ int ctcdec_result_lm_state(const ctcdec_result* r, int32_t utt, int32_t beam, ct
   const BeamResult* b = get_beam(r, utt, beam);
   if (!b) return fail(CTCDEC_ERR_ARG, "no such beam");
   *out = b->state;
+  return CTCDEC_OK;
+}
+int ctcdec_result_lm_state_of(const ctcdec_result* r, int32_t utt, int32_t beam, int32_t k, ctcdec_lm_state* out) {
+  const BeamResult* b = get_beam(r, utt, beam);
+  if (!b || !out) return fail(CTCDEC_ERR_ARG, "no such beam");
+  if (k == 0) {
+    *out = b->state;
+    return CTCDEC_OK;
+  }
+  if (k < 0 || (size_t)k > b->xstates.size()) return fail(CTCDEC_ERR_ARG, "no such language model");
+  *out = b->xstates[(size_t)k - 1];
   return CTCDEC_OK;
 }
 int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {

@@ -59,7 +59,8 @@ struct BeamArgs {
   EmitNode* emit_nodes;
   const uint64_t* text_off;  // [n_utts + 1] node offsets (device)
   const uint64_t* emit_off;  // [n_utts + 1]
-  const LmState* start_states;  // [n_utts] or nullptr
+  const LmState* start_states;  // [n_utts * max(1, tables.n_lms)] or nullptr
+  LmState* out_xstates;         // several LMs: [n_utts * out_stride * (n_lms - 1)], else nullptr
   OutBeam* out;                 // [n_utts * out_stride]
   int32_t out_stride;
   uint32_t* n_out;              // [n_utts]

@@ -492,7 +492,7 @@ struct GpuCtx {
   }
 };
 
-template <int BW, int NT>
+template <int BW, int NT, bool MULTI>
 __global__ __launch_bounds__(NT) void beam_decode(BeamArgs a, int surv_cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = blockIdx.x;
@@ -515,7 +515,9 @@ __global__ __launch_bounds__(NT) void beam_decode(BeamArgs a, int surv_cap) {
   io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
   io.emit_nodes = a.emit_nodes + a.emit_off[u];
   io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
-  io.start_state = a.start_states ? a.start_states + u : nullptr;
+  const uint32_t n_lms = MULTI ? a.tables.n_lms : 1u;
+  io.start_state = a.start_states ? a.start_states + (size_t)u * n_lms : nullptr;
+  io.out_xstates = (MULTI && a.out_xstates) ? a.out_xstates + (size_t)u * a.out_stride * (n_lms - 1) : nullptr;
   io.out = a.out + (size_t)u * a.out_stride;
   io.n_out = a.n_out + u;
   io.status = a.status + u;
@@ -527,24 +529,25 @@ __global__ __launch_bounds__(NT) void beam_decode(BeamArgs a, int surv_cap) {
   io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   GpuCtx ctx{(int)threadIdx.x, NT};
-  BeamDecoder<GpuCtx> dec(ctx, view, shape, a.tables, a.params, io);
+  BeamDecoder<GpuCtx, MULTI> dec(ctx, view, shape, a.tables, a.params, io);
   dec.run();
 }
 
-template <int BW, int NT>
+template <int BW, int NT, bool MULTI>
 static int launch_beam_t(const BeamArgs& a, const LdsShape& shape, size_t lds, std::string* err) {
-  HIP_TRY(hipFuncSetAttribute((const void*)beam_decode<BW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((beam_decode<BW, NT>), dim3((unsigned)a.n_utts), dim3(NT), lds, g_stream, a, shape.surv);
+  HIP_TRY(hipFuncSetAttribute((const void*)beam_decode<BW, NT, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds));
+  hipLaunchKernelGGL((beam_decode<BW, NT, MULTI>), dim3((unsigned)a.n_utts), dim3(NT), lds, g_stream, a, shape.surv);
   return 0;
 }
 
-template <int NT>
+template <int NT, bool MULTI>
 static int launch_beam_nt(const BeamArgs& a, const LdsShape& shape, size_t lds, std::string* err) {
   switch (shape.bw) {
-    case 32: return launch_beam_t<32, NT>(a, shape, lds, err);
-    case 64: return launch_beam_t<64, NT>(a, shape, lds, err);
-    case 128: return launch_beam_t<128, NT>(a, shape, lds, err);
-    default: return launch_beam_t<256, NT>(a, shape, lds, err);
+    case 32: return launch_beam_t<32, NT, MULTI>(a, shape, lds, err);
+    case 64: return launch_beam_t<64, NT, MULTI>(a, shape, lds, err);
+    case 128: return launch_beam_t<128, NT, MULTI>(a, shape, lds, err);
+    default: return launch_beam_t<256, NT, MULTI>(a, shape, lds, err);
   }
 }
 
@@ -564,8 +567,11 @@ int launch_beam(const BeamArgs& a, std::string* err) {
       int v = atoi(env);
       if (v == 64 || v == 128 || v == 256) nt = v;
     }
-    int rc = nt == 64 ? launch_beam_nt<64>(a, shape, lds, err)
-                      : nt == 128 ? launch_beam_nt<128>(a, shape, lds, err) : launch_beam_nt<256>(a, shape, lds, err);
+    int rc;
+    if (a.tables.n_lms > 1) rc = launch_beam_nt<256, true>(a, shape, lds, err);  // MultiLanguageModel
+    else
+      rc = nt == 64 ? launch_beam_nt<64, false>(a, shape, lds, err)
+                    : nt == 128 ? launch_beam_nt<128, false>(a, shape, lds, err) : launch_beam_nt<256, false>(a, shape, lds, err);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
   }

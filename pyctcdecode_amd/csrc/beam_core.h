@@ -204,7 +204,8 @@ struct UttIO {
   uint32_t text_cap;
   EmitNode* emit_nodes;
   uint32_t emit_cap;
-  const LmState* start_state;  // nullptr: LM default
+  const LmState* start_state;  // nullptr: LM default; several LMs: n_lms states
+  LmState* out_xstates;        // several LMs: [beam_width * (n_lms - 1)] states of LM 1.. per output beam
   OutBeam* out;                // [beam_width]
   uint32_t* n_out;
   uint32_t* status;
@@ -249,6 +250,19 @@ CTC_HD double partial_score(const DeviceTables& t, const DecodeParams& prm, uint
   bool on_trie = t.has_trie && (pf_flags & PF_UNI_PREFIX);
   double s = prm.unk * (on_trie ? 0.0 : 1.0);
   if (plen > 6) s = s * (double)plen / 6.0;
+  if (t.n_lms > 1) {  // MultiLanguageModel.score_partial_token: np.mean over the models (language_model.py:477-481)
+#pragma unroll
+    for (int k = 1; k < MAX_LMS; ++k) {
+      if ((uint32_t)k < t.n_lms) {
+        const LmExtra& x = t.x[k - 1];
+        const bool on_k = x.has_trie && (pf_flags & (1u << (PF_X_SHIFT + k)));
+        double sk = x.unk * (on_k ? 0.0 : 1.0);
+        if (plen > 6) sk = sk * (double)plen / 6.0;
+        s = s + sk;
+      }
+    }
+    s = s / (double)t.n_lms;
+  }
   return s;
 }
 
@@ -260,16 +274,24 @@ CTC_HD double total_score(const DeviceTables& t, double logit, double lm_hw, dou
 }
 
 // language_model.py:338-360 without the EOS term
+CTC_HD double lm_word_score_core(bool uniset_nonempty, double alpha, double beta, double unk, double log_base_change,
+                                 float base, bool uni_word, bool lm_word, double end_score, bool eos) {
+  double lm = (double)base;
+  bool oov = (uniset_nonempty && !uni_word) || !lm_word;
+  if (oov) lm += unk;
+  if (eos) lm = lm + end_score;
+  return alpha * lm * log_base_change + beta;
+}
 CTC_HD double lm_word_score(const DeviceTables& t, const DecodeParams& prm, float base, uint32_t wflags,
                             double end_score, bool eos) {
-  double lm = (double)base;
-  bool oov = (t.uniset_nonempty && !(wflags & PF_UNI_WORD)) || !(wflags & PF_LM_WORD);
-  if (oov) lm += prm.unk;
-  if (eos) lm = lm + end_score;
-  return prm.alpha * lm * prm.log_base_change + prm.beta;
+  return lm_word_score_core(t.uniset_nonempty != 0, prm.alpha, prm.beta, prm.unk, prm.log_base_change, base,
+                            (wflags & PF_UNI_WORD) != 0, (wflags & PF_LM_WORD) != 0, end_score, eos);
 }
 
-template <class Ctx>
+// MULTI: the language model is a MultiLanguageModel (2..MAX_LMS n-gram models, language_model.py:455-502).
+// A text then owns n_lms consecutive TextNodes: the first is the node proper, node k only carries model
+// k's state. Compile-time so that the single-model kernel contains none of it.
+template <class Ctx, bool MULTI = false>
 struct BeamDecoder {
   Ctx& ctx;
   LdsView& L;
@@ -366,11 +388,63 @@ struct BeamDecoder {
     make_completion_from(b, i, src, st);
   }
 
+  CTC_HD uint32_t node_span() const { return MULTI ? tab.n_lms : 1u; }
+
+  // One word under every model of a MultiLanguageModel: model k scores it from its own state in[k] and
+  // leaves its new state in out[k]; LanguageModel.score of each (language_model.py:338-360), averaged
+  // (:495-501). `uwid` indexes the union word list; each model maps it to its own vocabulary.
+  template <class GetIn, class PutOut>
+  CTC_HD double multi_word_score(uint32_t uwid, bool eos, GetIn get_in, PutOut put_out) const {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAX_LMS; ++k) {
+      if ((uint32_t)k < tab.n_lms) {
+        LmState in, out;
+        get_in(k, &in);
+        double sk;
+        if (k == 0) {
+          const uint32_t wi = tab.winfo0[uwid];
+          const float base = lm_base_score(tab, in, wi & WI_ID_MASK, &out);
+          double end = 0.0;
+          if (eos && prm.score_boundary) {
+            LmState tmp;
+            end = (double)lm_base_score(tab, out, tab.eos_id, &tmp);
+          }
+          sk = lm_word_score_core(tab.uniset_nonempty != 0, prm.alpha, prm.beta, prm.unk, prm.log_base_change, base,
+                                  (wi & WI_UNI_WORD) != 0, (wi & WI_LM_WORD) != 0, end, eos);
+        } else {
+          const LmExtra& x = tab.x[k > 0 ? k - 1 : 0];
+          const uint32_t wi = x.winfo[uwid];
+          const float base = lm_base_score(x, in, wi & WI_ID_MASK, &out);
+          double end = 0.0;
+          if (eos && x.score_boundary) {
+            LmState tmp;
+            end = (double)lm_base_score(x, out, x.eos_id, &tmp);
+          }
+          sk = lm_word_score_core(x.uniset_nonempty != 0, x.alpha, x.beta, x.unk, prm.log_base_change, base,
+                                  (wi & WI_UNI_WORD) != 0, (wi & WI_LM_WORD) != 0, end, eos);
+        }
+        put_out(k, out);
+        sum = sum + sk;
+      }
+    }
+    return sum / (double)tab.n_lms;
+  }
+
+  CTC_HD static void copy_state(LmState* d, const LmState& a) {
+    d->len = a.len;
+#pragma unroll
+    for (int k = 0; k < MAX_CTX; ++k) {
+      d->words[k] = a.words[k];
+      d->backoff[k] = a.backoff[k];
+    }
+  }
+
   CTC_HD void make_completion_from(const BeamSoA& b, int i, const TextNode& src, const LmState& src_state) {
-    uint32_t idx = ctx.atomic_add(&L.scal[1], 1u);
-    if (idx >= io.text_cap) {
+    uint32_t idx = ctx.atomic_add(&L.scal[1], node_span());
+    if (idx + node_span() > io.text_cap) {
       ctx.atomic_or(&L.scal[6], ST_TEXT_OVERFLOW);
-      idx = io.text_cap - 1;
+      idx = io.text_cap - node_span();
     }
     TextNode& dst = io.text_nodes[idx];
     const uint32_t m2 = b.meta2[i];
@@ -379,7 +453,17 @@ struct BeamDecoder {
       ctx.use(raw);
       tick<11>();
     }
-    if (tab.has_lm) {
+    if (MULTI) {
+      const TextNode* src_nodes = &src;
+      TextNode* dst_nodes = &dst;
+      raw = raw + multi_word_score(
+                      b.word_id[i], false,
+                      [&](int k, LmState* st) {
+                        if (k == 0) copy_state(st, src_state);
+                        else copy_state(st, src_nodes[k].state);
+                      },
+                      [&](int k, const LmState& st) { copy_state(&dst_nodes[k].state, st); });
+    } else if (tab.has_lm) {
       float base = lm_base_score(tab, src_state, b.word_id[i], &dst.state);
       if (io.prof) {
         ctx.use((double)base);
@@ -832,7 +916,7 @@ struct BeamDecoder {
       uint32_t hmin = tk.hot_min();
       uint32_t hcomp = tk.hot_complete();
       v.pl = tk.len_clean();
-      v.m2 = (tk.start_flags() & 0xFu) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
+      v.m2 = (tk.start_flags() & (PF_PARTIAL_MASK | PF_ON_TABLE)) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
       v.wid = tk.start_word_id();
       v.ps = partial_score(tab, prm, tk.start_flags(), hmin, v.pl);
     } else if (br == BR_APPEND) {
@@ -867,7 +951,7 @@ struct BeamDecoder {
         hcomp = eh.complete;
       }
       v.pl = plen(b, i) + tk.len_raw();
-      v.m2 = (on ? (PF_ON_TABLE | (pf & 7u)) : 0u) | (hon ? M2_HOT_ON : 0u) | ((hon && hcomp) ? M2_HOT_COMPLETE : 0u) |
+      v.m2 = (on ? (PF_ON_TABLE | (pf & PF_PARTIAL_MASK)) : 0u) | (hon ? M2_HOT_ON : 0u) | ((hon && hcomp) ? M2_HOT_COMPLETE : 0u) |
              ((hon ? hmin : 0u) << 8);
       v.wid = on ? nw : 0;
       v.ps = partial_score(tab, prm, on ? pf : 0u, hon ? hmin : 0u, v.pl);
@@ -1058,7 +1142,7 @@ struct BeamDecoder {
       depth += 1;
     }
     double ps = 0.0;
-    if (npl > 0) ps = partial_score(tab, prm, m2 & 7u, (m2 & M2_HOT_ON) ? (m2 >> 8) : 0u, npl);
+    if (npl > 0) ps = partial_score(tab, prm, m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
     nb.logit[dst] = L.p_logit[idx];
     nb.lm_hw[dst] = lmhw;
     nb.pscore[dst] = ps;
@@ -1202,7 +1286,7 @@ struct BeamDecoder {
   CTC_HD void init() {
     if (ctx.tid == 0) {
       for (int k = 0; k < 16; ++k) L.scal[k] = 0;
-      L.scal[1] = 1;  // text node 0 = empty text
+      L.scal[1] = node_span();  // text node 0 = empty text
       L.scal[2] = 1;  // emission node 0 = root
       TextNode root;
       root.text_h = 0;
@@ -1222,6 +1306,12 @@ struct BeamDecoder {
       if (io.start_state && io.start_state->len >= 0) st = *io.start_state;
       root.state = st;
       io.text_nodes[0] = root;
+      if (MULTI) {  // model k's start state rides in node k
+        for (uint32_t k = 1; k < tab.n_lms; ++k) {
+          root.state = io.start_state[k];
+          io.text_nodes[k] = root;
+        }
+      }
       EmitNode er;
       er.parent = 0;
       er.tok_branch = 0;
@@ -1290,7 +1380,7 @@ struct BeamDecoder {
       io.emit_nodes[1 + i] = en;
       b.logit[i] = m.logit_score;
       b.lm_hw[i] = lmhw;
-      b.pscore[i] = m.plen > 0 ? partial_score(tab, prm, m.m2 & 7u, (m.m2 & M2_HOT_ON) ? (m.m2 >> 8) : 0u, m.plen) : 0.0;
+      b.pscore[i] = m.plen > 0 ? partial_score(tab, prm, m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
       b.c_lm_hw[i] = 0.0;
       b.text_h[i] = m.text_h;
       b.part_h[i] = m.part_h;
@@ -1371,7 +1461,13 @@ struct BeamDecoder {
         if (eos) {
           const TextNode& src = io.text_nodes[b.text_node[d]];
           uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
-          if (tab.has_lm) {
+          if (MULTI) {
+            const TextNode* src_nodes = &src;
+            const double w = multi_word_score(
+                pl > 0 ? b.word_id[d] : 0u, true, [&](int k, LmState* st) { copy_state(st, src_nodes[k].state); },
+                [&](int, const LmState&) {});
+            lmhw = (src.raw_lm + w) + prm.hot_weight * (double)cnt;
+          } else if (tab.has_lm) {
             LmState end;
             uint32_t wid = pl > 0 ? b.word_id[d] : 0u;
             uint32_t wfl = pl > 0 ? m2 : 0u;
@@ -1448,6 +1544,19 @@ struct BeamDecoder {
         for (int k = 0; k < MAX_CTX; ++k) {
           ob.state.words[k] = 0;
           ob.state.backoff[k] = 0.f;
+        }
+      } else if (MULTI) {
+        // one state per model: LM 0 in the record, the others in the side array
+        LmState* xs = io.out_xstates + (size_t)r * (tab.n_lms - 1);
+        if (eos) {
+          const TextNode* src_nodes = &io.text_nodes[b.text_node[d]];
+          multi_word_score(
+              pl > 0 ? b.word_id[d] : 0u, false, [&](int k, LmState* st) { copy_state(st, src_nodes[k].state); },
+              [&](int k, const LmState& st) { copy_state(k == 0 ? &ob.state : &xs[k > 0 ? k - 1 : 0], st); });
+        } else {
+          const TextNode* nodes = &node;
+          copy_state(&ob.state, nodes[0].state);
+          for (uint32_t k = 1; k < tab.n_lms; ++k) copy_state(&xs[k - 1], nodes[k].state);
         }
       } else if (eos) {
         // last_lm_state: state after the last word, before </s> (language_model.py:357); an empty

@@ -90,9 +90,18 @@ enum : uint32_t {
 };
 struct PrefixEntry {  // 16 B
   uint64_t key;       // H(prefix bytes); never 0 for a stored prefix
-  uint32_t word_id;   // LM vocabulary index when PF_LM_WORD, else 0 (<unk>)
-  uint32_t flags;
+  uint32_t word_id;   // LM vocabulary index when PF_LM_WORD, else 0 (<unk>); several LMs: index into the
+                      // union word list (see LmExtra::winfo)
+  uint32_t flags;     // PF_* of LM 0; several LMs: PF_UNI_PREFIX of LM k >= 1 in bit PF_X_SHIFT + k
 };
+// MultiLanguageModel (language_model.py:455-502): up to MAX_LMS n-gram models scored side by side. The
+// per-frame state of a beam only needs each model's "is a unigram-trie prefix" bit; word identity and
+// the vocabulary flags of each model are looked up by union word index when a word is completed.
+constexpr int MAX_LMS = 4;
+constexpr uint32_t PF_X_SHIFT = 23u;                   // LM k's prefix bit = 1 << (PF_X_SHIFT + k), k = 1..3
+constexpr uint32_t PF_X_MASK = 0x07000000u;            // bits 24..26
+constexpr uint32_t PF_PARTIAL_MASK = PF_X_MASK | 7u;   // what a beam keeps of a table entry's flags
+constexpr uint32_t WI_LM_WORD = 0x80000000u, WI_UNI_WORD = 0x40000000u, WI_ID_MASK = 0x3FFFFFFFu;
 
 struct HotEntry {  // 16 B; every prefix of every hot-word unigram (language_model.py:133-150)
   uint64_t key;
@@ -185,6 +194,18 @@ struct ImportBeam {  // 160 B
   uint32_t pad;
 };
 
+// one additional language model of a MultiLanguageModel (LM 0 lives in DeviceTables / DecodeParams)
+struct LmExtra {
+  const UnigramEntry* unigrams;
+  const NgramEntry* ngrams;
+  uint64_t ngram_mask;
+  const uint32_t* winfo;  // union word index -> local word id | WI_* flags
+  uint32_t lm_order, has_trie, uniset_nonempty, eos_id;
+  double alpha, beta, unk;
+  int32_t score_boundary;
+  int32_t pad;
+};
+
 struct DeviceTables {
   const TokInfo* tok;
   const TokHot* tok_hot;
@@ -203,6 +224,10 @@ struct DeviceTables {
   uint32_t uniset_nonempty; // len(unigram_set) > 0       (language_model.py:350)
   uint32_t eos_id;          // vocabulary index of "</s>" (0 if absent)
   uint32_t n_hist;          // max(1, order-1)            (decoder.py:244)
+  uint32_t n_lms;           // 0/1: the single model above; 2..MAX_LMS: MultiLanguageModel
+  uint32_t pad_lms;
+  const uint32_t* winfo0;   // LM 0's view of the union word list (several LMs only)
+  LmExtra x[MAX_LMS - 1];   // LM 1..n_lms-1
 };
 
 struct DecodeParams {
@@ -281,7 +306,8 @@ CTC_HD uint64_t lm_key(const LmState& in, uint32_t wid) {
 }
 
 // finish the probe of one order: first entry `e` was loaded from slot `s`; walk on collisions (rare)
-CTC_HD bool lm_resolve(const DeviceTables& t, uint64_t key, uint64_t s, NgramEntry e, float* prob, float* bo) {
+template <class Tab>
+CTC_HD bool lm_resolve(const Tab& t, uint64_t key, uint64_t s, NgramEntry e, float* prob, float* bo) {
   while (e.key != key && e.key != 0) {
     s = (s + 1) & t.ngram_mask;
     e = t.ngrams[s];
@@ -292,7 +318,9 @@ CTC_HD bool lm_resolve(const DeviceTables& t, uint64_t key, uint64_t s, NgramEnt
   return true;
 }
 
-CTC_HD float lm_base_score(const DeviceTables& t, const LmState& in, uint32_t wid, LmState* out) {
+// Tab: DeviceTables (LM 0) or LmExtra (a further model): unigrams, ngrams, ngram_mask, lm_order
+template <class Tab>
+CTC_HD float lm_base_score(const Tab& t, const LmState& in, uint32_t wid, LmState* out) {
   const UnigramEntry u = t.unigrams[wid];
   const int in_len = in.len;
   const int max_n = !t.ngrams ? 1 : ((int)t.lm_order < in_len + 1 ? (int)t.lm_order : in_len + 1);

@@ -299,17 +299,69 @@ void HostLM::build_prefix_table() {
   }
 }
 
-void HostLM::fill_token_starts(HostAlphabet* alpha) const {
+void fill_token_starts_from(const std::vector<PrefixEntry>& table, uint64_t mask, HostAlphabet* alpha) {
   for (size_t i = 0; i < alpha->tok.size(); ++i) {
     TokInfo& t = alpha->tok[i];
     t.start_flags = 0;
     t.start_word_id = 0;
     uint32_t wid = 0, fl = 0;
-    if (t.len_clean > 0 && !prefix_table.empty() &&
-        prefix_lookup(prefix_table.data(), prefix_mask, t.h_clean, &wid, &fl)) {
+    if (t.len_clean > 0 && !table.empty() && prefix_lookup(table.data(), mask, t.h_clean, &wid, &fl)) {
       t.start_flags = fl | PF_ON_TABLE;
       t.start_word_id = wid;
     }
+  }
+}
+
+void HostLM::fill_token_starts(HostAlphabet* alpha) const { fill_token_starts_from(prefix_table, prefix_mask, alpha); }
+
+void HostMulti::build() {
+  const size_t K = lms.size();
+  std::unordered_map<std::string, uint32_t> uni;
+  words.assign(1, std::string());
+  order = 0;
+  for (const auto& lm : lms) {
+    order = std::max(order, lm->order);
+    for (uint32_t id = 1; id < lm->words.size(); ++id)
+      if (uni.emplace(lm->words[id], (uint32_t)words.size()).second) words.push_back(lm->words[id]);
+  }
+  winfo.assign(K, std::vector<uint32_t>(words.size(), 0u));
+  for (size_t k = 0; k < K; ++k) {
+    const HostLM& lm = *lms[k];
+    for (uint32_t id = 1; id < lm.words.size(); ++id)
+      winfo[k][uni[lm.words[id]]] = id | WI_LM_WORD | (lm.in_uniset[id] ? WI_UNI_WORD : 0u);
+  }
+  std::unordered_map<uint64_t, PrefixEntry> m;
+  m.reserve(words.size() * 6);
+  std::vector<size_t> bounds;
+  for (uint32_t u = 1; u < words.size(); ++u) {
+    const std::string& w = words[u];
+    uint32_t pbits = 0;  // models whose unigram set holds this word: their tries hold all its prefixes
+    for (size_t k = 0; k < K; ++k)
+      if (winfo[k][u] & WI_UNI_WORD) pbits |= k == 0 ? PF_UNI_PREFIX : (1u << (PF_X_SHIFT + (uint32_t)k));
+    utf8_boundaries(w.data(), w.size(), &bounds);
+    uint64_t h = 0;
+    size_t pos = 0;
+    for (size_t b : bounds) {
+      for (; pos < b; ++pos) h = addmod61(mulmod61(h, STR_BASE), (uint64_t)(unsigned char)w[pos] + 1);
+      PrefixEntry& e = m[h];
+      e.key = h;
+      e.flags |= pbits;
+      if (b == w.size()) {
+        e.word_id = u;
+        if (winfo[0][u] & WI_LM_WORD) e.flags |= PF_LM_WORD;
+        if (winfo[0][u] & WI_UNI_WORD) e.flags |= PF_UNI_WORD;
+      }
+    }
+  }
+  uint64_t size = 16;
+  while (size < 4 * m.size() + 1) size <<= 1;
+  prefix_table.assign(size, PrefixEntry{0, 0, 0});
+  prefix_mask = size - 1;
+  for (auto& kv : m) {
+    if (kv.first == 0) continue;
+    uint64_t s = mix64(kv.first) & prefix_mask;
+    while (prefix_table[s].key != 0) s = (s + 1) & prefix_mask;
+    prefix_table[s] = kv.second;
   }
 }
 
@@ -343,6 +395,7 @@ void HostHotwords::build(const std::vector<std::string>& uni, const HostAlphabet
   for (const std::string& w : uni) {
     if (w.empty()) continue;
     uint32_t wl = utf8_length(w.data(), w.size());
+    if (wl > 0xFFFFu) wl = 0xFFFFu;  // 16 bits in a beam's flag word
     utf8_boundaries(w.data(), w.size(), &bounds);
     uint64_t h = 0;
     size_t pos = 0;

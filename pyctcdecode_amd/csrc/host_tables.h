@@ -4,6 +4,7 @@
 // hot-word table (replaces HotwordScorer.build_scorer, language_model.py:152-189).
 // Pure C++ (no HIP): shared by the library (api.cpp) and the CPU simulator (tests/sim).
 #pragma once
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -49,6 +50,21 @@ struct HostLM {
   void fill_token_starts(HostAlphabet* alpha) const;
   void start_state(bool begin_sentence, LmState* out) const;
   void tables(DeviceTables* t) const;  // host pointers (for the host-side query)
+};
+
+// TokInfo.start_* of every label, looked up in a vocabulary prefix table
+void fill_token_starts_from(const std::vector<PrefixEntry>& table, uint64_t mask, HostAlphabet* alpha);
+
+// MultiLanguageModel (language_model.py:455-502): the union word list of the member models, each
+// model's view of it, and one prefix table that carries every model's unigram-trie bit.
+struct HostMulti {
+  std::vector<std::shared_ptr<HostLM>> lms;  // 2..MAX_LMS
+  std::vector<std::string> words;            // union index -> string; 0 = no word
+  std::vector<std::vector<uint32_t>> winfo;  // [lm][union index]: local id | WI_* flags
+  std::vector<PrefixEntry> prefix_table;
+  uint64_t prefix_mask = 0;
+  int order = 0;                             // max over the models (language_model.py:467-469)
+  void build();
 };
 
 struct HostHotwords {

@@ -38,6 +38,9 @@ from .language_model import (
     HotwordScorer,
     KenlmState,
     LanguageModel,
+    MAX_LANGUAGE_MODELS,
+    MultiLanguageModel,
+    MultiLanguageModelState,
     NgramModel,
     NgramState,
     _default_device,
@@ -211,12 +214,20 @@ class BeamSearchDecoderCTC:
         self._is_bpe = alphabet.is_bpe
         self._model_key = os.urandom(16)
         BeamSearchDecoderCTC.model_container[self._model_key] = language_model
-        if language_model is not None and not isinstance(language_model, LanguageModel):
+        members: List[LanguageModel] = []
+        if isinstance(language_model, MultiLanguageModel):
+            members = language_model.language_models
+            if len(members) > MAX_LANGUAGE_MODELS:
+                raise NotImplementedError("a MultiLanguageModel of more than %d models" % MAX_LANGUAGE_MODELS)
+        elif language_model is not None:
+            members = [language_model]
+        if not all(isinstance(m, LanguageModel) for m in members):
             raise NotImplementedError(
-                "only the n-gram LanguageModel can be lowered to the device trie; user-defined "
-                "AbstractLanguageModel subclasses and MultiLanguageModel are not supported "
+                "only n-gram LanguageModels (alone or inside a MultiLanguageModel) can be lowered to the "
+                "device trie; user-defined AbstractLanguageModel subclasses are not supported "
                 "(there is deliberately no CPU fallback)"
             )
+        self._members = members
         lib = B.get_library()
         self._lib = lib
         blob, off = B.pack_strings(self._alphabet.labels)
@@ -226,8 +237,11 @@ class BeamSearchDecoderCTC:
                                   _default_device(), C.byref(handle))
         )
         self._handle = handle
-        if language_model is not None:
-            lib.check(lib.dll.ctcdec_lm_share(handle, language_model._kenlm_model._handle))
+        if len(members) == 1:
+            lib.check(lib.dll.ctcdec_lm_share(handle, members[0]._kenlm_model._handle))
+        elif len(members) > 1:
+            srcs = (C.c_void_p * len(members))(*[m._kenlm_model._handle for m in members])
+            lib.check(lib.dll.ctcdec_lm_share_multi(handle, srcs, len(members)))
         self._hot_key: Optional[Tuple[str, ...]] = None
 
     def __del__(self):
@@ -295,7 +309,10 @@ class BeamSearchDecoderCTC:
         self._hot_key = key
 
     def _params(self, beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_weight, n_best) -> B.Params:
-        lm = self._language_model
+        lm = self._members[0] if self._members else None  # model 0; the others go through ctcdec_lm_set_params
+        for k, m in enumerate(self._members[1:], start=1):
+            self._lib.check(self._lib.dll.ctcdec_lm_set_params(
+                self._handle, k, float(m.alpha), float(m.beta), float(m.unk_score_offset), int(bool(m.score_boundary))))
         p = B.Params()
         p.beam_width = int(beam_width)
         p.prune_history = int(bool(prune_history))
@@ -320,15 +337,28 @@ class BeamSearchDecoderCTC:
         ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
         frames = (C.c_int32 * max(n, 1))(*batch.frames)
         st_arr = None
-        if start_states is not None and self._language_model is not None:
-            st_arr = (B.LmState * max(n, 1))()
+        n_lms = len(self._members)
+        if start_states is not None and n_lms > 0:
+            st_arr = (B.LmState * max(n * n_lms, 1))()
             for k, s in enumerate(start_states):
                 if s is None:
-                    st_arr[k].length = -1
+                    for j in range(n_lms):
+                        st_arr[k * n_lms + j].length = -1
+                    continue
+                if n_lms > 1:  # language_model.py:488-497
+                    if not isinstance(s, MultiLanguageModelState):
+                        raise AssertionError(
+                            f"Wrong input state type found. Expected MultiLanguageModelState, got {type(s)}")
+                    if len(s.states) != n_lms:
+                        raise AssertionError(
+                            f"Number of states ({len(s.states)}) does not match number of language models ({n_lms}).")
+                    parts = s.states
                 else:
-                    if not isinstance(s, KenlmState):
-                        raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(s)}")
-                    st_arr[k] = s.state.to_c()
+                    parts = [s]
+                for j, part in enumerate(parts):
+                    if not isinstance(part, KenlmState):
+                        raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(part)}")
+                    st_arr[k * n_lms + j] = part.state.to_c()
         res = C.c_void_p()
         self._lib.check(
             self._lib.dll.ctcdec_decode_batch(self._handle, ptrs, frames, n, batch.dtype, int(batch.is_device),
@@ -367,6 +397,14 @@ class BeamSearchDecoderCTC:
                 state = None
                 if with_state and has_lm:
                     state = KenlmState(NgramState.from_c(pk.lm_state[k]))
+                    if len(self._members) > 1:
+                        parts = [state]
+                        for j in range(1, len(self._members)):
+                            cst = B.LmState()
+                            self._lib.check(self._lib.dll.ctcdec_result_lm_state_of(
+                                res, u, k - int(beam_off[u]), j, C.byref(cst)))
+                            parts.append(KenlmState(NgramState.from_c(cst)))
+                        state = MultiLanguageModelState(parts)
                 beams.append(OutputBeam(text, state, frames, float(logit[k]), float(lm[k])))
             out.append(beams)
         return out
@@ -587,6 +625,8 @@ class BeamSearchDecoderCTC:
             blob, off = B.pack_strings(unigrams)
             self._lib.check(self._lib.dll.ctcdec_set_hotwords(self._handle, blob, B.off_ptr(off), len(unigrams)))
             self._hot_key = key
+        if len(self._members) > 1:
+            raise NotImplementedError("streaming decode with a MultiLanguageModel is not supported")
         has_lm = self._language_model is not None
         vocab2idx = self._vocab2idx
         pieces: List[bytes] = []

@@ -77,6 +77,17 @@ class KenlmState(AbstractLMState):
         return self._state
 
 
+class MultiLanguageModelState(AbstractLMState):
+    """language_model.py:56-64: one state per contained model."""
+
+    def __init__(self, states: List[AbstractLMState]) -> None:
+        self._states = states
+
+    @property
+    def states(self) -> List[AbstractLMState]:
+        return self._states
+
+
 class NgramModel:
     """The n-gram model inside libctcdec: what ``kenlm.Model(path)`` is to the reference
     (decoder.py:1074).  ARPA text only; kenlm binary files are not readable."""
@@ -440,3 +451,56 @@ class LanguageModel(AbstractLanguageModel):
             lm_score = lm_score + self._get_raw_end_score(end_state)
         lm_score = self.alpha * lm_score * LOG_BASE_CHANGE_FACTOR + self.beta
         return lm_score, KenlmState(end_state)
+
+
+MAX_LANGUAGE_MODELS = 4  # CTCDEC_MAX_LMS
+
+
+class MultiLanguageModel(AbstractLanguageModel):
+    """language_model.py:455-502: several n-gram LanguageModels scored side by side -- word scores
+    averaged, partial-word scores averaged, history pruning by the largest order.  The decode path runs
+    the same arithmetic on the device (ctcdec_lm_share_multi); the methods here serve the public API."""
+
+    def __init__(self, language_models: Sequence[AbstractLanguageModel]) -> None:
+        if len(language_models) < 2:
+            raise ValueError("This class is meant to contain at least 2 language models.")
+        self._language_models = list(language_models)
+
+    @property
+    def language_models(self) -> List[AbstractLanguageModel]:
+        return list(self._language_models)
+
+    @property
+    def order(self) -> int:
+        return max([lm.order for lm in self._language_models])
+
+    def get_start_state(self) -> MultiLanguageModelState:
+        return MultiLanguageModelState([lm.get_start_state() for lm in self._language_models])
+
+    def score_partial_token(self, partial_token: str) -> float:
+        scores = [lm.score_partial_token(partial_token) for lm in self._language_models]
+        total = 0.0
+        for sc in scores:
+            total += sc
+        return float(total / len(scores))
+
+    def score(
+        self, prev_state: AbstractLMState, word: str, is_last_word: bool = False
+    ) -> Tuple[float, MultiLanguageModelState]:
+        if not isinstance(prev_state, MultiLanguageModelState):
+            raise AssertionError(
+                f"Wrong input state type found. Expected MultiLanguageModelState, got {type(prev_state)}"
+            )
+        if len(prev_state.states) != len(self._language_models):
+            raise AssertionError(
+                f"Number of states ({len(prev_state.states)}) does not match number of language "
+                f"models ({len(self._language_models)})."
+            )
+        score = 0.0
+        end_state = []
+        for lm_prev_state, lm in zip(prev_state.states, self._language_models):
+            lm_score, lm_end_state = lm.score(lm_prev_state, word, is_last_word=is_last_word)
+            score += lm_score
+            end_state.append(lm_end_state)
+        score = score / len(self._language_models)
+        return score, MultiLanguageModelState(end_state)

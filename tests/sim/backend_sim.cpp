@@ -149,7 +149,9 @@ int launch_beam(const BeamArgs& a, std::string*) {
     io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
     io.emit_nodes = a.emit_nodes + a.emit_off[u];
     io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
-    io.start_state = a.start_states ? a.start_states + u : nullptr;
+    const uint32_t n_lms = a.tables.n_lms > 1 ? a.tables.n_lms : 1u;
+    io.start_state = a.start_states ? a.start_states + (size_t)u * n_lms : nullptr;
+    io.out_xstates = a.out_xstates ? a.out_xstates + (size_t)u * a.out_stride * (n_lms - 1) : nullptr;
     io.out = a.out + (size_t)u * a.out_stride;
     io.n_out = a.n_out + u;
     io.status = a.status + u;
@@ -161,8 +163,13 @@ int launch_beam(const BeamArgs& a, std::string*) {
     io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
     io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
     SeqCtx ctx;
-    BeamDecoder<SeqCtx> dec(ctx, view, shape, a.tables, a.params, io);
-    dec.run();
+    if (n_lms > 1) {
+      BeamDecoder<SeqCtx, true> dec(ctx, view, shape, a.tables, a.params, io);
+      dec.run();
+    } else {
+      BeamDecoder<SeqCtx, false> dec(ctx, view, shape, a.tables, a.params, io);
+      dec.run();
+    }
   }
   return 0;
 }

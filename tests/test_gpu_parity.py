@@ -313,3 +313,40 @@ def test_hip_probability_rows_overflowing_the_survivor_bound():
     got = dec.decode_beams(x, beam_width=20)
     exp = _oracle_expected(orc, x, {"beam_width": 20})
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="overflow")
+
+
+# ---- MultiLanguageModel (language_model.py:455-502) on the HIP path ---------------------------------
+from tests import test_multi_lm as _multi  # noqa: E402  (case loaders only; its own tests are not gpu-marked)
+
+
+@pytest.mark.parametrize("case", _multi.CASES, ids=[c["name"] for c in _multi.CASES])
+def test_hip_multi_lm_matches_reference_golden(case):
+    _loaded_native()
+    dec, lms = _multi.build_product_multi(case)
+    out = dec.decode_beams(_multi.INPUTS[case["input"]], **case["decode"])
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in out], case["expected"], tol=TOL,
+                what=case["name"])
+    for o, e in zip(out, case["expected"]):
+        for m, st, es in zip(lms, o.last_lm_state.states, e["states"]):
+            assert [m._kenlm_model.word(i) for i in st.state.words] == es["words"]
+
+
+def test_hip_multi_lm_vs_oracle_batch(lm, bpe):
+    """Two models of different order over the BPE-1024 vocabulary, a batch of word-like utterances."""
+    import torch
+
+    case = {"labels": bpe, "members": [{"lm": {"n_words": 300, "n_sent": 400, "order": 4, "seed": 2}},
+                                       {"lm": {"n_words": 200, "n_sent": 300, "order": 3, "seed": 3},
+                                        "build": {"alpha": 0.8, "beta": 1.0}}]}
+    dec, _ = _multi.build_product_multi(case)
+    orc = _multi.build_oracle_multi(case)
+    xs = [synth.d_words(4, u, 120, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0, space_label="|")
+          for u in range(6)]
+    hot = lm.hotwords(4, 1)
+    got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], prune_history=True, hotwords=hot)
+    for u, x in enumerate(xs):
+        exp = _oracle_expected(orc, x.astype(np.float64), {"prune_history": True, "hotwords": hot})
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL,
+                    what="multi%d" % u)
+    texts = dec.decode_batch(None, torch.from_numpy(np.stack(xs)).cuda(), hotwords=hot)
+    assert texts == [g[0].text for g in got]

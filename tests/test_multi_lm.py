@@ -1,0 +1,112 @@
+"""MultiLanguageModel (reference language_model.py:455-502): the oracle and the sequential-sim build of
+the device code against golden vectors the unmodified reference produced (oracle/make_golden_multi.py).
+The HIP build of the same path is checked in tests/test_gpu_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.arpa_lm import ArpaModel
+from oracle.ctc_oracle import LMOracle, MultiLMOracle, OracleDecoder, load_unigrams_from_arpa
+from pyctcdecode_amd.alphabet import Alphabet
+from tests.golden_util import GOLD, check_beams, lm_path
+from tests.sim_util import sim_library  # noqa: F401
+
+with open(os.path.join(GOLD, "cases_multi.json")) as _f:
+    _DATA = json.load(_f)
+CASES = _DATA["cases"]
+INPUTS = np.load(os.path.join(GOLD, "inputs_multi.npz"))
+
+
+def member_unigrams(member):
+    uni = member.get("unigrams", "auto")
+    if uni == "auto":
+        return sorted(load_unigrams_from_arpa(lm_path(member["lm"])))
+    return uni
+
+
+def build_oracle_multi(case):
+    alpha = Alphabet.build_alphabet(case["labels"])
+    lms = []
+    for m in case["members"]:
+        b = m.get("build", {})
+        lms.append(LMOracle(ArpaModel(lm_path(m["lm"])), member_unigrams(m), b.get("alpha", 0.5), b.get("beta", 1.5),
+                            b.get("unk_score_offset", -10.0), b.get("score_boundary", True)))
+    return OracleDecoder(alpha.labels, alpha.is_bpe, MultiLMOracle(lms))
+
+
+def build_product_multi(case):
+    from pyctcdecode_amd.decoder import BeamSearchDecoderCTC
+    from pyctcdecode_amd.language_model import LanguageModel, MultiLanguageModel, NgramModel
+
+    lms = [LanguageModel(NgramModel(lm_path(m["lm"])), member_unigrams(m), **m.get("build", {})) for m in case["members"]]
+    return BeamSearchDecoderCTC(Alphabet.build_alphabet(case["labels"]), MultiLanguageModel(lms)), lms
+
+
+def check_product_case(case):
+    dec, lms = build_product_multi(case)
+    out = dec.decode_beams(INPUTS[case["input"]], **case["decode"])
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in out], case["expected"], tol=1e-9,
+                what=case["name"])
+    for o, e in zip(out, case["expected"]):
+        assert len(o.last_lm_state.states) == len(lms)
+        for lm, st, es in zip(lms, o.last_lm_state.states, e["states"]):
+            assert [lm._kenlm_model.word(i) for i in st.state.words] == es["words"]
+            assert [float(np.float32(b)) for b in st.state.backoff] == es["backoff"]
+    return dec
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_multi_matches_reference_golden(case):
+    orc = build_oracle_multi(case)
+    with np.errstate(all="ignore"):
+        out = orc.decode_beams(INPUTS[case["input"]], **case["decode"])
+    check_beams([(o[0], o[2], o[3], o[4]) for o in out], case["expected"], what=case["name"])
+    for o, e in zip(out, case["expected"]):
+        for lm, st, es in zip(orc.lm.lms, o[1], e["states"]):
+            assert [lm.model.words[i] for i in st.words] == es["words"]
+            assert [float(b) for b in st.backoff] == es["backoff"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_sim_multi_matches_reference_golden(case, sim_library):  # noqa: F811
+    check_product_case(case)
+
+
+def test_sim_multi_stateful_and_batch(sim_library):  # noqa: F811
+    case = next(c for c in CASES if c["name"] == "toy_same_twice")
+    case2 = dict(case, members=[case["members"][0], dict(case["members"][0], build={"alpha": 1.0})])
+    dec, _ = build_product_multi(case2)
+    x = INPUTS[case["input"]]
+    first = dec.decode_beams(x[:5])
+    assert first[0].text == _DATA["stateful"]["first"]
+    second = dec.decode_beams(x[7:], lm_start_state=first[0].last_lm_state)
+    assert second[0].text == _DATA["stateful"]["second"]["text"]
+    assert abs(second[0].lm_score - _DATA["stateful"]["second"]["lm"]) < 1e-9
+    assert abs(second[0].logit_score - _DATA["stateful"]["second"]["logit"]) < 1e-9
+    # batch entry points share the path
+    texts = dec.decode_batch(None, [x, x[:5]])
+    assert texts[0] == dec.decode(x) and texts[1] == dec.decode(x[:5])
+    with pytest.raises(AssertionError):
+        dec.decode_beams(x, lm_start_state=first[0].last_lm_state.states[0])
+    with pytest.raises(NotImplementedError):
+        dec.partial_decode_beams(x, *dec.get_starting_state()[1:], dec.get_starting_state()[0], 0)
+
+
+def test_multi_public_scorer_matches_oracle(sim_library):  # noqa: F811
+    """MultiLanguageModel.score / score_partial_token (the public, host-side methods)."""
+    case = next(c for c in CASES if c["name"] == "libri_three_models_beams")
+    dec, lms = build_product_multi(case)
+    orc = build_oracle_multi(case)
+    mlm = dec._language_model
+    assert mlm.order == orc.lm.order == 4
+    st, ost = mlm.get_start_state(), orc.lm.start_state()
+    import synth
+
+    words = synth.make_words(300, seed=2)
+    for w in [words[3], words[10], "zzzz", words[7]]:
+        (s, st), (os_, ost) = mlm.score(st, w), orc.lm.score(ost, w, False)
+        assert abs(s - os_) < 1e-12
+    for p in ["a", words[5][:2], "qqqqqqqqq", words[8]]:
+        assert abs(mlm.score_partial_token(p) - orc.lm.score_partial(p)) < 1e-12
