@@ -157,6 +157,8 @@ typedef struct ctcdec_beam_in {
   int32_t reserved;
   int64_t text_begin, text_end;        /* byte range in text_blob */
   int64_t partial_begin, partial_end;  /* byte range in text_blob */
+  const ctcdec_lm_state* more_states;  /* several language models: the states of model 1.. (n-1 entries,
+                                          lm_state above being model 0's); NULL with a single model */
 } ctcdec_beam_in;
 int ctcdec_decode_stream_batch(ctcdec_decoder* dec, const void* const* utt_logits,
                                const int32_t* utt_frames, int32_t n_streams, int32_t dtype,

@@ -78,6 +78,7 @@ class BeamIn(C.Structure):
         ("text_end", C.c_int64),
         ("partial_begin", C.c_int64),
         ("partial_end", C.c_int64),
+        ("more_states", C.POINTER(LmState)),
     ]
 
 

@@ -114,7 +114,7 @@ struct ctcdec_decoder {
   HostHotwords hot;
   bool tables_dirty = true, hot_dirty = true;
   DevBuf d_tok, d_tok_hot, d_uni, d_ngr, d_pref, d_hot;
-  DevBuf d_xuni[MAX_LMS - 1], d_xngr[MAX_LMS - 1], d_winfo[MAX_LMS], w_xstate;
+  DevBuf d_xuni[MAX_LMS - 1], d_xngr[MAX_LMS - 1], d_winfo[MAX_LMS], w_xstate, w_impx;
   HostBuf h_xstate;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
@@ -133,6 +133,7 @@ struct ctcdec_decoder {
     }
     for (int k = 0; k < MAX_LMS; ++k) d_winfo[k].drop();
     w_xstate.drop();
+    w_impx.drop();
     h_xstate.drop();
     h_tok.drop();
     h_out.drop();
@@ -453,7 +454,8 @@ int ctcdec_decode_stream_batch(ctcdec_decoder* dec, const void* const* utt_logit
 // the beam row and its TextNode from this)
 static int64_t shape_bw_limit(int beam_width) { return beam_bucket(beam_width); }
 
-static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, int64_t k, int beam_width, ImportBeam* m) {
+static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, int64_t k, int beam_width, ImportBeam* m,
+                                LmState* more /* n_lms - 1 entries, or nullptr */) {
   const ctcdec_beam_in& in = st.beams[k];
   memset(m, 0, sizeof(*m));
   if (in.text_end < in.text_begin || in.partial_end < in.partial_begin) return "bad beam text range";
@@ -489,7 +491,9 @@ static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, i
   uint32_t m2 = 0, wid = 0;
   if (pn > 0) {
     uint32_t fl = 0, w = 0;
-    if (dec->has_lm && prefix_lookup(dec->lm_ref().prefix_table.data(), dec->lm_ref().prefix_mask, m->part_h, &w, &fl)) {
+    const std::vector<PrefixEntry>& ptab = dec->multi ? dec->multi->prefix_table : dec->lm_ref().prefix_table;
+    const uint64_t pmask = dec->multi ? dec->multi->prefix_mask : dec->lm_ref().prefix_mask;
+    if (dec->has_lm && prefix_lookup(ptab.data(), pmask, m->part_h, &w, &fl)) {
       m2 |= PF_ON_TABLE | (fl & PF_PARTIAL_MASK);
       wid = w;
     }
@@ -514,6 +518,21 @@ static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, i
       m->state.backoff[j] = in.lm_state.backoff[j];
     }
   }
+  if (dec->multi) {
+    if (!in.more_states) return "beam lacks the states of the further language models";
+    for (int x = 1; x < dec->n_lms(); ++x) {
+      const ctcdec_lm_state& g = in.more_states[x - 1];
+      LmState& o = more[x - 1];
+      memset(&o, 0, sizeof(o));
+      if (g.length < 0 || g.length > MAX_CTX) return "bad LM state in beam";
+      o.len = g.length;
+      for (int j = 0; j < o.len; ++j) {
+        if (g.words[j] >= dec->multi->lms[(size_t)x]->words.size()) return "bad LM state word in beam";
+        o.words[j] = g.words[j];
+        o.backoff[j] = g.backoff[j];
+      }
+    }
+  }
   (void)beam_width;
   return "";
 }
@@ -536,8 +555,6 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     return CTCDEC_OK;
   }
   const int K = dec->has_lm ? dec->n_lms() : 1;
-  if (stream && K > 1)
-    return fail(CTCDEC_ERR_LIMIT, "streaming decode with a MultiLanguageModel is not supported");
   if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
@@ -587,9 +604,11 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + 2 * (int64_t)n_utts);
   // streaming: carried-over beams of every stream
   const ImportBeam* d_imports = nullptr;
+  const LmState* d_import_x = nullptr;
   if (stream) {
     const int64_t n_imp_total = stream->beam_off[n_utts];
     std::vector<ImportBeam> imps((size_t)std::max<int64_t>(n_imp_total, 1));
+    std::vector<LmState> imps_x(K > 1 ? (size_t)std::max<int64_t>(n_imp_total, 1) * (size_t)(K - 1) : 0);
     std::vector<int64_t> ioff(stream->beam_off, stream->beam_off + n_utts + 1);
     std::vector<int32_t> ff(stream->first_frame, stream->first_frame + n_utts);
     for (int32_t u = 0; u < n_utts; ++u) {
@@ -597,13 +616,18 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       if (cnt < 1 || cnt > shape_bw_limit(B))
         return fail(CTCDEC_ERR_ARG, "a stream must carry between 1 and beam-capacity beams");
       for (int64_t k = ioff[(size_t)u]; k < ioff[(size_t)u + 1]; ++k) {
-        std::string e = build_import(dec, *stream, k, B, &imps[(size_t)k]);
+        std::string e = build_import(dec, *stream, k, B, &imps[(size_t)k],
+                                     K > 1 ? &imps_x[(size_t)k * (size_t)(K - 1)] : nullptr);
         if (!e.empty()) return fail(CTCDEC_ERR_ARG, e);
       }
     }
     if (upload(dec->w_imp, imps, &err) || upload(dec->w_impoff, ioff, &err) || upload(dec->w_ff, ff, &err))
       return fail(CTCDEC_ERR_DEVICE, err);
     d_imports = (const ImportBeam*)dec->w_imp.p;
+    if (K > 1) {
+      if (upload(dec->w_impx, imps_x, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      d_import_x = (const LmState*)dec->w_impx.p;
+    }
   }
   if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
       dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_toff, toff, &err) ||
@@ -682,6 +706,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.tok_pool_cap = tok_cap;
   ba.prof = nullptr;
   ba.imports = d_imports;
+  ba.import_xstates = d_import_x;
   ba.import_off = stream ? (const int64_t*)dec->w_impoff.p : nullptr;
   ba.first_frames = stream ? (const int32_t*)dec->w_ff.p : nullptr;
   if (dec->profile) {

@@ -70,6 +70,7 @@ struct BeamArgs {
   unsigned long long tok_pool_cap;
   unsigned long long* prof;  // [N_PROF] phase cycle counters of utterance 0, or nullptr
   const ImportBeam* imports;   // streaming: all utterances' carried-over beams, or nullptr
+  const LmState* import_xstates;  // several LMs: [total beams * (n_lms - 1)] their states of LM 1.., else nullptr
   const int64_t* import_off;   // [n_utts + 1] (device)
   const int32_t* first_frames; // [n_utts] processed_frames per utterance (device), or nullptr
 };

@@ -527,6 +527,7 @@ __global__ __launch_bounds__(NT) void beam_decode(BeamArgs a, int surv_cap) {
   io.prof = (u == 0) ? a.prof : nullptr;
   io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
   io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+    io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   GpuCtx ctx{(int)threadIdx.x, NT};
   BeamDecoder<GpuCtx, MULTI> dec(ctx, view, shape, a.tables, a.params, io);

@@ -214,6 +214,7 @@ struct UttIO {
   unsigned long long tok_pool_cap;
   unsigned long long* prof;  // optional per-phase cycle accumulators (diagnostics), else nullptr
   const ImportBeam* imports;  // streaming: the caller's live beams (rank order), else nullptr
+  const LmState* import_xstates;  // several LMs: [n_import * (n_lms - 1)] states of LM 1.. of those beams
   int32_t n_import;
   int32_t first_frame;        // processed_frames of this utterance (decoder.py:443)
 };
@@ -1306,7 +1307,7 @@ struct BeamDecoder {
       if (io.start_state && io.start_state->len >= 0) st = *io.start_state;
       root.state = st;
       io.text_nodes[0] = root;
-      if (MULTI) {  // model k's start state rides in node k
+      if (MULTI && io.start_state) {  // model k's start state rides in node k
         for (uint32_t k = 1; k < tab.n_lms; ++k) {
           root.state = io.start_state[k];
           io.text_nodes[k] = root;
@@ -1351,7 +1352,9 @@ struct BeamDecoder {
     const int n = io.n_import;
     for (int i = ctx.tid; i < n; i += ctx.nt) {
       const ImportBeam& m = io.imports[i];
-      TextNode& tn = io.text_nodes[1 + i];
+      const uint32_t span = node_span();
+      const uint32_t node = (1u + (uint32_t)i) * span;  // node 0 (.. span-1) is the empty text
+      TextNode& tn = io.text_nodes[node];
       tn.text_h = m.text_h;
       tn.raw_lm = m.raw_lm;
       const double lmhw = m.raw_lm + prm.hot_weight * (double)m.hw_cnt;
@@ -1372,6 +1375,11 @@ struct BeamDecoder {
         tn.state.words[k] = m.state.words[k];
         tn.state.backoff[k] = m.state.backoff[k];
       }
+      if (MULTI) {
+        TextNode* more = &tn;
+        for (uint32_t k = 1; k < span; ++k)
+          copy_state(&more[k].state, io.import_xstates[(size_t)i * (span - 1) + (k - 1)]);
+      }
       EmitNode en;
       en.parent = 0;
       en.tok_branch = (uint32_t)i | (BR_IMPORT << 16);
@@ -1387,7 +1395,7 @@ struct BeamDecoder {
       b.hist_h[i] = hh;
       b.c_text_h[i] = 0;
       b.c_hist_h[i] = 0;
-      b.text_node[i] = 1 + i;
+      b.text_node[i] = node;
       b.comp_node[i] = 0;
       b.emit_node[i] = 1 + i;
       b.word_id[i] = m.word_id;
@@ -1398,7 +1406,7 @@ struct BeamDecoder {
       b.pend[i] = m.pend;
     }
     if (ctx.tid == 0) {
-      L.scal[1] = 1 + (uint32_t)n;
+      L.scal[1] = (1 + (uint32_t)n) * node_span();
       L.scal[2] = 1 + (uint32_t)n;
     }
     ctx.sync_mem();

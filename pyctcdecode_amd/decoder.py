@@ -625,14 +625,14 @@ class BeamSearchDecoderCTC:
             blob, off = B.pack_strings(unigrams)
             self._lib.check(self._lib.dll.ctcdec_set_hotwords(self._handle, blob, B.off_ptr(off), len(unigrams)))
             self._hot_key = key
-        if len(self._members) > 1:
-            raise NotImplementedError("streaming decode with a MultiLanguageModel is not supported")
-        has_lm = self._language_model is not None
+        n_lms = len(self._members)
+        has_lm = n_lms > 0
         vocab2idx = self._vocab2idx
         pieces: List[bytes] = []
         pos = 0
         total = sum(len(b) for b in beams_list)
         arr = (B.BeamIn * max(total, 1))()
+        more = (B.LmState * max(total * (n_lms - 1), 1))() if n_lms > 1 else None  # model 1..'s states per beam
         beam_off = np.zeros(n + 1, dtype=np.int64)
         texts: List[List[str]] = []
         k = 0
@@ -649,6 +649,15 @@ class BeamSearchDecoderCTC:
                 e.logit_score = float(beam.logit_score)
                 if has_lm:
                     raw, state = self._memo_entry(cached_lm_scores_list[u], text)
+                    if n_lms > 1:
+                        if not isinstance(state, MultiLanguageModelState) or len(state.states) != n_lms:
+                            raise AssertionError(
+                                f"Wrong input state type found. Expected MultiLanguageModelState of {n_lms}, got {type(state)}")
+                        parts = state.states
+                        for j in range(1, n_lms):
+                            more[k * (n_lms - 1) + j - 1] = parts[j].state.to_c()
+                        e.more_states = C.cast(C.byref(more, k * (n_lms - 1) * C.sizeof(B.LmState)), C.POINTER(B.LmState))
+                        state = parts[0]
                     if not isinstance(state, KenlmState):
                         raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(state)}")
                     e.raw_lm_score = float(raw)
@@ -721,7 +730,16 @@ class BeamSearchDecoderCTC:
                                (int(ps[j]), int(pe[j])), float(logit[j]), float(lms[j]))
                     )
                     if has_lm and (text, False) not in memo:
-                        memo[(text, False)] = (float(raw[j]), float(raw[j]), KenlmState(NgramState.from_c(pk.lm_state[j])))
+                        state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[j]))
+                        if n_lms > 1:
+                            parts = [state]
+                            for x in range(1, n_lms):
+                                cst = B.LmState()
+                                self._lib.check(self._lib.dll.ctcdec_result_lm_state_of(
+                                    res, u, j - int(b_off[u]), x, C.byref(cst)))
+                                parts.append(KenlmState(NgramState.from_c(cst)))
+                            state = MultiLanguageModelState(parts)
+                        memo[(text, False)] = (float(raw[j]), float(raw[j]), state)
                 out.append(outs)
             return out
         finally:

@@ -161,6 +161,7 @@ int launch_beam(const BeamArgs& a, std::string*) {
     io.prof = nullptr;
     io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
     io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+    io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
     io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
     SeqCtx ctx;
     if (n_lms > 1) {

@@ -350,3 +350,9 @@ def test_hip_multi_lm_vs_oracle_batch(lm, bpe):
                     what="multi%d" % u)
     texts = dec.decode_batch(None, torch.from_numpy(np.stack(xs)).cuda(), hotwords=hot)
     assert texts == [g[0].text for g in got]
+
+
+@pytest.mark.parametrize("name", _multi.STREAM_CASES)
+def test_hip_multi_lm_streaming_equals_reference_golden(name):
+    _loaded_native()
+    _multi.check_chunked_case(name, TOL)

@@ -90,8 +90,34 @@ def test_sim_multi_stateful_and_batch(sim_library):  # noqa: F811
     assert texts[0] == dec.decode(x) and texts[1] == dec.decode(x[:5])
     with pytest.raises(AssertionError):
         dec.decode_beams(x, lm_start_state=first[0].last_lm_state.states[0])
-    with pytest.raises(NotImplementedError):
-        dec.partial_decode_beams(x, *dec.get_starting_state()[1:], dec.get_starting_state()[0], 0)
+
+
+STREAM_CASES = ["toy_alpha_mix", "libri_two_orders", "libri_three_models_beams", "bpe1023_two_models_hot"]
+
+
+@pytest.mark.parametrize("name", STREAM_CASES)
+def test_sim_multi_streaming_equals_whole(name, sim_library):  # noqa: F811
+    """partial_decode_beams in chunks (decoder.py:681-728) == decode_beams == the reference's golden beams."""
+    check_chunked_case(name, 1e-9)
+
+
+def check_chunked_case(name, tol):
+    from pyctcdecode_amd.language_model import HotwordScorer
+
+    case = next(c for c in CASES if c["name"] == name)
+    dec, _ = build_product_multi(case)
+    x = INPUTS[case["input"]]
+    kw = dict(case["decode"])
+    hot = kw.pop("hotwords", None)
+    if hot is not None:
+        kw["hotword_scorer"] = HotwordScorer.build_scorer(hot, weight=kw.pop("hotword_weight", 10.0))
+    T = x.shape[0]
+    cuts = [0, T // 3, T // 3 + 1, (2 * T) // 3, T]
+    beams, c1, c2 = dec.get_starting_state()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        beams = dec.partial_decode_beams(x[a:b], c1, c2, beams, a, is_end=(b == T), **kw)
+    got = [(bm.text, list(zip(bm.text.split(), bm.text_frames)), bm.logit_score, bm.lm_score) for bm in beams]
+    check_beams(got, case["expected"], tol=tol, what=name + "/chunked")
 
 
 def test_multi_public_scorer_matches_oracle(sim_library):  # noqa: F811
