@@ -81,6 +81,13 @@ void ctcdec_destroy(ctcdec_decoder* dec);
  * trie and upload it.  order_out receives the n-gram order (LanguageModel.order). */
 int ctcdec_lm_load_arpa(ctcdec_decoder* dec, const char* path, int32_t* order_out);
 
+/* The parsed model as one flat file (vocabulary, unigram array and the hashed n-gram table in upload
+ * layout): what a kenlm binary is to an ARPA file (language_model.py:424 accepts .bin/.binary next to
+ * .arpa) -- loading is a few reads instead of a parse.  kenlm's own binary formats are NOT readable
+ * (out of scope); convert once from the ARPA file with ctcdec_lm_save_flat. */
+int ctcdec_lm_save_flat(const ctcdec_decoder* dec, const char* path);
+int ctcdec_lm_load_flat(ctcdec_decoder* dec, const char* path, int32_t* order_out);
+
 /* Replaces LanguageModel.__init__'s unigram handling (language_model.py:257-265, :87-103):
  * unigrams given as a UTF-8 blob + offsets; has_unigrams=0 means "unigrams is None" (no trie).
  * Words not in the LM vocabulary are dropped (language_model.py:95).  n_kept_out: |unigram_set|. */

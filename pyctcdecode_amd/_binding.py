@@ -88,6 +88,8 @@ _PROTOS = {
     "ctcdec_create": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "ctcdec_destroy": (None, [_VP]),
     "ctcdec_lm_load_arpa": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int32)]),
+    "ctcdec_lm_save_flat": (C.c_int, [_VP, C.c_char_p]),
+    "ctcdec_lm_load_flat": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int32)]),
     "ctcdec_lm_set_unigrams": (C.c_int, [_VP, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
                                          C.POINTER(C.c_int64)]),
     "ctcdec_lm_share": (C.c_int, [_VP, _VP]),

@@ -245,6 +245,82 @@ std::string HostLM::load_arpa(const std::string& path) {
   return "";
 }
 
+// ---- flat model file: "CTCDLM01" | order, n_words, bos, eos (u32) | n_ngrams, table_size, blob_bytes (u64)
+//      | word end offsets u64[n_words] | word bytes | UnigramEntry[n_words] | NgramEntry[table_size] | "CTCDEND1"
+static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '1'};
+static const char kCacheEnd[8] = {'C', 'T', 'C', 'D', 'E', 'N', 'D', '1'};
+
+std::string HostLM::save_cache(const std::string& path) const {
+  if (order <= 0) return "no language model loaded";
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return "cannot write " + path;
+  bool ok = fwrite(kCacheMagic, 1, 8, f) == 8;
+  const uint32_t h32[4] = {(uint32_t)order, (uint32_t)words.size(), bos_id, eos_id};
+  std::vector<uint64_t> ends(words.size());
+  uint64_t blob = 0;
+  for (size_t i = 0; i < words.size(); ++i) ends[i] = (blob += words[i].size());
+  const uint64_t h64[3] = {(uint64_t)n_ngrams, (uint64_t)ngram_table.size(), blob};
+  ok = ok && fwrite(h32, 4, 4, f) == 4 && fwrite(h64, 8, 3, f) == 3;
+  ok = ok && fwrite(ends.data(), 8, ends.size(), f) == ends.size();
+  for (const std::string& w : words) ok = ok && (w.empty() || fwrite(w.data(), 1, w.size(), f) == w.size());
+  ok = ok && fwrite(unigrams.data(), sizeof(UnigramEntry), unigrams.size(), f) == unigrams.size();
+  ok = ok && fwrite(ngram_table.data(), sizeof(NgramEntry), ngram_table.size(), f) == ngram_table.size();
+  ok = ok && fwrite(kCacheEnd, 1, 8, f) == 8;
+  ok = (fclose(f) == 0) && ok;
+  return ok ? "" : "short write to " + path;
+}
+
+std::string HostLM::load_cache(const std::string& path) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return "cannot open LM file " + path;
+  auto bad = [&](const std::string& why) {
+    fclose(f);
+    return "not a usable ctcdec model file (" + why + "): " + path;
+  };
+  char magic[8];
+  uint32_t h32[4];
+  uint64_t h64[3];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kCacheMagic, 8) != 0) return bad("magic");
+  if (fread(h32, 4, 4, f) != 4 || fread(h64, 8, 3, f) != 3) return bad("header");
+  const uint64_t nw = h32[1], tsize = h64[1], blob = h64[2];
+  if (h32[0] < 1 || h32[0] > (uint32_t)(MAX_CTX + 1)) return bad("order");
+  if (nw < 1 || nw > WI_ID_MASK || h32[2] >= nw || h32[3] >= nw) return bad("vocabulary");
+  if (tsize < 16 || (tsize & (tsize - 1)) != 0 || h64[0] >= tsize) return bad("table size");
+  std::vector<uint64_t> ends(nw);
+  if (fread(ends.data(), 8, nw, f) != nw || ends[nw - 1] != blob) return bad("word offsets");
+  std::string bytes(blob, '\0');
+  if (blob && fread(&bytes[0], 1, blob, f) != blob) return bad("word bytes");
+  std::vector<UnigramEntry> uni(nw);
+  std::vector<NgramEntry> tab(tsize);
+  if (fread(uni.data(), sizeof(UnigramEntry), nw, f) != nw || fread(tab.data(), sizeof(NgramEntry), tsize, f) != tsize)
+    return bad("tables");
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kCacheEnd, 8) != 0) return bad("truncated");
+  fclose(f);
+  words.assign(nw, std::string());
+  vocab.clear();
+  vocab.reserve(nw * 2);
+  uint64_t a = 0;
+  for (uint64_t i = 0; i < nw; ++i) {
+    if (ends[i] < a || ends[i] > blob) return "corrupt word offsets in " + path;
+    words[i].assign(bytes, a, ends[i] - a);
+    a = ends[i];
+    if (i > 0) vocab.emplace(words[i], (uint32_t)i);
+  }
+  vocab["<unk>"] = 0;
+  order = (int)h32[0];
+  bos_id = h32[2];
+  eos_id = h32[3];
+  n_ngrams = h64[0];
+  unigrams.swap(uni);
+  ngram_table.swap(tab);
+  ngram_mask = tsize - 1;
+  in_uniset.assign(words.size(), 0);
+  has_trie = false;
+  uniset_size = 0;
+  build_prefix_table();
+  return "";
+}
+
 uint32_t HostLM::index(const std::string& w) const {
   auto it = vocab.find(w);
   return it == vocab.end() ? 0u : it->second;

@@ -44,6 +44,10 @@ struct HostLM {
 
   // returns "" on success, else an error message
   std::string load_arpa(const std::string& path);
+  // The parsed model as one flat file (vocabulary, unigram array, hashed n-gram table exactly as they
+  // are uploaded): loading it is a few freads instead of an ARPA parse.  Same return convention.
+  std::string save_cache(const std::string& path) const;
+  std::string load_cache(const std::string& path);
   uint32_t index(const std::string& w) const;  // 0 for OOV and for "<unk>"
   void set_unigrams(bool has, const std::vector<std::string>& unigrams);
   void build_prefix_table();

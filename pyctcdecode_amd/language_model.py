@@ -90,16 +90,21 @@ class MultiLanguageModelState(AbstractLMState):
 
 class NgramModel:
     """The n-gram model inside libctcdec: what ``kenlm.Model(path)`` is to the reference
-    (decoder.py:1074).  ARPA text only; kenlm binary files are not readable."""
+    (decoder.py:1074).  Reads ARPA text and its own flat model files (``*.ctcdec``, written by
+    :meth:`save_flat`: the ARPA file parsed once, loading is a few reads -- the role a kenlm binary plays
+    for the reference); kenlm's binary formats themselves are not readable."""
+
+    FLAT_SUFFIX = ".ctcdec"
 
     def __init__(self, path: str):
         lib = B.get_library()
         self._lib = lib
         self.path = path.encode("utf-8")
-        if not path.endswith(".arpa"):
+        flat = path.endswith(self.FLAT_SUFFIX)
+        if not flat and not path.endswith(".arpa"):
             raise NotImplementedError(
-                "only ARPA text models are supported by the device trie builder; got %r "
-                "(kenlm binary formats are not readable)" % path
+                "only ARPA text models (and their %s conversions) are supported by the device trie builder; "
+                "got %r (kenlm binary formats are not readable)" % (self.FLAT_SUFFIX, path)
             )
         blob, off = B.pack_strings([""])
         handle = C.c_void_p()
@@ -107,7 +112,8 @@ class NgramModel:
         self._handle = handle
         order = C.c_int32()
         try:
-            lib.check(lib.dll.ctcdec_lm_load_arpa(handle, self.path, C.byref(order)))
+            load = lib.dll.ctcdec_lm_load_flat if flat else lib.dll.ctcdec_lm_load_arpa
+            lib.check(load(handle, self.path, C.byref(order)))
         except Exception:
             lib.dll.ctcdec_destroy(handle)
             self._handle = None
@@ -121,6 +127,13 @@ class NgramModel:
                 self._lib.dll.ctcdec_destroy(h)
             except Exception:  # pragma: no cover - interpreter shutdown
                 pass
+
+    def save_flat(self, path: str) -> None:
+        """Write the parsed model as one flat file; ``NgramModel(path)`` / ``build_ctcdecoder(labels, path,
+        unigrams)`` load it without parsing (the name must end in ``.ctcdec``)."""
+        if not path.endswith(self.FLAT_SUFFIX):
+            raise ValueError("flat model files are named *%s" % self.FLAT_SUFFIX)
+        self._lib.check(self._lib.dll.ctcdec_lm_save_flat(self._handle, path.encode("utf-8")))
 
     def index(self, word: str) -> int:
         w = word.encode("utf-8")
@@ -375,7 +388,7 @@ class LanguageModel(AbstractLanguageModel):
                 raise ValueError(f"did not find {what} file in files: {contents}")
             contents.remove(needed)
         kenlm_file = contents[0]
-        if os.path.splitext(kenlm_file)[1] not in {".arpa", ".bin", ".binary"}:
+        if os.path.splitext(kenlm_file)[1] not in {".arpa", ".bin", ".binary", NgramModel.FLAT_SUFFIX}:
             raise ValueError(f"Explected kenlm file to end in `.arpa` or `.bin(ary)`. Found {kenlm_file}")
         return {
             "json_attrs": os.path.join(filepath, LanguageModel._ATTRS_SERIALIZED_FILENAME),
