@@ -100,6 +100,7 @@ struct LdsView {
   LPtr<uint32_t> p_wid, p_m2;  // prefix/hot-word view of the candidate's new partial word
   // sort buffer (aliases the candidate arrays)
   LPtr<uint64_t> s_k0, s_k1;
+  LPtr<uint64_t> s_hk;  // folded history-prune key of the first 256 compacted entries (small-set ranking)
   // scalars
   LPtr<uint32_t> scal;  // [0] pool_n [1] text_next [2] emit_next [3] flag [4] need_comp [5] n_sel [6] status [7] n_new [8] tok_len
   LPtr<uint64_t> smax;  // [0] sortable max score [1] token pool base [2] sortable score of the beam_width-th best so far
@@ -161,8 +162,10 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.keep = lds_take<uint32_t>(p, 4 * s.bw);
   o.sel = lds_take<uint32_t>(p, 4 * s.bw);
   o.part = lds_take<uint32_t>(p, 4 * 64);
-  o.hk_h = lds_take<uint64_t>(p, 8 * s.bw);
-  o.hk_p = lds_take<uint64_t>(p, 8 * s.bw);
+  // one block: the two key arrays of the large-set path, or the 256 folded keys of the small-set path
+  o.s_hk = lds_take<uint64_t>(p, 8 * (2 * s.bw > 256 ? 2 * s.bw : 256));
+  o.hk_h.p = o.s_hk.p;
+  o.hk_p.p = o.s_hk.p + s.bw;
   o.hk_c = lds_take<uint32_t>(p, 4 * s.bw);
   // candidate arrays and the sort buffer share one region
   lds_bytes_t shared0 = p;
@@ -304,6 +307,8 @@ struct BeamDecoder {
   int N;    // live beams
   uint32_t pf_cnt = 0, pf_id = 0;  // survivors of the NEXT frame, fetched one frame ahead
   double pf_lp = 0.0;
+  bool pf_live = false;
+  TokLite pf_tok;                  // ... and the label constants of this thread's survivor
   unsigned long long t_last = 0;
   unsigned long long t_acc[N_PROF] = {};
 
@@ -560,12 +565,43 @@ struct BeamDecoder {
 
   // issue the loads of frame t's survivor list; they are consumed by load_survivors(t) one frame later
   CTC_HD void prefetch(int t) {
-    if (t >= io.T) return;
+    pf_live = t < io.T;
+    if (!pf_live) return;
     pf_cnt = io.surv_cnt[t];
     if (ctx.tid < prm.max_surv) {
       pf_id = io.surv_id[(size_t)t * prm.max_surv + ctx.tid];
       pf_lp = io.surv_lp[(size_t)t * prm.max_surv + ctx.tid];
     }
+  }
+
+  // second stage of the prefetch, issued later in the frame when the ids above have landed: the label
+  // constants of the next frame's first TOK_STAGE survivors (their address depends on the id)
+  CTC_HD void prefetch_tok() {
+    if (!pf_live || ctx.tid >= TOK_STAGE || (uint32_t)ctx.tid >= pf_cnt) return;
+    const TokInfo& g = tab.tok[pf_id];
+    pf_tok.h_raw = g.h_raw;
+    pf_tok.pow_raw = g.pow_raw;
+    pf_tok.h_clean = g.h_clean;
+    pf_tok.len_raw = g.len_raw;
+    pf_tok.len_clean = g.len_clean;
+    pf_tok.flags = g.flags;
+    pf_tok.start_flags = g.start_flags;
+    pf_tok.start_word_id = g.start_word_id;
+    pf_tok.hot_min = tab.tok_hot ? tab.tok_hot[pf_id].min_len : 0u;
+    pf_tok.hot_complete = tab.tok_hot ? tab.tok_hot[pf_id].complete : 0u;
+  }
+
+  CTC_HD void store_tok(uint32_t s) {  // survivor slot s <- the prefetched constants of this thread's label
+    L.stok[s].h_raw = pf_tok.h_raw;
+    L.stok[s].pow_raw = pf_tok.pow_raw;
+    L.stok[s].h_clean = pf_tok.h_clean;
+    L.stok[s].len_raw = pf_tok.len_raw;
+    L.stok[s].len_clean = pf_tok.len_clean;
+    L.stok[s].flags = pf_tok.flags;
+    L.stok[s].start_flags = pf_tok.start_flags;
+    L.stok[s].start_word_id = pf_tok.start_word_id;
+    L.stok[s].hot_min = pf_tok.hot_min;
+    L.stok[s].hot_complete = pf_tok.hot_complete;
   }
 
   CTC_HD uint32_t load_survivors(int t) {
@@ -575,7 +611,7 @@ struct BeamDecoder {
     if ((uint32_t)ctx.tid < ns) {
       L.surv[ctx.tid].id = pf_id;
       L.surv[ctx.tid].lp = pf_lp;
-      if (ctx.tid < TOK_STAGE) stage_tok((uint32_t)ctx.tid, pf_id);
+      if (ctx.tid < TOK_STAGE) store_tok((uint32_t)ctx.tid);
     }
     for (uint32_t s = ctx.tid + ctx.nt; s < ns; s += ctx.nt) {
       uint32_t id = ids[s];
@@ -700,6 +736,14 @@ struct BeamDecoder {
         uint32_t pos = ctx.atomic_add(&L.scal[5], 1u);
         L.s_k0[pos] = score_sort_key(sc);
         L.s_k1[pos] = ((uint64_t)L.p_arr[k] << 32) | k;
+        if (with_hist && pos < 256u) {
+          // (history, partial, last_char) folded to 64 bits: equality of the folds stands in for equality of
+          // the triple (its members are 61/64-bit string hashes already)
+          uint64_t hh, ph;
+          uint32_t cc;
+          hist_key(k, &hh, &ph, &cc);
+          L.s_hk[pos] = mix64(hh ^ mix64(ph + 0x9E3779B97F4A7C15ull * (uint64_t)(cc + 1u)));
+        }
       }
     }
     ctx.sync();
@@ -709,33 +753,50 @@ struct BeamDecoder {
     if (n <= 256u) {
       for (uint32_t e = ctx.tid; e < n; e += ctx.nt) {
         const uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
-        uint32_t rank = 0, same = 0;
+        uint32_t rank = 0, same = 0, dup = 0;
         uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {  // four independent LDS reads in flight per step
-          uint64_t x0 = L.s_k0[j], x1 = L.s_k0[j + 1], x2 = L.s_k0[j + 2], x3 = L.s_k0[j + 3];
-          rank += (x0 < a0 ? 1u : 0u) + (x1 < a0 ? 1u : 0u) + (x2 < a0 ? 1u : 0u) + (x3 < a0 ? 1u : 0u);
-          same += (x0 == a0 ? 1u : 0u) + (x1 == a0 ? 1u : 0u) + (x2 == a0 ? 1u : 0u) + (x3 == a0 ? 1u : 0u);
-        }
-        for (; j < n; ++j) {
-          const uint64_t x = L.s_k0[j];
-          rank += x < a0 ? 1u : 0u;
-          same += x == a0 ? 1u : 0u;
-        }
-        if (same > 1u) {  // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
-          for (j = 0; j < n; ++j) rank += (L.s_k0[j] == a0 && L.s_k1[j] < a1) ? 1u : 0u;
+        if (with_hist) {
+          // history prune in the same sweep: an entry is dropped when a better-ranked one has the same
+          // (history, partial, last_char) -- first in sorted order wins (decoder.py:248-257)
+          const uint64_t ah = L.s_hk[e];
+          for (; j + 2 <= n; j += 2) {
+            const uint64_t x0 = L.s_k0[j], x1 = L.s_k0[j + 1];
+            const uint64_t h0 = L.s_hk[j], h1 = L.s_hk[j + 1];
+            rank += (x0 < a0 ? 1u : 0u) + (x1 < a0 ? 1u : 0u);
+            same += (x0 == a0 ? 1u : 0u) + (x1 == a0 ? 1u : 0u);
+            dup |= ((x0 < a0 && h0 == ah) ? 1u : 0u) | ((x1 < a0 && h1 == ah) ? 1u : 0u);
+          }
+          for (; j < n; ++j) {
+            const uint64_t x = L.s_k0[j];
+            rank += x < a0 ? 1u : 0u;
+            same += x == a0 ? 1u : 0u;
+            dup |= (x < a0 && L.s_hk[j] == ah) ? 1u : 0u;
+          }
+          if (same > 1u) {  // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
+            for (j = 0; j < n; ++j) {
+              const bool before = L.s_k0[j] == a0 && L.s_k1[j] < a1;
+              rank += before ? 1u : 0u;
+              dup |= (before && L.s_hk[j] == ah) ? 1u : 0u;
+            }
+          }
+        } else {
+          for (; j + 4 <= n; j += 4) {  // four independent LDS reads in flight per step
+            uint64_t x0 = L.s_k0[j], x1 = L.s_k0[j + 1], x2 = L.s_k0[j + 2], x3 = L.s_k0[j + 3];
+            rank += (x0 < a0 ? 1u : 0u) + (x1 < a0 ? 1u : 0u) + (x2 < a0 ? 1u : 0u) + (x3 < a0 ? 1u : 0u);
+            same += (x0 == a0 ? 1u : 0u) + (x1 == a0 ? 1u : 0u) + (x2 == a0 ? 1u : 0u) + (x3 == a0 ? 1u : 0u);
+          }
+          for (; j < n; ++j) {
+            const uint64_t x = L.s_k0[j];
+            rank += x < a0 ? 1u : 0u;
+            same += x == a0 ? 1u : 0u;
+          }
+          if (same > 1u) {
+            for (j = 0; j < n; ++j) rank += (L.s_k0[j] == a0 && L.s_k1[j] < a1) ? 1u : 0u;
+          }
         }
         if (rank < want) {
-          const uint32_t idx = (uint32_t)(a1 & 0xFFFFFFFFu);
-          L.sel[rank] = idx;
-          L.keep[rank] = 1u;
-          if (with_hist) {
-            uint64_t hh, ph;
-            uint32_t cc;
-            hist_key(idx, &hh, &ph, &cc);
-            L.hk_h[rank] = hh;
-            L.hk_p[rank] = ph;
-            L.hk_c[rank] = cc;
-          }
+          L.sel[rank] = (uint32_t)(a1 & 0xFFFFFFFFu);
+          L.keep[rank] = dup ? 0u : 1u;
         }
       }
       ctx.sync();
@@ -1223,6 +1284,7 @@ struct BeamDecoder {
       if (L.scal[0] + (s1 - s0) * (uint32_t)N > (uint32_t)shape.pool) prune_pool();
       process_chunk(s0, s1, frame);
     }
+    prefetch_tok();
     finish_frame(frame, false);
   }
 
@@ -1233,6 +1295,7 @@ struct BeamDecoder {
     const bool hist = prm.prune_history && !final_stage;
     uint32_t n = sort_pool(pool_n, thr, hist);
     tick<7>();
+    const bool big_set = n > 256u;  // ranked by the bucket selection: history keys still to be compared
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     const BeamSoA nb = beams_at(cur ^ 1);
     if (final_stage) {
@@ -1240,7 +1303,7 @@ struct BeamDecoder {
       ctx.sync();
       return;
     }
-    if (hist) {
+    if (hist && big_set) {  // (small sets: already done by the ranking sweep)
       // first of each (history, partial, last_char) in sorted order wins (decoder.py:248-257).
       // The r2 < r pair space is tiled 16 x 16 over the threads so that no thread walks a whole row.
       const uint32_t ta = (uint32_t)ctx.tid >> 4, tb = (uint32_t)ctx.tid & 15u;
@@ -1607,6 +1670,7 @@ struct BeamDecoder {
     init();
     if (io.prof && ctx.tid == 0) t_last = ctx.clock();
     prefetch(0);
+    prefetch_tok();
     for (int t = 0; t < io.T; ++t) step(t);
     tick<9>();
     finalise();
