@@ -626,6 +626,36 @@ struct BeamDecoder {
   // decoder.py:442,474-482 threads through the labels in iteration order; each label acts on the flag
   // as identity / clear / set, so the flag seen by label s is that of the last non-identity label
   // before it: one ballot pair per 64 labels instead of a serial walk.
+  // One block of <= wave-width BPE labels, one per lane of the first wave: flags `fl` / id `c` of this lane's
+  // label (TK_BLANK when the lane has none). Returns the lane's mode word; f = running force_next_break flag.
+  CTC_HD uint32_t mode_block(const BeamSoA& b, uint32_t lane, uint32_t fl, uint32_t c, uint32_t& f, bool& need) {
+    uint32_t first = (uint32_t)N;
+    bool any = false;
+    if (!(fl & TK_BLANK)) {
+      int i = 0;
+      while (i < N && last_char(b, i) == c) ++i;  // first beam that does not repeat the label
+      first = (uint32_t)i;
+      any = i < N;
+    }
+    const bool lead = (fl & TK_LEAD) != 0, trail = (fl & TK_TRAIL) != 0, blank = (fl & TK_BLANK) != 0;
+    // effect on the flag: lead label with a taker -> set to `trail`; other label with a taker and no
+    // trailing mark -> clear; everything else -> identity
+    const bool sets = !blank && any && lead && trail;
+    const bool clears = !blank && any && ((lead && !trail) || (!lead && !trail));
+    const uint64_t m_one = ctx.ballot(sets);
+    const uint64_t m_set = m_one | ctx.ballot(clears);
+    const uint64_t prior = m_set & ((lane >= 64u) ? ~0ull : ((1ull << lane) - 1ull));
+    uint32_t f_in = f;
+    if (prior) f_in = (uint32_t)((m_one >> (63 - ctx.clz64(prior))) & 1ull);
+    uint32_t mode = MODE_D;
+    if (blank) mode = MODE_A;
+    else if (lead) mode = MODE_ALL_B;
+    else if (f_in && any) mode = trail ? MODE_ALL_B : MODE_FIRST_B;
+    need = need || (ctx.ballot(!blank && any && mode != MODE_D) != 0ull);
+    if (m_set) f = (uint32_t)((m_one >> (63 - ctx.clz64(m_set))) & 1ull);
+    return mode | (first << 8);
+  }
+
   CTC_HD void compute_modes(uint32_t ns) {
     const BeamSoA b = beams_at(cur);
     if (!tab.is_bpe) {
@@ -645,39 +675,46 @@ struct BeamDecoder {
       bool need = false;
       for (uint32_t base = 0; base < ns; base += W) {
         const uint32_t s = base + lane;
-        uint32_t fl = TK_BLANK, first = (uint32_t)N;
-        bool any = false;
-        if (s < ns) {
-          fl = tok_of(s).flags();
-          if (!(fl & TK_BLANK)) {
-            const uint32_t c = L.surv[s].id;
-            int i = 0;
-            while (i < N && last_char(b, i) == c) ++i;  // first beam that does not repeat the label
-            first = (uint32_t)i;
-            any = i < N;
-          }
-        }
-        const bool lead = (fl & TK_LEAD) != 0, trail = (fl & TK_TRAIL) != 0, blank = (fl & TK_BLANK) != 0;
-        // effect on the flag: lead label with a taker -> set to `trail`; other label with a taker and no
-        // trailing mark -> clear; everything else -> identity
-        const bool sets = !blank && any && lead && trail;
-        const bool clears = !blank && any && ((lead && !trail) || (!lead && !trail));
-        const uint64_t m_one = ctx.ballot(sets);
-        const uint64_t m_set = m_one | ctx.ballot(clears);
-        const uint64_t prior = m_set & ((lane >= 64u) ? ~0ull : ((1ull << lane) - 1ull));
-        uint32_t f_in = f;
-        if (prior) f_in = (uint32_t)((m_one >> (63 - ctx.clz64(prior))) & 1ull);
-        uint32_t mode = MODE_D;
-        if (blank) mode = MODE_A;
-        else if (lead) mode = MODE_ALL_B;
-        else if (f_in && any) mode = trail ? MODE_ALL_B : MODE_FIRST_B;
-        if (s < ns) L.surv[s].mode = mode | (first << 8);
-        need = need || (ctx.ballot(!blank && any && mode != MODE_D) != 0ull);
-        if (m_set) f = (uint32_t)((m_one >> (63 - ctx.clz64(m_set))) & 1ull);
+        const uint32_t fl = s < ns ? tok_of(s).flags() : (uint32_t)TK_BLANK;
+        const uint32_t c = s < ns ? L.surv[s].id : 0u;
+        const uint32_t mw = mode_block(b, lane, fl, c, f, need);
+        if (s < ns) L.surv[s].mode = mw;
       }
       if (lane == 0) {
         L.scal[3] = f;
         if (need) L.scal[4] = 1u;
+      }
+    }
+    ctx.sync();
+  }
+
+  // The usual frame (no more survivors than one wave has lanes, all of them staged): the first wave writes
+  // the survivor list AND works out the modes from the prefetched registers -- one phase, one barrier.
+  CTC_HD void load_survivors_and_modes(uint32_t ns) {
+    const BeamSoA b = beams_at(cur);
+    if ((uint32_t)ctx.tid < (uint32_t)ctx.wave_width()) {
+      const uint32_t lane = (uint32_t)ctx.tid;
+      const bool mine = lane < ns;
+      const uint32_t fl = mine ? pf_tok.flags : (uint32_t)TK_BLANK;
+      uint32_t mw;
+      if (!tab.is_bpe) {
+        const uint32_t mode = (fl & TK_BLANK) ? MODE_A : ((fl & TK_SPACE) ? MODE_C : MODE_D);
+        if (mine && mode == MODE_C) L.scal[4] = 1u;
+        mw = mode | ((uint32_t)N << 8);
+      } else {
+        uint32_t f = L.scal[3];
+        bool need = false;
+        mw = mode_block(b, lane, fl, pf_id, f, need);
+        if (lane == 0) {
+          L.scal[3] = f;
+          if (need) L.scal[4] = 1u;
+        }
+      }
+      if (mine) {
+        L.surv[lane].id = pf_id;
+        L.surv[lane].lp = pf_lp;
+        L.surv[lane].mode = mw;
+        store_tok(lane);
       }
     }
     ctx.sync();
@@ -1256,11 +1293,17 @@ struct BeamDecoder {
     }
     tick<9>();
     const BeamSoA b = beams_at(cur);
-    uint32_t ns = load_survivors(t);
-    ctx.sync();
     prefetch_node(b);  // in flight while the first wave works out the branch modes
-    tick<0>();
-    compute_modes(ns);
+    const uint32_t ns = pf_cnt;
+    if (ns <= (uint32_t)ctx.wave_width() && ns <= (uint32_t)TOK_STAGE) {
+      load_survivors_and_modes(ns);
+      tick<0>();
+    } else {
+      load_survivors(t);
+      ctx.sync();
+      tick<0>();
+      compute_modes(ns);
+    }
     tick<1>();
     if (L.scal[4]) {
       for (int i = ctx.tid; i < N; i += ctx.nt)
