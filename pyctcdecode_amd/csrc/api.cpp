@@ -798,6 +798,10 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     return fail(CTCDEC_ERR_DEVICE, err);
   auto t_kernel = std::chrono::steady_clock::now();
   for (int32_t u = 0; u < n_utts; ++u)
+    if (status[u] & ST_NO_BEAMS)  // the reference: ValueError from max([]) (decoder.py:545 / :585)
+      return fail(CTCDEC_ERR_ARG, "max() arg is an empty sequence (utterance " + std::to_string(u) +
+                                      ": no beam survived -- non-finite scores or a positive beam_prune_logp)");
+  for (int32_t u = 0; u < n_utts; ++u)
     if (status[u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[u]) +
                                                         " for utterance " + std::to_string(u));
   const OutBeam* obs = (const OutBeam*)dec->h_out.p;

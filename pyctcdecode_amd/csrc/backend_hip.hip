@@ -157,7 +157,8 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
   if (lane == 0) {
     double mean = r1 > r0 ? s / (double)(r1 - r0) : NAN;
     // math.isclose(mean, 1): |mean - 1| <= 1e-9 * max(|mean|, 1)   (decoder.py:760)
-    bool is_prob = fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);
+    // (an infinite mean -- rows masked with -inf -- is never close: math.isclose(+-inf, 1) is False)
+    bool is_prob = isfinite(mean) && fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
     if (is_prob) a.overflow[1] = 1u;  // flags[1]: some utterance needs the probability pass
   }
@@ -184,6 +185,24 @@ __device__ __forceinline__ PruneLds prune_lds(char* smem, int wave, uint32_t ms,
   return w;
 }
 
+// numpy.argmax semantics on a row that may hold NaN (non-finite input rows): the first NaN wins, else the
+// first maximum. (best, best_id) start as (-inf, INT_MAX); ids arrive in ascending order inside a lane.
+__device__ __forceinline__ void argmax_take(double y, int id, double& best, int& best_id) {
+  const bool bnan = best != best;
+  if (!bnan && (y != y || y > best)) {
+    best = y;
+    best_id = id;
+  }
+}
+__device__ __forceinline__ void argmax_merge(double ob, int oi, double& best, int& best_id) {
+  const bool bnan = best != best, onan = ob != ob;
+  const bool take = onan ? (!bnan || oi < best_id) : (!bnan && (ob > best || (ob == best && oi < best_id)));
+  if (take) {
+    best = ob;
+    best_id = oi;
+  }
+}
+
 // Common tail: argmax across the wave (first maximum, like numpy), CPython-set ordering on lane 0,
 // coalesced write of the ordered (id, logp) list.
 __device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, int lane, const PruneLds& w, uint32_t n,
@@ -198,10 +217,7 @@ __device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, in
   for (int off = 32; off > 0; off >>= 1) {
     double ob = __shfl_xor(best, off, 64);
     int oi = __shfl_xor(best_id, off, 64);
-    if (ob > best || (ob == best && oi < best_id)) {
-      best = ob;
-      best_id = oi;
-    }
+    argmax_merge(ob, oi, best, best_id);
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
@@ -290,10 +306,7 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
     bool in = v < V;
     if (in) {
       y = to_logp(ld(x, v), is_prob, mx, lse);
-      if (y > best) {
-        best = y;
-        best_id = v;
-      }
+      argmax_take(y, v, best, best_id);
     }
     bool keep = in && y >= a.token_min_logp;
     unsigned long long mask = __ballot(keep);
@@ -372,10 +385,10 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
       y1 = to_logp((double)r[k].y, is_prob, mx, lse);
       y2 = to_logp((double)r[k].z, is_prob, mx, lse);
       y3 = to_logp((double)r[k].w, is_prob, mx, lse);
-      if (y0 > best) { best = y0; best_id = v0; }
-      if (y1 > best) { best = y1; best_id = v0 + 1; }
-      if (y2 > best) { best = y2; best_id = v0 + 2; }
-      if (y3 > best) { best = y3; best_id = v0 + 3; }
+      argmax_take(y0, v0, best, best_id);
+      argmax_take(y1, v0 + 1, best, best_id);
+      argmax_take(y2, v0 + 2, best, best_id);
+      argmax_take(y3, v0 + 3, best, best_id);
     }
     const bool k0 = in && y0 >= a.token_min_logp, k1 = in && y1 >= a.token_min_logp;
     const bool k2 = in && y2 >= a.token_min_logp, k3 = in && y3 >= a.token_min_logp;

@@ -38,7 +38,7 @@ constexpr uint32_t M2_HOT_COMPLETE = 32u;  // partial is itself a hot word
 constexpr uint32_t EMPTY_PARTIAL_M2 = PF_ON_TABLE | M2_HOT_ON;
 
 enum : uint32_t { MODE_A = 0, MODE_ALL_B = 1, MODE_FIRST_B = 2, MODE_C = 3, MODE_D = 4 };
-enum : uint32_t { ST_TEXT_OVERFLOW = 1u, ST_EMIT_OVERFLOW = 2u, ST_POOL_OVERFLOW = 4u, ST_TOK_OVERFLOW = 8u };
+enum : uint32_t { ST_TEXT_OVERFLOW = 1u, ST_EMIT_OVERFLOW = 2u, ST_POOL_OVERFLOW = 4u, ST_TOK_OVERFLOW = 8u, ST_NO_BEAMS = 16u };
 
 struct BeamSoA {
   LPtr<double> logit, lm_hw, pscore, c_lm_hw;
@@ -1284,6 +1284,7 @@ struct BeamDecoder {
   }
 
   CTC_HD void step(int t) {
+    if (N == 0) return;  // no beam left (ST_NO_BEAMS is already set): nothing can be extended
     int frame = io.first_frame + t;
     if (ctx.tid == 0) {
       L.scal[0] = 0;
@@ -1340,6 +1341,12 @@ struct BeamDecoder {
     tick<7>();
     const bool big_set = n > 256u;  // ranked by the bucket selection: history keys still to be compared
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
+    // nothing passed the threshold: only possible with non-finite scores (NaN rows) or a positive
+    // beam_prune_logp; the reference then dies on max([]) (decoder.py:545) -- reported through the status
+    if (n == 0 && ctx.tid == 0) {
+      L.scal[7] = 0;
+      L.scal[6] |= ST_NO_BEAMS;
+    }
     const BeamSoA nb = beams_at(cur ^ 1);
     if (final_stage) {
       if (ctx.tid == 0) L.scal[9] = n;

@@ -356,3 +356,44 @@ def test_hip_multi_lm_vs_oracle_batch(lm, bpe):
 def test_hip_multi_lm_streaming_equals_reference_golden(name):
     _loaded_native()
     _multi.check_chunked_case(name, TOL)
+
+
+def test_hip_non_finite_logits_follow_the_reference():
+    """-inf masked labels are ordinary logits; NaN rows end in the reference's ValueError, not in a fault."""
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    _loaded_native()
+    dec = build_ctcdecoder(synth.LIBRI_LABELS)
+    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((40, 29)).astype(np.float32)
+    masked = x.copy()
+    masked[:, 10:20] = -np.inf
+    with np.errstate(all="ignore"):
+        exp = _oracle_expected(orc, masked.astype(np.float64), {"beam_width": 20})
+    got = dec.decode_beams(torch.from_numpy(masked).cuda(), beam_width=20)
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="masked")
+    big = rng.standard_normal((30, 1024)).astype(np.float32)  # the register-resident prune kernel
+    dec_big = build_ctcdecoder([chr(0x4E00 + i) for i in range(1023)])
+    for poison in ("row", "nan", "pinf", "last"):
+        for base, d in ((x, dec), (big, dec_big)):
+            bad = base.copy()
+            if poison == "row":
+                bad[5, :] = -np.inf
+            elif poison == "nan":
+                bad[3, 4] = np.nan
+            elif poison == "pinf":
+                bad[3, 4] = np.inf
+            else:
+                bad[-1, :] = -np.inf
+            with pytest.raises(ValueError):
+                d.decode_beams(bad, beam_width=5)
+            with pytest.raises(ValueError):
+                d.decode_batch(None, [base, bad])
+    assert dec.decode(x) == orc.decode(x.astype(np.float64))
+    assert len(dec_big.decode(big)) > 0
