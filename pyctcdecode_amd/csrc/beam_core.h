@@ -1284,7 +1284,6 @@ struct BeamDecoder {
   }
 
   CTC_HD void step(int t) {
-    if (N == 0) return;  // no beam left (ST_NO_BEAMS is already set): nothing can be extended
     int frame = io.first_frame + t;
     if (ctx.tid == 0) {
       L.scal[0] = 0;
@@ -1321,7 +1320,8 @@ struct BeamDecoder {
     // Labels are taken in chunks of whole labels (<= cand candidates). Before a chunk that might not fit
     // the pool, the pool is compacted to its best beam_width entries; that also fixes the score a later
     // candidate has to beat (smax[2]), so the following chunks add little to the pool.
-    uint32_t per = (uint32_t)shape.cand / (uint32_t)N;
+    // (N == 0 -- no beam left, ST_NO_BEAMS already set -- runs through with empty candidate sets)
+    uint32_t per = (uint32_t)shape.cand / (uint32_t)(N > 0 ? N : 1);
     if (per == 0) per = 1;
     for (uint32_t s0 = 0; s0 < ns; s0 += per) {
       uint32_t s1 = s0 + per < ns ? s0 + per : ns;
