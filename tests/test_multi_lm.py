@@ -136,3 +136,48 @@ def test_multi_public_scorer_matches_oracle(sim_library):  # noqa: F811
         assert abs(s - os_) < 1e-12
     for p in ["a", words[5][:2], "qqqqqqqqq", words[8]]:
         assert abs(mlm.score_partial_token(p) - orc.lm.score_partial(p)) < 1e-12
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_sim_multi_vs_oracle_random(seed, sim_library):  # noqa: F811
+    """Random member sets / weights / unigram sets / decode arguments: device logic == oracle (which is pinned
+    on the reference by oracle/check_vs_reference.py ... multi)."""
+    import synth
+
+    rng = np.random.default_rng(1000 + seed)
+    specs = [{"n_words": 300, "n_sent": 400, "order": 4, "seed": 2}, {"n_words": 200, "n_sent": 300, "order": 3, "seed": 3},
+             {"n_words": 200, "n_sent": 300, "order": 2, "seed": 1}, "toy"]
+    members = []
+    for _ in range(int(rng.integers(2, 5))):
+        spec = specs[int(rng.integers(0, len(specs)))]
+        r = rng.random()
+        m = {"lm": spec, "build": {"alpha": float(rng.choice([0.5, 0.0, 1.0])), "beta": float(rng.choice([1.5, 0.0, 3.0])),
+                                   "unk_score_offset": float(rng.choice([-10.0, 0.0, -4.0])),
+                                   "score_boundary": bool(rng.random() < 0.7)}}
+        if r < 0.2:
+            m["unigrams"] = None
+        elif r < 0.5:
+            m["unigrams"] = sorted(load_unigrams_from_arpa(lm_path(spec)))[: int(rng.integers(1, 60))]
+        members.append(m)
+    bpe = rng.random() < 0.5
+    lm_a = synth.SynthLM(os.path.join(GOLD, "_lm"), 300, 400, order=4, seed=2)
+    labels = synth.make_bpe_vocab(lm_a.words, size=255) if bpe else list(synth.LIBRI_LABELS)
+    case = {"labels": labels, "members": members}
+    dec, _ = build_product_multi(case)
+    orc = build_oracle_multi(case)
+    T = int(rng.integers(1, 50))
+    if rng.random() < 0.6:
+        x = synth.d_words(2, seed, T, labels, bpe, lm_a.words, lm_a.sentences, len(labels), boost=float(rng.choice([4.0, 6.0])),
+                          space_label="|" if bpe else " ").astype(np.float64)
+    else:
+        x = rng.standard_normal((T, len(labels) + 1))
+    kw = {"beam_width": int(rng.choice([1, 5, 30, 100])), "prune_history": bool(rng.random() < 0.5),
+          "beam_prune_logp": float(rng.choice([-5.0, -10.0, -30.0]))}
+    if rng.random() < 0.4:
+        kw["hotwords"] = lm_a.words[:3] + ["zzqx"]
+    with np.errstate(all="ignore"):
+        exp = orc.decode_beams(x, **kw)
+    got = dec.decode_beams(x, **kw)
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got],
+                [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp],
+                tol=1e-9, what="multi-rand%d" % seed)
