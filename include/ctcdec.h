@@ -224,6 +224,15 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out);
 int ctcdec_result_timing(const ctcdec_result* r, double* ms3);
 void ctcdec_result_free(ctcdec_result* r);
 
+/* Diagnostics: the frame-prune stage alone on one [n_frames, V] matrix -- per frame the labels
+ * `set(np.where(logp >= token_min_logp)[0]) | {argmax}` in CPython's set ITERATION order (the order the
+ * reference walks them in, decoder.py:444-447) with their log-probabilities. counts[t] entries of row t are
+ * written to ids / logps at t*stride (at most `stride` of them). Lets a test pin the order emulation on
+ * CPython itself. */
+int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_frames, int32_t dtype,
+                           int32_t is_device, double token_min_logp, int32_t stride, int32_t* counts,
+                           int32_t* ids, double* logps);
+
 /* Diagnostics: enable/disable per-phase tick accumulation (100 MHz wall clock) for utterance 0 of the
  * following decode calls and read the 24 counters of the last one (0 load, 1 modes, 2 completions,
  * 3 keys, 4 merge, 5 score, 6 clear, 7 sort, 8 rebuild, 9 rest, 10 finalise). No reference analogue. */

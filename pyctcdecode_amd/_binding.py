@@ -116,6 +116,8 @@ _PROTOS = {
                                        C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32)),
                                        C.POINTER(C.POINTER(C.c_int32))]),
     "ctcdec_result_lm_state": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(LmState)]),
+    "ctcdec_frame_survivors": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "ctcdec_result_lm_state_of": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LmState)]),
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),

@@ -884,6 +884,73 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   return CTCDEC_OK;
 }
 
+// Diagnostics: run only the frame-prune stage on one utterance and hand back its survivor lists.
+int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_frames, int32_t dtype, int32_t is_device,
+                           double token_min_logp, int32_t stride, int32_t* counts, int32_t* ids, double* logps) {
+  if (!dec || !counts || !ids || !logps || n_frames < 0 || stride < 1 || (n_frames > 0 && !logits))
+    return fail(CTCDEC_ERR_ARG, "bad arguments");
+  if (dtype < CTCDEC_F32 || dtype > CTCDEC_BF16) return fail(CTCDEC_ERR_ARG, "dtype must be f32, f64, f16 or bf16");
+  if (n_frames == 0) return CTCDEC_OK;
+  std::string err;
+  const int V = (int)dec->alpha.labels.size();
+  const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
+  const size_t rows = (size_t)n_frames;
+  std::vector<const void*> ptrs(1, logits);
+  if (!is_device) {
+    if (dec->w_logits.ensure(rows * V * esz, &err) || be::h2d(dec->w_logits.p, logits, rows * V * esz, &err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    ptrs[0] = dec->w_logits.p;
+  }
+  std::vector<int64_t> row0 = {0, (int64_t)n_frames};
+  int max_surv = V;  // the decode path's bound: rows are normalised, at most floor(e^-min) labels pass
+  if (token_min_logp > log(1e-15)) {
+    double bound = floor(exp(-token_min_logp)) + 2.0;
+    if (bound < (double)V) max_surv = (int)bound;
+  }
+  if (upload(dec->w_ptrs, ptrs, &err) || upload(dec->w_row0, row0, &err) || dec->w_rowsum.ensure(rows * 8, &err) ||
+      dec->w_isprob.ensure(4, &err) || dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
+      dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err) || be::zero(dec->w_flags.p, 16, &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  be::PruneArgs pa;
+  pa.utt_logits = (const void* const*)dec->w_ptrs.p;
+  pa.utt_row0 = (const int64_t*)dec->w_row0.p;
+  pa.n_utts = 1;
+  pa.n_rows = n_frames;
+  pa.n_labels = V;
+  pa.dtype = dtype;
+  pa.token_min_logp = token_min_logp;
+  pa.max_surv = max_surv;
+  pa.row_sum = (double*)dec->w_rowsum.p;
+  pa.utt_is_prob = (uint32_t*)dec->w_isprob.p;
+  pa.surv_cnt = (uint32_t*)dec->w_scnt.p;
+  pa.surv_id = (uint16_t*)dec->w_sid.p;
+  pa.surv_lp = (double*)dec->w_slp.p;
+  pa.overflow = (uint32_t*)dec->w_flags.p;
+  pa.pass = 0;
+  pa.rows_aligned16 = (((uintptr_t)ptrs[0]) & 15u) == 0 ? 1 : 0;
+  if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  uint32_t flags[2] = {0, 0};
+  if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  if (flags[1]) {
+    pa.pass = 1;
+    if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  }
+  std::vector<uint32_t> cnt(rows);
+  std::vector<uint16_t> sid(rows * (size_t)max_surv);
+  std::vector<double> slp(rows * (size_t)max_surv);
+  if (be::d2h(cnt.data(), dec->w_scnt.p, rows * 4, &err) || be::d2h(sid.data(), dec->w_sid.p, sid.size() * 2, &err) ||
+      be::d2h(slp.data(), dec->w_slp.p, slp.size() * 8, &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  for (size_t t = 0; t < rows; ++t) {
+    counts[t] = (int32_t)cnt[t];
+    for (uint32_t k = 0; k < cnt[t] && k < (uint32_t)stride; ++k) {
+      ids[t * (size_t)stride + k] = sid[t * (size_t)max_surv + k];
+      logps[t * (size_t)stride + k] = slp[t * (size_t)max_surv + k];
+    }
+  }
+  return CTCDEC_OK;
+}
+
 int32_t ctcdec_result_num_utts(const ctcdec_result* r) { return r ? (int32_t)r->utts.size() : 0; }
 int32_t ctcdec_result_num_beams(const ctcdec_result* r, int32_t utt) {
   if (!r || utt < 0 || (size_t)utt >= r->utts.size()) return 0;

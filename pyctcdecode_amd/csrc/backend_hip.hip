@@ -205,6 +205,109 @@ __device__ __forceinline__ void argmax_merge(double ob, int oi, double& best, in
 
 // Common tail: argmax across the wave (first maximum, like numpy), CPython-set ordering on lane 0,
 // coalesced write of the ordered (id, logp) list.
+// ---- CPython set order with the table spread over the wave -------------------------------------------
+// The same algorithm as set_order.h (Objects/setobject.c: set_add_entry / set_insert_clean /
+// set_table_resize / set_merge) for tables of at most 64 slots: slot k lives in lane k, the free-slot map is
+// a wave-uniform 64-bit mask, keys are wave-uniform -- so a probe sequence is a handful of SCALAR
+// instructions on that mask (the linear 10-slot window is one shift + ctz) instead of a lane-0 walk over LDS.
+// Up to 18 keys (+ argmax) never need more than 64 slots: 8 -> 32 at the 5th key, 128 only at the 19th.
+constexpr uint32_t WAVE_SET_MAX_KEYS = 18;
+struct WTab {
+  uint32_t val;    // this lane's slot (SET_EMPTY when free)
+  uint64_t empty;  // bit k: slot k is free            (uniform)
+  uint32_t mask;   // table size - 1                   (uniform)
+  uint32_t used;   //                                  (uniform)
+};
+__device__ __forceinline__ uint64_t wt_all(uint32_t size) { return size >= 64u ? ~0ull : ((1ull << size) - 1ull); }
+__device__ __forceinline__ void wt_clear(WTab& t, uint32_t size) {
+  t.val = SET_EMPTY;
+  t.mask = size - 1u;
+  t.used = 0;
+  t.empty = wt_all(size);
+}
+__device__ __forceinline__ void wt_put(WTab& t, int lane, uint32_t pos, uint32_t key) {
+  if ((uint32_t)lane == pos) t.val = key;
+  t.empty &= ~(1ull << pos);
+}
+__device__ __forceinline__ void wt_insert_clean(WTab& t, int lane, uint32_t key) {  // set_insert_clean
+  const uint32_t mask = t.mask;
+  uint32_t perturb = key, i = key & mask;
+  for (;;) {
+    const uint64_t win = (t.empty >> i) & ((i + 9u <= mask) ? 0x3FFull : 1ull);  // slot i and the 9 after it
+    if (win) {
+      wt_put(t, lane, i + (uint32_t)__builtin_ctzll(win), key);
+      return;
+    }
+    perturb >>= 5;
+    i = (i * 5u + 1u + perturb) & mask;
+  }
+}
+// every occupied slot of `src`, in slot order, re-inserted into `dst`
+__device__ __forceinline__ void wt_reinsert(WTab& dst, int lane, uint32_t src_val, uint64_t src_occ) {
+  while (src_occ) {
+    const uint32_t k = (uint32_t)__builtin_ctzll(src_occ);
+    src_occ &= src_occ - 1ull;
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)src_val, (int)k);
+    wt_insert_clean(dst, lane, key);
+  }
+}
+__device__ __forceinline__ void wt_resize(WTab& t, int lane, uint32_t minused) {  // set_table_resize
+  uint32_t newsize = 8;
+  while (newsize <= minused) newsize <<= 1;
+  const uint32_t old_val = t.val, used = t.used;
+  const uint64_t occ = ~t.empty & wt_all(t.mask + 1u);
+  wt_clear(t, newsize);
+  t.used = used;
+  wt_reinsert(t, lane, old_val, occ);
+}
+__device__ __forceinline__ void wt_add(WTab& t, int lane, uint32_t key) {  // set_add_entry
+  const uint32_t mask = t.mask;
+  const uint64_t same = __ballot(t.val == key);
+  uint32_t perturb = key, i = key & mask;
+  for (;;) {
+    const uint64_t winmask = (i + 9u <= mask) ? 0x3FFull : 1ull;
+    const uint64_t we = (t.empty >> i) & winmask, ws = (same >> i) & winmask;
+    if (we | ws) {
+      const uint32_t first = (uint32_t)__builtin_ctzll(we | ws);
+      if ((ws >> first) & 1ull) return;  // already a member
+      wt_put(t, lane, i + first, key);
+      t.used += 1u;
+      if (t.used * 5u >= mask * 3u) wt_resize(t, lane, t.used > 50000u ? t.used * 2u : t.used * 4u);
+      return;
+    }
+    perturb >>= 5;
+    i = (i * 5u + 1u + perturb) & mask;
+  }
+}
+// set(asc[0..n)) | {argmax} for n <= WAVE_SET_MAX_KEYS: returns the member count; this lane's slot value and
+// the occupancy mask (slot order = iteration order) come back through the references.
+__device__ __forceinline__ uint32_t wave_set_order(const uint16_t* asc, uint32_t n, uint32_t argmax, int lane,
+                                                   uint32_t& my_val, uint64_t& occ) {
+  WTab a, r;
+  wt_clear(a, 8);
+  for (uint32_t k = 0; k < n; ++k) wt_add(a, lane, (uint32_t)__builtin_amdgcn_readfirstlane((int)asc[k]));
+  wt_clear(r, 8);
+  if (a.used) {  // set_merge (the `|` copies the left operand first)
+    if (a.used * 5u >= r.mask * 3u) {
+      uint32_t newsize = 8;
+      while (newsize <= a.used * 2u) newsize <<= 1;
+      wt_clear(r, newsize);
+    }
+    if (r.mask == a.mask) {
+      r.val = a.val;
+      r.empty = a.empty;
+    } else {
+      wt_reinsert(r, lane, a.val, ~a.empty & wt_all(a.mask + 1u));
+    }
+    r.used = a.used;
+  }
+  if ((r.used + 1u) * 5u >= r.mask * 3u) wt_resize(r, lane, (r.used + 1u) * 2u);
+  wt_add(r, lane, argmax);
+  my_val = r.val;
+  occ = ~r.empty & wt_all(r.mask + 1u);
+  return (uint32_t)__popcll(occ);
+}
+
 __device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, int lane, const PruneLds& w, uint32_t n,
                                              double best, int best_id) {
   const uint32_t ms = (uint32_t)a.max_surv;
@@ -221,6 +324,30 @@ __device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, in
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
+  uint16_t* out_id = a.surv_id + (size_t)row * ms;
+  double* out_lp = a.surv_lp + (size_t)row * ms;
+  if (n <= WAVE_SET_MAX_KEYS) {  // the usual frame: a handful of survivors, table in registers
+    uint32_t my_id = SET_EMPTY;
+    uint64_t occ = 0;
+    uint32_t m = wave_set_order(w.asc_id, n, (uint32_t)__builtin_amdgcn_readfirstlane(best_id), lane, my_id, occ);
+    const uint32_t pos = (uint32_t)__popcll(occ & ((1ull << lane) - 1ull));
+    if (m > ms) {
+      overflow = true;
+      m = ms;
+    }
+    if (lane == 0) {
+      a.surv_cnt[row] = m;
+      if (overflow) a.overflow[0] = 1u;
+    }
+    if (((occ >> lane) & 1ull) && pos < m) {
+      double lp = best;  // the argmax may be absent from the list (below the threshold)
+      for (uint32_t k = 0; k < n; ++k)
+        if (w.asc_id[k] == my_id) lp = w.asc_lp[k];
+      out_id[pos] = (uint16_t)my_id;
+      out_lp[pos] = lp;
+    }
+    return;
+  }
   uint32_t m = 0;
   if (lane == 0) m = cpython_set_order(w.asc_id, n, (uint32_t)best_id, w.tabA, w.tabR, w.scratch, w.order);
   m = __shfl(m, 0, 64);
@@ -233,8 +360,6 @@ __device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, in
     a.surv_cnt[row] = m;
     if (overflow) a.overflow[0] = 1u;
   }
-  uint16_t* out_id = a.surv_id + (size_t)row * ms;
-  double* out_lp = a.surv_lp + (size_t)row * ms;
   for (uint32_t k = lane; k < m; k += 64) {
     uint32_t id = w.order[k];
     // binary search the ascending list for the log-prob (the argmax may be absent: below threshold)

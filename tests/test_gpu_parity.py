@@ -397,3 +397,22 @@ def test_hip_non_finite_logits_follow_the_reference():
                 d.decode_batch(None, [base, bad])
     assert dec.decode(x) == orc.decode(x.astype(np.float64))
     assert len(dec_big.decode(big)) > 0
+
+
+def test_hip_frame_survivors_in_cpython_set_order():
+    """The prune kernels' per-frame label order against a REAL CPython set (the wave-distributed table for
+    up to 18 survivors, the lane-0 LDS walk above that; register-resident and generic kernels; fp32/fp64/fp16)."""
+    from pyctcdecode_amd import build_ctcdecoder
+    from tests.survivor_util import check_against_cpython
+
+    _loaded_native()
+    rng = np.random.default_rng(11)
+    border = frames = 0
+    for V, scale, tmin, dt in [(29, 1.0, -5.0, np.float32), (29, 3.0, -3.0, np.float64), (300, 2.0, -5.0, np.float32),
+                               (1024, 1.0, -6.5, np.float32), (1024, 1.0, -7.5, np.float32), (1024, 4.0, -5.0, np.float32),
+                               (1024, 2.0, -5.0, np.float16), (5000, 3.0, -6.0, np.float32), (29, 0.3, -3.2, np.float32)]:
+        dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
+        x = (rng.standard_normal((300, V)) * scale).astype(dt)
+        border += check_against_cpython(dec, x, tmin, TOL)
+        frames += 300
+    assert border < frames // 20

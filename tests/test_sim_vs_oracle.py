@@ -187,3 +187,15 @@ def test_non_finite_logits_follow_the_reference(sim_library):  # noqa: F811
     with pytest.raises(ValueError):
         dec.decode_beams(x, beam_prune_logp=1.0)
     assert dec.decode(x) == orc.decode(x.astype(np.float64))  # still healthy afterwards
+
+
+def test_frame_survivors_in_cpython_set_order(sim_library):  # noqa: F811
+    """The prune stage's per-frame label order IS the iteration order of a real CPython set."""
+    from pyctcdecode_amd import build_ctcdecoder
+    from tests.survivor_util import check_against_cpython
+
+    rng = np.random.default_rng(11)
+    for V, scale, tmin in [(29, 1.0, -5.0), (29, 3.0, -3.0), (300, 2.0, -5.0), (1024, 1.0, -6.5), (1024, 4.0, -5.0)]:
+        dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
+        x = (rng.standard_normal((40, V)) * scale).astype(np.float32)
+        check_against_cpython(dec, x, tmin, 1e-9)
