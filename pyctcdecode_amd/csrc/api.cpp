@@ -5,7 +5,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <thread>
@@ -99,7 +103,77 @@ struct StreamIn {
 
 }  // namespace
 
+// A few persistent host threads for the per-utterance replay (spawning them per call cost more than the
+// work itself: 8 x ~80 us on the bench box). Jobs are index ranges handed out through an atomic cursor.
+class ReplayPool {
+ public:
+  explicit ReplayPool(int n) {
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~ReplayPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  int size() const { return (int)workers_.size(); }
+  // fn(u0, u1) over [0, n) in chunks; returns when all chunks are done (the caller works too)
+  void run(int32_t n, int32_t chunk, const std::function<void(int32_t, int32_t)>& fn) {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      fn_ = &fn;
+      n_ = n;
+      chunk_ = chunk;
+      next_.store(0);
+      pending_ = (int)workers_.size();
+      ++epoch_;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      int32_t u0 = next_.fetch_add(chunk_);
+      if (u0 >= n_) return;
+      (*fn_)(u0, std::min(n_, u0 + chunk_));
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+      }
+      work();
+      {
+        std::lock_guard<std::mutex> g(m_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int32_t, int32_t)>* fn_ = nullptr;
+  std::atomic<int32_t> next_{0};
+  int32_t n_ = 0, chunk_ = 1;
+  int pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+
 struct ctcdec_decoder {
+  std::unique_ptr<ReplayPool> replay_pool;  // created on the first large batch
   HostAlphabet alpha;
   std::shared_ptr<HostLM> lm_ptr = std::make_shared<HostLM>();
   HostLM& lm_ref() { return *lm_ptr; }
@@ -860,16 +934,17 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     }
   };
   // host replay is independent per utterance: a few threads once there is enough of it
-  int n_thr = (head > 50000 && n_utts >= 16) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-  if (n_thr <= 1) {
-    replay_range(0, n_utts);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_thr; ++t) {
-      int32_t u0 = (int32_t)((int64_t)n_utts * t / n_thr), u1 = (int32_t)((int64_t)n_utts * (t + 1) / n_thr);
-      pool.emplace_back(replay_range, u0, u1);
+  if (head > 50000 && n_utts >= 16) {
+    if (!dec->replay_pool) {
+      unsigned want = 15u;  // + the calling thread
+      if (const char* env = getenv("CTCDEC_REPLAY_THREADS")) want = (unsigned)std::max(0, atoi(env) - 1);
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      dec->replay_pool.reset(new ReplayPool((int)std::min(want, hw > 1 ? hw - 1 : 0u)));
     }
-    for (auto& th : pool) th.join();
+    const std::function<void(int32_t, int32_t)> job = replay_range;
+    dec->replay_pool->run(n_utts, 4, job);
+  } else {
+    replay_range(0, n_utts);
   }
   auto t_end = std::chrono::steady_clock::now();
   res->ms[2] = std::chrono::duration<double, std::milli>(t_end - t_begin).count();
