@@ -309,18 +309,20 @@ __device__ __forceinline__ uint32_t wave_set_order(const uint16_t* asc, uint32_t
 }
 
 __device__ __forceinline__ void prune_finish(const PruneArgs& a, int64_t row, int lane, const PruneLds& w, uint32_t n,
-                                             double best, int best_id) {
+                                             double best, int best_id, bool reduced = false) {
   const uint32_t ms = (uint32_t)a.max_surv;
   bool overflow = false;
   if (n > ms) {
     overflow = true;
     n = ms;
   }
+  if (!reduced) {  // (best, best_id) are per-lane candidates: reduce across the wave
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double ob = __shfl_xor(best, off, 64);
-    int oi = __shfl_xor(best_id, off, 64);
-    argmax_merge(ob, oi, best, best_id);
+    for (int off = 32; off > 0; off >>= 1) {
+      double ob = __shfl_xor(best, off, 64);
+      int oi = __shfl_xor(best_id, off, 64);
+      argmax_merge(ob, oi, best, best_id);
+    }
   }
   __builtin_amdgcn_wave_barrier();
   __threadfence_block();
@@ -447,6 +449,31 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
   prune_finish(a, row, lane, w, n, best, best_id);
 }
 
+// exp(d) for d <= 0 (d = logit - row max), fp64, ~1 ulp: 2^k * exp(r) with k = rint(d / ln 2), |r| <= ln2/2,
+// exp(r) by its degree-13 Taylor polynomial (next term < 5e-18 relative). No overflow side to handle and the
+// underflow side is a clamp, which is what makes it ~2/3 of the general routine's instructions.
+__device__ __forceinline__ double exp_nonpos(double d) {
+  d = fmax(d, -750.0);  // exp(-750) == 0 in fp64; also maps -inf (masked labels) to 0
+  const double kf = rint(d * 1.44269504088896338700e+00);
+  double r = fma(kf, -6.93147180369123816490e-01, d);
+  r = fma(kf, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;            // 1/13!
+  p = fma(p, r, 2.08767569878680990e-09);       // 1/12!
+  p = fma(p, r, 2.50521083854417188e-08);       // 1/11!
+  p = fma(p, r, 2.75573192239858907e-07);       // 1/10!
+  p = fma(p, r, 2.75573192239858907e-06);       // 1/9!
+  p = fma(p, r, 2.48015873015873016e-05);       // 1/8!
+  p = fma(p, r, 1.98412698412698413e-04);       // 1/7!
+  p = fma(p, r, 1.38888888888888889e-03);       // 1/6!
+  p = fma(p, r, 8.33333333333333333e-03);       // 1/5!
+  p = fma(p, r, 4.16666666666666667e-02);       // 1/4!
+  p = fma(p, r, 1.66666666666666667e-01);       // 1/3!
+  p = fma(p, r, 5.00000000000000000e-01);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
+
 // Register-resident frame-prune for fp32 rows with V % 4 == 0 and V <= 1024*... (NC chunks of 256
 // labels): each lane pulls its 4*NC logits with 16-byte loads ONCE (1 KiB per wave-instruction, fully
 // coalesced) and all three sweeps run out of registers: the logits cross HBM exactly once.
@@ -471,6 +498,8 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
     r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   }
   double mx = 0.0, lse = 0.0;
+  const uint32_t ms = (uint32_t)a.max_surv;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   if (!is_prob) {
     float mf = -INFINITY;
     double rs = 0.0;
@@ -484,6 +513,69 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
     double m = wave_max((double)mf);
     rs = wave_sum(rs);
     if (lane == 0) a.row_sum[row] = rs;
+    // ---- the clean row (finite maximum, no NaN: -inf masks are fine): everything below in its cheapest form
+    if (isfinite(m) && rs == rs) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (k * 64 + lane < n4)
+          s += (exp_nonpos((double)r[k].x - m) + exp_nonpos((double)r[k].y - m)) +
+               (exp_nonpos((double)r[k].z - m) + exp_nonpos((double)r[k].w - m));
+      }
+      s = wave_sum(s);
+      lse = log(s);
+      // argmax of the log-probs = first maximum of the logits (x -> clip(x - m - lse) is monotone, and two
+      // different fp32 logits never round to the same fp64 value after the two subtractions)
+      const float mfw = (float)m;
+      int first = 0x7FFFFFFF;
+#pragma unroll
+      for (int k = NC - 1; k >= 0; --k) {
+        const int v0 = (k * 64 + lane) * 4;
+        if (k * 64 + lane < n4) {
+          first = r[k].w == mfw ? v0 + 3 : first;
+          first = r[k].z == mfw ? v0 + 2 : first;
+          first = r[k].y == mfw ? v0 + 1 : first;
+          first = r[k].x == mfw ? v0 : first;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(first, off, 64);
+        first = o < first ? o : first;
+      }
+      const double best = to_logp((double)mfw, false, m, lse);
+      // survivors: an fp32 screen that cannot miss (threshold rounded down, with a margin far above the fp64
+      // rounding of the exact test), then the exact fp64 test only in the 256-label chunks that have a candidate
+      const double xthr = m + lse + a.token_min_logp;
+      const float pre = __double2float_rd(xthr - 1e-6 * (1.0 + fabs(xthr)));
+      uint32_t n = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const bool in = k * 64 + lane < n4;
+        const bool cand = in && (r[k].x >= pre || r[k].y >= pre || r[k].z >= pre || r[k].w >= pre);
+        if (__ballot(cand)) {
+          const int v0 = (k * 64 + lane) * 4;
+          double y0 = -INFINITY, y1 = -INFINITY, y2 = -INFINITY, y3 = -INFINITY;
+          if (cand) {
+            y0 = to_logp((double)r[k].x, false, m, lse);
+            y1 = to_logp((double)r[k].y, false, m, lse);
+            y2 = to_logp((double)r[k].z, false, m, lse);
+            y3 = to_logp((double)r[k].w, false, m, lse);
+          }
+          const bool k0 = cand && y0 >= a.token_min_logp, k1 = cand && y1 >= a.token_min_logp;
+          const bool k2 = cand && y2 >= a.token_min_logp, k3 = cand && y3 >= a.token_min_logp;
+          const unsigned long long b0 = __ballot(k0), b1 = __ballot(k1), b2 = __ballot(k2), b3 = __ballot(k3);
+          uint32_t pos = n + (uint32_t)(__popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt));
+          if (k0) { if (pos < ms) { w.asc_id[pos] = (uint16_t)v0; w.asc_lp[pos] = y0; } ++pos; }
+          if (k1) { if (pos < ms) { w.asc_id[pos] = (uint16_t)(v0 + 1); w.asc_lp[pos] = y1; } ++pos; }
+          if (k2) { if (pos < ms) { w.asc_id[pos] = (uint16_t)(v0 + 2); w.asc_lp[pos] = y2; } ++pos; }
+          if (k3) { if (pos < ms) { w.asc_id[pos] = (uint16_t)(v0 + 3); w.asc_lp[pos] = y3; } ++pos; }
+          n += (uint32_t)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+        }
+      }
+      prune_finish(a, row, lane, w, n, best, first, /*reduced=*/true);
+      return;
+    }
     if (!isfinite(m)) m = 0.0;
     double s = 0.0;
 #pragma unroll
@@ -498,8 +590,6 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
   uint32_t n = 0;
   double best = -INFINITY;
   int best_id = 0x7FFFFFFF;
-  const uint32_t ms = (uint32_t)a.max_surv;
-  const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const bool in = k * 64 + lane < n4;
