@@ -8,7 +8,7 @@
 // the frame-prune kernel, and two append-only arenas (TextNode, EmitNode).
 //
 // The code is written against an execution context `Ctx` {tid, nt, sync(), LDS atomics} so the
-// same source runs as a HIP workgroup (kernels.hip) and as a 1-thread sequential simulation
+// same source runs as a HIP workgroup (backend_hip.hip) and as a 1-thread sequential simulation
 // (tests/sim, test infrastructure only -- the product never runs it).
 #pragma once
 #include <math.h>
@@ -240,7 +240,7 @@ CTC_HD double lse2(double a, double b) {  // decoder.py:170-177
 
 CTC_HD uint64_t hist_hash(const uint64_t* ring, uint32_t cnt) {
   uint64_t h = 0x9E3779B97F4A7C15ull + cnt;
-#pragma unroll
+CTC_UNROLL
   for (int k = MAX_CTX - 1; k >= 0; --k)
     if ((uint32_t)k < cnt) h = mix64(h ^ ring[k]) + 0x632BE59BD9B4E019ull;
   return h;
@@ -255,7 +255,7 @@ CTC_HD double partial_score(const DeviceTables& t, const DecodeParams& prm, uint
   double s = prm.unk * (on_trie ? 0.0 : 1.0);
   if (plen > 6) s = s * (double)plen / 6.0;
   if (t.n_lms > 1) {  // MultiLanguageModel.score_partial_token: np.mean over the models (language_model.py:477-481)
-#pragma unroll
+CTC_UNROLL
     for (int k = 1; k < MAX_LMS; ++k) {
       if ((uint32_t)k < t.n_lms) {
         const LmExtra& x = t.x[k - 1];
@@ -369,7 +369,7 @@ struct BeamDecoder {
     if (tab.has_lm && i < N && plen(b, i) > 0 && b.comp_node[i] == 0) {
       const TextNode& src = io.text_nodes[b.text_node[i]];
       pre_state.len = src.state.len;
-#pragma unroll
+CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) {
         pre_state.words[k] = src.state.words[k];
         pre_state.backoff[k] = src.state.backoff[k];
@@ -385,7 +385,7 @@ struct BeamDecoder {
       st = pre_state;
     } else {
       st.len = src.state.len;
-#pragma unroll
+CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) {
         st.words[k] = src.state.words[k];
         st.backoff[k] = src.state.backoff[k];
@@ -402,7 +402,7 @@ struct BeamDecoder {
   template <class GetIn, class PutOut>
   CTC_HD double multi_word_score(uint32_t uwid, bool eos, GetIn get_in, PutOut put_out) const {
     double sum = 0.0;
-#pragma unroll
+CTC_UNROLL
     for (int k = 0; k < MAX_LMS; ++k) {
       if ((uint32_t)k < tab.n_lms) {
         LmState in, out;
@@ -439,7 +439,7 @@ struct BeamDecoder {
 
   CTC_HD static void copy_state(LmState* d, const LmState& a) {
     d->len = a.len;
-#pragma unroll
+CTC_UNROLL
     for (int k = 0; k < MAX_CTX; ++k) {
       d->words[k] = a.words[k];
       d->backoff[k] = a.backoff[k];
@@ -478,7 +478,7 @@ struct BeamDecoder {
       raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
     } else {
       dst.state.len = src.state.len;
-#pragma unroll
+CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) {
         dst.state.words[k] = src.state.words[k];
         dst.state.backoff[k] = src.state.backoff[k];
@@ -491,7 +491,7 @@ struct BeamDecoder {
     const uint32_t rc = src.ring_cnt + 1 > tab.n_hist ? tab.n_hist : src.ring_cnt + 1;
     // history ring (newest first) and its hash, without run-time indexed temporaries
     uint64_t hh = 0x9E3779B97F4A7C15ull + rc;
-#pragma unroll
+CTC_UNROLL
     for (int k = MAX_CTX - 1; k >= 0; --k) {
       uint64_t rk = k == 0 ? wh : ((uint32_t)k < rc ? src.ring[k > 0 ? k - 1 : 0] : 0ull);
       dst.ring[k] = rk;
@@ -1002,7 +1002,7 @@ struct BeamDecoder {
     uint32_t pl, m2, wid;
     double ps;
   };
-  CTC_HD PartView new_partial(const BeamSoA& b, int i, uint32_t c, const TkView& tk, uint32_t br,
+  CTC_HD PartView new_partial(const BeamSoA& b, int i, const TkView& tk, uint32_t br,
                               uint64_t new_part_h, bool have_pre, const PrefixEntry& pre_p,
                               const HotEntry& pre_h) const {
     PartView v;
@@ -1064,7 +1064,7 @@ struct BeamDecoder {
   }
 
   // Candidate generation + merge + scoring for survivors [s0, s1)
-  CTC_HD void process_chunk(uint32_t s0, uint32_t s1, int frame) {
+  CTC_HD void process_chunk(uint32_t s0, uint32_t s1) {
     const BeamSoA b = beams_at(cur);
     uint32_t Q = (s1 - s0) * (uint32_t)N;
     // conservative running threshold from the chunks already seen (nobody writes smax here)
@@ -1151,7 +1151,7 @@ struct BeamDecoder {
           ctx.use(lg + lmhw);
           tick<14>();
         }
-        PartView pv = new_partial(b, i, c, tk, br, L.ck_part[q], have_pre && base == 0, pre_p, pre_h);
+        PartView pv = new_partial(b, i, tk, br, L.ck_part[q], have_pre && base == 0, pre_p, pre_h);
         if (io.prof) {
           ctx.use(pv.ps);
           tick<15>();
@@ -1326,7 +1326,7 @@ struct BeamDecoder {
     for (uint32_t s0 = 0; s0 < ns; s0 += per) {
       uint32_t s1 = s0 + per < ns ? s0 + per : ns;
       if (L.scal[0] + (s1 - s0) * (uint32_t)N > (uint32_t)shape.pool) prune_pool();
-      process_chunk(s0, s1, frame);
+      process_chunk(s0, s1);
     }
     prefetch_tok();
     finish_frame(frame, false);
@@ -1473,7 +1473,7 @@ struct BeamDecoder {
       const double lmhw = m.raw_lm + prm.hot_weight * (double)m.hw_cnt;
       tn.lm_hw = lmhw;
       uint64_t hh = 0x9E3779B97F4A7C15ull + m.ring_cnt;
-#pragma unroll
+CTC_UNROLL
       for (int k = MAX_CTX - 1; k >= 0; --k) {
         tn.ring[k] = m.ring[k];
         if ((uint32_t)k < m.ring_cnt) hh = mix64(hh ^ m.ring[k]) + 0x632BE59BD9B4E019ull;
@@ -1483,7 +1483,7 @@ struct BeamDecoder {
       tn.ring_cnt = m.ring_cnt;
       tn.pad0 = 0;
       tn.state.len = m.state.len;
-#pragma unroll
+CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) {
         tn.state.words[k] = m.state.words[k];
         tn.state.backoff[k] = m.state.backoff[k];
@@ -1661,7 +1661,7 @@ struct BeamDecoder {
       ob.raw_lm = node.raw_lm;
       if (!tab.has_lm) {
         ob.state.len = -1;
-#pragma unroll
+CTC_UNROLL
         for (int k = 0; k < MAX_CTX; ++k) {
           ob.state.words[k] = 0;
           ob.state.backoff[k] = 0.f;
@@ -1686,7 +1686,7 @@ struct BeamDecoder {
         lm_base_score(tab, src.state, pl > 0 ? b.word_id[d] : 0u, &ob.state);
       } else {
         ob.state.len = node.state.len;
-#pragma unroll
+CTC_UNROLL
         for (int k = 0; k < MAX_CTX; ++k) {
           ob.state.words[k] = node.state.words[k];
           ob.state.backoff[k] = node.state.backoff[k];
@@ -1726,7 +1726,7 @@ struct BeamDecoder {
     finalise();
     tick<10>();
     if (io.prof && ctx.tid == 0) {
-#pragma unroll
+CTC_UNROLL
       for (int k = 0; k < N_PROF; ++k) io.prof[k] = t_acc[k];
     }
   }

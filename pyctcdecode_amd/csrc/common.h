@@ -9,6 +9,13 @@
 #define CTC_HD inline
 #endif
 
+// loop unrolling request for the device compiler (a plain host compiler does not know the pragma)
+#if defined(__HIPCC__) && !defined(CTC_SIM)
+#define CTC_UNROLL _Pragma("unroll")
+#else
+#define CTC_UNROLL
+#endif
+
 namespace ctc {
 
 // ---------------------------------------------------------------------------------------------
@@ -300,7 +307,7 @@ CTC_HD bool ngram_lookup(const NgramEntry* tab, uint64_t mask, uint64_t key, flo
 template <int N>
 CTC_HD uint64_t lm_key(const LmState& in, uint32_t wid) {
   uint64_t k = ngram_key_begin((uint32_t)N);
-#pragma unroll
+CTC_UNROLL
   for (int c = N - 2; c >= 0; --c) k = ngram_key_push(k, in.words[c]);
   return ngram_key_end(ngram_key_push(k, wid));
 }
