@@ -308,6 +308,7 @@ struct BeamDecoder {
   uint32_t pf_cnt = 0, pf_id = 0;  // survivors of the NEXT frame, fetched one frame ahead
   double pf_lp = 0.0;
   bool pf_live = false;
+  bool flush_nodes = false;        // TextNode stores of this frame still to be completed behind a barrier
   TokLite pf_tok;                  // ... and the label constants of this thread's survivor
   unsigned long long t_last = 0;
   unsigned long long t_acc[N_PROF] = {};
@@ -1167,7 +1168,12 @@ CTC_UNROLL
       const uint64_t wave_key = ctx.wave_max_u64(my_key);
       if (ctx.is_wave_leader() && wave_key != 0) ctx.atomic_max64(&L.smax[0], wave_key);
     }
-    ctx.sync();
+    if (flush_nodes) {  // (uniform) see step(): completes this frame's TextNode stores
+      ctx.sync_mem();
+      flush_nodes = false;
+    } else {
+      ctx.sync();
+    }
     tick<5>();
     if (!one_pass) {
       clear_table();
@@ -1308,13 +1314,14 @@ CTC_UNROLL
     if (L.scal[4]) {
       for (int i = ctx.tid; i < N; i += ctx.nt)
         if (plen(b, i) > 0 && b.comp_node[i] == 0) make_completion(b, i);
-      // the TextNodes written here are read by other threads in later frames: the full barrier waits
-      // for the stores (the LDS-only one does not)
-      ctx.sync_mem();
+      // The TextNodes written here are read by other threads from the next frame on. Their stores have to be
+      // complete behind a barrier by then, but nothing in THIS frame reads them (the c_* copies are in LDS):
+      // the full barrier that waits for them is the one that ends the scoring phase, a few microseconds
+      // from now, when the wait is free -- here it would stall every wave for a store round trip.
+      flush_nodes = true;
       tick<22>();
-    } else {
-      ctx.sync();
     }
+    ctx.sync();
     prefetch(t + 1);  // lands while this frame's candidates are processed
     tick<2>();
     // Labels are taken in chunks of whole labels (<= cand candidates). Before a chunk that might not fit
@@ -1327,6 +1334,10 @@ CTC_UNROLL
       uint32_t s1 = s0 + per < ns ? s0 + per : ns;
       if (L.scal[0] + (s1 - s0) * (uint32_t)N > (uint32_t)shape.pool) prune_pool();
       process_chunk(s0, s1);
+    }
+    if (flush_nodes) {  // (no chunk ran: cannot happen with >= 1 survivor per frame, kept for safety)
+      ctx.sync_mem();
+      flush_nodes = false;
     }
     prefetch_tok();
     finish_frame(frame, false);
