@@ -26,6 +26,9 @@ _BRACKETED = re.compile(r"^[<\[].+[>\]]$")          # <s>, [CLS], ...
 _PAD = re.compile(r"^[<\[]pad[>\]]$", re.IGNORECASE)  # CTC blank spelled as a pad token
 _UNK = re.compile(r"^[<\[]unk[>\]]$", re.IGNORECASE)
 
+# names under which callers of the reference import the same patterns (alphabet.py:15-17)
+SPECIAL_TOKEN_PTN, BLANK_TOKEN_PTN, UNK_TOKEN_PTN = _BRACKETED, _PAD, _UNK
+
 Rule = Callable[[List[str]], List[str]]
 
 

@@ -14,7 +14,7 @@ import dataclasses
 import logging
 import math
 import os
-from typing import Any, Collection, Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Any, Collection, Dict, Iterable, List, Optional, Sequence, Tuple, TypeVar
 
 import numpy as np
 
@@ -51,6 +51,12 @@ logger = logging.getLogger(__name__)
 
 Frames = Tuple[int, int]
 WordFrames = Tuple[str, Frames]
+# type aliases callers of the reference import from here (decoder.py:121-126, 142-143)
+LMScoreCacheKey = Tuple[str, bool]
+LMScoreCacheValue = Tuple[float, float, AbstractLMState]
+LMScoreCache = Dict[LMScoreCacheKey, LMScoreCacheValue]
+FloatVar = TypeVar("FloatVar", bound=np.floating)
+Shape = TypeVar("Shape")
 
 
 @dataclasses.dataclass(frozen=True)
