@@ -23,6 +23,9 @@
 using namespace ctc;
 
 static thread_local std::string g_err;
+// The backend owns one stream and one set of timing events per process: calls that touch the device are
+// serialised (several host threads may share decoders; the GIL is released during ctypes calls).
+static std::mutex g_device_mu;
 static int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -466,6 +469,7 @@ int ctcdec_lm_base_score(const ctcdec_decoder* dec, const ctcdec_lm_state* in, u
 
 int ctcdec_set_hotwords(ctcdec_decoder* dec, const char* blob, const int64_t* off, int64_t n_words) {
   if (!dec) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  std::lock_guard<std::mutex> device_lock(g_device_mu);
   std::vector<std::string> uni;
   for (int64_t i = 0; i < n_words; ++i) uni.emplace_back(blob + off[i], (size_t)(off[i + 1] - off[i]));
   dec->hot.build(uni, dec->alpha);
@@ -647,6 +651,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     return CTCDEC_OK;
   }
   const int K = dec->has_lm ? dec->n_lms() : 1;
+  std::lock_guard<std::mutex> device_lock(g_device_mu);
   if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
@@ -967,6 +972,7 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   if (dtype < CTCDEC_F32 || dtype > CTCDEC_BF16) return fail(CTCDEC_ERR_ARG, "dtype must be f32, f64, f16 or bf16");
   if (n_frames == 0) return CTCDEC_OK;
   std::string err;
+  std::lock_guard<std::mutex> device_lock(g_device_mu);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
   const size_t rows = (size_t)n_frames;

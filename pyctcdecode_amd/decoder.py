@@ -14,6 +14,7 @@ import dataclasses
 import logging
 import math
 import os
+import threading
 from typing import Any, Collection, Dict, Iterable, List, Optional, Sequence, Tuple, TypeVar
 
 import numpy as np
@@ -249,6 +250,9 @@ class BeamSearchDecoderCTC:
             srcs = (C.c_void_p * len(members))(*[m._kenlm_model._handle for m in members])
             lib.check(lib.dll.ctcdec_lm_share_multi(handle, srcs, len(members)))
         self._hot_key: Optional[Tuple[str, ...]] = None
+        # one native call at a time per decoder: hot words / per-model weights are decoder state that a call sets
+        # up first (host threads may share a decoder; ctypes releases the GIL while the device works)
+        self._call_lock = threading.RLock()
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -336,7 +340,11 @@ class BeamSearchDecoderCTC:
         return p
 
     def _run(self, logits_list: Sequence[Any], params: B.Params, hotwords, start_states=None):
-        """-> (packed numpy views, result handle). Caller must free the handle."""
+        """-> result handle. Caller must free the handle."""
+        with self._call_lock:
+            return self._run_locked(logits_list, params, hotwords, start_states)
+
+    def _run_locked(self, logits_list: Sequence[Any], params: B.Params, hotwords, start_states=None):
         self._set_hotwords(hotwords)
         batch = _Batch(logits_list, len(self._idx2vocab))
         n = len(batch.ptrs)
@@ -619,6 +627,15 @@ class BeamSearchDecoderCTC:
     ) -> List[List[LMBeam]]:
         """Many independent streams advanced by one chunk each in ONE device launch (extension of
         partial_decode_beams, decoder.py:681-728; one workgroup per stream)."""
+        with self._call_lock:
+            return self._partial_decode_beams_batch_locked(
+                logits_list, cached_lm_scores_list, cached_p_lm_scores_list, beams_list, processed_frames_list,
+                beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_scorer, force_next_word, is_end)
+
+    def _partial_decode_beams_batch_locked(
+        self, logits_list, cached_lm_scores_list, cached_p_lm_scores_list, beams_list, processed_frames_list,
+        beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_scorer, force_next_word, is_end,
+    ) -> List[List[LMBeam]]:
         n = len(logits_list)
         for logits in logits_list:
             self._check_logits_dimension(logits)

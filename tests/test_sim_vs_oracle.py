@@ -199,3 +199,33 @@ def test_frame_survivors_in_cpython_set_order(sim_library):  # noqa: F811
         dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
         x = (rng.standard_normal((40, V)) * scale).astype(np.float32)
         check_against_cpython(dec, x, tmin, 1e-9)
+
+
+def test_decode_calls_from_several_host_threads(sim_library):  # noqa: F811
+    """Two decoders driven from four host threads at once (ctypes releases the GIL): calls are serialised
+    inside the library, every result equals the single-threaded one."""
+    import threading
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    lm = synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2)
+    decs = [build_ctcdecoder(synth.LIBRI_LABELS, lm.path), build_ctcdecoder(synth.LIBRI_LABELS)]
+    xs = [synth.d_words(2, u, 40, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=5.0) for u in range(8)]
+    want = [[d.decode(x) for x in xs] for d in decs]
+    got = [[None] * len(xs) for _ in decs]
+    errs = []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                for u in range(k % 2, len(xs), 2):
+                    got[k // 2][u] = decs[k // 2].decode(xs[u])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs and got == want
