@@ -500,20 +500,17 @@ class MultiLanguageModel(AbstractLanguageModel):
     def score(
         self, prev_state: AbstractLMState, word: str, is_last_word: bool = False
     ) -> Tuple[float, MultiLanguageModelState]:
+        """Every member scores `word` from its own state; the scores are averaged (left-to-right sum, then one
+        division, as in the reference: language_model.py:495-501)."""
+        members = self._language_models
         if not isinstance(prev_state, MultiLanguageModelState):
             raise AssertionError(
-                f"Wrong input state type found. Expected MultiLanguageModelState, got {type(prev_state)}"
-            )
-        if len(prev_state.states) != len(self._language_models):
-            raise AssertionError(
-                f"Number of states ({len(prev_state.states)}) does not match number of language "
-                f"models ({len(self._language_models)})."
-            )
-        score = 0.0
-        end_state = []
-        for lm_prev_state, lm in zip(prev_state.states, self._language_models):
-            lm_score, lm_end_state = lm.score(lm_prev_state, word, is_last_word=is_last_word)
-            score += lm_score
-            end_state.append(lm_end_state)
-        score = score / len(self._language_models)
-        return score, MultiLanguageModelState(end_state)
+                "Wrong input state type found. Expected MultiLanguageModelState, got %s" % type(prev_state))
+        if len(prev_state.states) != len(members):
+            raise AssertionError("Number of states (%d) does not match number of language models (%d)." % (
+                len(prev_state.states), len(members)))
+        scored = [lm.score(st, word, is_last_word=is_last_word) for st, lm in zip(prev_state.states, members)]
+        total = 0.0
+        for value, _ in scored:
+            total += value
+        return total / len(members), MultiLanguageModelState([st for _, st in scored])
