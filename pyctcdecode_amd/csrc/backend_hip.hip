@@ -139,6 +139,20 @@ __device__ __forceinline__ uint64_t comb_max_f64(uint64_t a, uint64_t b) {
   return (uint64_t)__double_as_longlong(fmax(__longlong_as_double((long long)a), __longlong_as_double((long long)b)));
 }
 __device__ __forceinline__ uint64_t comb_max_u64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_i32(int v) {
+  const int o = __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = dpp_min_i32<0x111, 0xf>(v);
+  v = dpp_min_i32<0x112, 0xf>(v);
+  v = dpp_min_i32<0x114, 0xf>(v);
+  v = dpp_min_i32<0x118, 0xf>(v);
+  v = dpp_min_i32<0x142, 0xa>(v);
+  v = dpp_min_i32<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ double wave_sum(double x) {
   uint64_t v = (uint64_t)__double_as_longlong(x);
   CTC_DPP_REDUCE(v, 0ull, comb_add_f64);  // +0.0
@@ -569,11 +583,7 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
           first = r[k].x == mfw ? v0 : first;
         }
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(first, off, 64);
-        first = o < first ? o : first;
-      }
+      first = wave_min_i32(first);
       const double best = to_logp((double)mfw, false, m, lse);
       // survivors: an fp32 screen that cannot miss (threshold rounded down, with a margin far above the fp64
       // rounding of the exact test), then the exact fp64 test only in the 256-label chunks that have a candidate
