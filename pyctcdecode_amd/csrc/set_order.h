@@ -94,8 +94,12 @@ inline uint32_t set_table_cap(uint32_t n) {
     }
     if (size > cap) cap = size;
   }
-  // the copy made by `|` may be rebuilt at (used+1)*2 or used*2: never larger than the above
-  return cap;
+  // The copy made by `|` is sized in one step for used*2 (set_merge) or (used+1)*2 (the resize before the
+  // argmax is added): the smallest power of two above that. This can exceed the incremental sizes above
+  // (16 keys live in a 32-slot table, their union copy takes 64 slots), so it bounds the capacity too.
+  uint32_t merged = 8;
+  while (merged <= (n + 1) * 2) merged <<= 1;
+  return merged > cap ? merged : cap;
 }
 
 // asc: ascending ids (n of them). tabA/tabR/scratch: `cap` uint16 each. out: n+1 entries.

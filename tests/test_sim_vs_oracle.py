@@ -195,7 +195,10 @@ def test_frame_survivors_in_cpython_set_order(sim_library):  # noqa: F811
     from tests.survivor_util import check_against_cpython
 
     rng = np.random.default_rng(11)
-    for V, scale, tmin in [(29, 1.0, -5.0), (29, 3.0, -3.0), (300, 2.0, -5.0), (1024, 1.0, -6.5), (1024, 4.0, -5.0)]:
+    # (the near-uniform rows keep every label: 16-18, 64-76 and 256-306 members are the sizes whose union copy
+    # outgrows the table the set was built in -- the capacity bound once missed that)
+    for V, scale, tmin in [(29, 1.0, -5.0), (29, 3.0, -3.0), (300, 2.0, -5.0), (1024, 1.0, -6.5), (1024, 4.0, -5.0),
+                           (17, 0.05, -8.0), (18, 0.05, -8.0), (70, 0.05, -8.0), (76, 0.05, -8.0), (300, 0.05, -8.0)]:
         dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
         x = (rng.standard_normal((40, V)) * scale).astype(np.float32)
         check_against_cpython(dec, x, tmin, 1e-9)

@@ -1,0 +1,180 @@
+"""Random differential hunt: the sequential-sim build of the device code (through the full Python shell and
+C ABI) against the oracle, over random vocabularies / language models (single and multi) / hot words / decode
+arguments / input styles / chunkings.  TEST INFRASTRUCTURE (CPU only):  python tools/fuzz_sim_vs_oracle.py [n] [seed]
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+warnings.simplefilter("ignore")
+import logging  # noqa: E402
+
+logging.disable(logging.CRITICAL)
+
+import synth  # noqa: E402
+from oracle.arpa_lm import ArpaModel  # noqa: E402
+from oracle.ctc_oracle import LMOracle, MultiLMOracle, OracleDecoder, load_unigrams_from_arpa  # noqa: E402
+from pyctcdecode_amd import _binding as B  # noqa: E402
+from tests.golden_util import LM_DIR, TOY_ARPA, check_beams  # noqa: E402
+from tests.sim.build_sim import build  # noqa: E402
+
+B._LIB = B.Library(os.environ.get("FUZZ_LIB") or build())  # FUZZ_LIB: e.g. an AddressSanitizer build of the sim
+from pyctcdecode_amd.alphabet import Alphabet  # noqa: E402
+from pyctcdecode_amd.decoder import BeamSearchDecoderCTC  # noqa: E402
+from pyctcdecode_amd.language_model import HotwordScorer, LanguageModel, MultiLanguageModel, NgramModel  # noqa: E402
+
+WORDS = synth.make_words(300, seed=2)
+LM_SPECS = [(300, 400, 4, 2), (200, 300, 3, 3), (200, 300, 2, 1)]
+
+
+def lm_file(rng):
+    if rng.random() < 0.25:
+        return TOY_ARPA
+    nw, ns, order, seed = LM_SPECS[int(rng.integers(0, len(LM_SPECS)))]
+    return synth.SynthLM(LM_DIR, nw, ns, order=order, seed=seed).path
+
+
+def one_case(rng):
+    kind = rng.choice(["char", "toy", "bpe_small", "bpe255", "bpe1023"])
+    if kind == "char":
+        labels = list(synth.LIBRI_LABELS)
+    elif kind == "toy":
+        labels = [" ", "b", "g", "n", "s", "u", "y", ""]
+    elif kind == "bpe_small":
+        labels = ["<unk>", "▁", "a", "b", "▁a", "▁b", "▁bu", "gs", "nny", "▁bugs", "n", "y", "s", "g", "u"]
+    else:
+        labels = synth.make_bpe_vocab(WORDS, size=255 if kind == "bpe255" else 1023)
+    alpha = Alphabet.build_alphabet(labels)
+    n_lm = int(rng.choice([0, 1, 1, 1, 2, 3]))
+    members, olms = [], []
+    for _ in range(n_lm):
+        path = lm_file(rng)
+        r = rng.random()
+        uni = None if r < 0.15 else (sorted(load_unigrams_from_arpa(path))[: int(rng.integers(1, 80))] if r < 0.4
+                                     else sorted(load_unigrams_from_arpa(path)))
+        kw = dict(alpha=float(rng.choice([0.5, 0.0, 1.0, 0.7])), beta=float(rng.choice([1.5, 0.0, 3.0])),
+                  unk_score_offset=float(rng.choice([-10.0, 0.0, -4.0])), score_boundary=bool(rng.random() < 0.7))
+        members.append(LanguageModel(NgramModel(path), uni, **kw))
+        olms.append(LMOracle(ArpaModel(path), uni, kw["alpha"], kw["beta"], kw["unk_score_offset"], kw["score_boundary"]))
+    lm = None if n_lm == 0 else (members[0] if n_lm == 1 else MultiLanguageModel(members))
+    olm = None if n_lm == 0 else (olms[0] if n_lm == 1 else MultiLMOracle(olms))
+    dec = BeamSearchDecoderCTC(alpha, lm)
+    orc = OracleDecoder(alpha.labels, alpha.is_bpe, olm)
+    V = len(alpha.labels)
+    T = int(rng.integers(0, 45))
+    style = rng.choice(["normal", "peaky", "int", "prob", "masked", "words"])
+    if style == "normal":
+        x = rng.standard_normal((T, V)) * rng.choice([1.0, 1.5, 3.0])
+    elif style == "peaky":
+        x = rng.standard_normal((T, V))
+        if T:
+            x[np.arange(T), rng.integers(0, V, size=T)] += 6.0
+    elif style == "int":
+        # integer logits make every score difference an exact integer: massive ties. Exact ties are covered by the
+        # golden vectors; here a near-tie (1 ulp) straddling the beam-width cut would be decided by the last bit
+        # of exp/log, which legitimately differs between libm and numpy -- so the ties are broken by small noise
+        x = rng.integers(-8, 1, size=(T, V)).astype(np.float64) + 1e-3 * rng.standard_normal((T, V))
+    elif style == "prob":
+        e = np.exp(rng.standard_normal((T, V)) * 2)
+        x = e / e.sum(axis=1, keepdims=True) if T else e
+    elif style == "masked":
+        x = rng.standard_normal((T, V)) * 2
+        x[:, rng.random(V) < 0.3] = -np.inf
+        if T:
+            x[np.arange(T), rng.integers(0, V, size=T)] = 3.0  # at least one finite entry per row
+    else:
+        lm_a = synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2)
+        space = " " if " " in alpha.labels else "|"
+        try:
+            x = synth.d_words(2, int(rng.integers(0, 1000)), max(T, 1), labels, alpha.is_bpe, lm_a.words, lm_a.sentences,
+                              V - 1, boost=float(rng.choice([4.0, 6.0])), space_label=space).astype(np.float64)[:T]
+        except Exception:
+            x = rng.standard_normal((T, V))
+    dt = rng.choice(["f64", "f32", "f16"])
+    if dt == "f32":
+        x = x.astype(np.float32)
+    elif dt == "f16" and style not in ("prob",):
+        x = np.clip(x, -60000, 60000).astype(np.float16)
+    hot = None
+    if rng.random() < 0.4:
+        hot = [str(s) for s in rng.choice(["bugs", "bunny", "bun", "ab", "bugs bunny", "a", "zq", WORDS[3], WORDS[7]], size=3)]
+    dkw = dict(beam_width=int(rng.choice([1, 3, 10, 25, 100, 200])), beam_prune_logp=float(rng.choice([-3.0, -10.0, -30.0])),
+               token_min_logp=float(rng.choice([-5.0, -3.0, -8.0, 0.0])), prune_history=bool(rng.random() < 0.5),
+               hotwords=hot, hotword_weight=float(rng.choice([10.0, 3.0])))
+    return dec, orc, x, dkw
+
+
+def run_case(rng, execute=True):
+    dec, orc, x, dkw = one_case(rng)
+    if not execute:  # replaying the generator up to the case of interest (FUZZ_ONLY)
+        if x.shape[0] >= 2:
+            if rng.random() < 0.5:
+                rng.integers(0, x.shape[0] + 1, size=2)
+        return "skipped"
+    if os.environ.get("FUZZ_TRACE"):
+        print("   V=%d T=%d dtype=%s lm=%s %r" % (x.shape[1], x.shape[0], x.dtype, type(dec._language_model).__name__, dkw), flush=True)
+    x64 = x.astype(np.float64)
+    with np.errstate(all="ignore"):
+        try:
+            exp = orc.decode_beams(x64, **dkw)
+            err = None
+        except ValueError as e:
+            exp, err = None, e
+    try:
+        got = dec.decode_beams(x, **dkw)
+    except ValueError:
+        assert err is not None, "product raised ValueError, oracle did not"
+        return "both raise"
+    assert err is None, "oracle raised %r, product did not" % (err,)
+    tol = 1e-9 if x.dtype != np.float16 else 1e-9
+    expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], expd, tol=tol, what="whole")
+    # the same utterance in chunks through partial_decode_beams
+    T = x.shape[0]
+    if T >= 2 and rng.random() < 0.5:
+        cuts = sorted(set([0, T] + [int(c) for c in rng.integers(0, T + 1, size=2)]))
+        kw = {k: v for k, v in dkw.items() if k not in ("hotwords", "hotword_weight")}
+        kw["hotword_scorer"] = HotwordScorer.build_scorer(dkw["hotwords"], weight=dkw["hotword_weight"])
+        beams, c1, c2 = dec.get_starting_state()
+        st = orc.get_starting_state()
+        okw = {k: v for k, v in dkw.items()}
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            beams = dec.partial_decode_beams(x[a:b], c1, c2, beams, a, is_end=(b == T), **kw)
+            # chunked vs chunked: the BPE force_next_break flag is local to a call (decoder.py:442), so a chunk
+            # boundary may legitimately change the result -- the oracle is cut at the same places
+            with np.errstate(all="ignore"):
+                ob = orc.partial_decode_beams(x64[a:b], st, a, is_end=(b == T), **okw)
+            gotc = [(bm.text + "|" + bm.partial_word, [(str(k), f) for k, f in enumerate(bm.text_frames)] + [("p", bm.partial_frames)],
+                     bm.logit_score, bm.lm_score) for bm in beams]
+            expc = [{"text": o.text + "|" + o.partial, "frames": [[str(k), int(f[0]), int(f[1])] for k, f in enumerate(o.tframes)]
+                     + [["p", int(o.pframes[0]), int(o.pframes[1])]], "logit": o.logit, "lm": o.lm} for o in ob]
+            check_beams(gotc, expc, tol=1e-9, what="chunk %d:%d" % (a, b))
+        return "ok+chunked"
+    return "ok"
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    stats = {}
+    for i in range(n):
+        state = rng.bit_generator.state
+        if os.environ.get("FUZZ_TRACE"):
+            print("case", i, flush=True)
+        only = os.environ.get("FUZZ_ONLY")
+        try:
+            r = run_case(rng, execute=(only is None or int(only) == i))
+        except Exception:
+            print("FAILED case %d (seed %d); rng state before the case:\n%r" % (i, seed, state))
+            raise
+        stats[r] = stats.get(r, 0) + 1
+    print("sim == oracle on %d random cases (seed %d): %s" % (n, seed, stats))
+
+
+if __name__ == "__main__":
+    main()
