@@ -148,6 +148,36 @@ def run_case(rng, execute=True):
         if common_ok and only_g and only_e and twins(only_g, list(em.values())) and twins(only_e, list(gm.values())):
             return "near-tie at a cut"
         raise
+    # batch entry points: ragged batch (incl. an empty utterance) == utterance by utterance
+    if rng.random() < 0.25:
+        T0 = x.shape[0]
+        parts = [x, x[: T0 // 2], x[:0], x[T0 // 3:]]
+        bkw = {k: v for k, v in dkw.items() if k != "prune_history"}
+        texts = dec.decode_batch(None, parts, **bkw)
+        singles = [dec.decode(p_, **bkw) for p_ in parts]
+        assert texts == singles, ("decode_batch != decode", texts, singles)
+        bb = dec.decode_beams_batch(None, parts, **dkw)
+        for p_, beams_b in zip(parts, bb):
+            one = dec.decode_beams(p_, **dkw)
+            assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in one] == [
+                (o.text, o.text_frames, o.logit_score, o.lm_score) for o in beams_b], "decode_beams_batch != decode_beams"
+    # stateful decoding: the second half from the first half's last LM state (tests/test_decoder.py:426-456)
+    if dec._language_model is not None and x.shape[0] >= 4 and rng.random() < 0.25:
+        h = x.shape[0] // 2
+        first = dec.decode_beams(x[:h], **dkw)
+        with np.errstate(all="ignore"):
+            ofirst = orc.decode_beams(x64[:h], **dkw)
+        if first and ofirst and first[0].text == ofirst[0][0]:
+            second = dec.decode_beams(x[h:], lm_start_state=first[0].last_lm_state, **dkw)
+            with np.errstate(all="ignore"):
+                osecond = orc.decode_beams(x64[h:], lm_start_state=ofirst[0][1], **dkw)
+            expd2 = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in osecond]
+            try:
+                check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in second], expd2, tol=1e-9, what="stateful")
+            except AssertionError:
+                if x.dtype == np.float16:  # quantised logits: near-ties at cuts (see above)
+                    return "near-tie at a cut"
+                raise
     # the same utterance in chunks through partial_decode_beams
     T = x.shape[0]
     if T >= 2 and rng.random() < 0.5:
