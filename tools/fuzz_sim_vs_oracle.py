@@ -1,5 +1,5 @@
-"""Random differential hunt: the sequential-sim build of the device code (through the full Python shell and
-C ABI) against the oracle, over random vocabularies / language models (single and multi) / hot words / decode
+"""Random differential hunt: the sequential-sim build of the device code (or, with FUZZ_BACKEND=hip on a GPU box,
+the HIP build) through the full Python shell and C ABI against the oracle, over random vocabularies / language models (single and multi) / hot words / decode
 arguments / input styles / chunkings.  TEST INFRASTRUCTURE (CPU only):  python tools/fuzz_sim_vs_oracle.py [n] [seed]
 """
 import os
@@ -22,7 +22,10 @@ from pyctcdecode_amd import _binding as B  # noqa: E402
 from tests.golden_util import LM_DIR, TOY_ARPA, check_beams  # noqa: E402
 from tests.sim.build_sim import build  # noqa: E402
 
-B._LIB = B.Library(os.environ.get("FUZZ_LIB") or build())  # FUZZ_LIB: e.g. an AddressSanitizer build of the sim
+HIP = os.environ.get("FUZZ_BACKEND") == "hip"  # the product library on a GPU box instead of the sequential sim
+if not HIP:
+    B._LIB = B.Library(os.environ.get("FUZZ_LIB") or build())  # FUZZ_LIB: e.g. an AddressSanitizer build of the sim
+TOL = 1e-6 if HIP else 1e-9
 from pyctcdecode_amd.alphabet import Alphabet  # noqa: E402
 from pyctcdecode_amd.decoder import BeamSearchDecoderCTC  # noqa: E402
 from pyctcdecode_amd.language_model import HotwordScorer, LanguageModel, MultiLanguageModel, NgramModel  # noqa: E402
@@ -130,7 +133,7 @@ def run_case(rng, execute=True):
         assert err is not None, "product raised ValueError, oracle did not"
         return "both raise"
     assert err is None, "oracle raised %r, product did not" % (err,)
-    tol = 1e-9 if x.dtype != np.float16 else 1e-9
+    tol = TOL
     expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
     try:
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], expd, tol=tol, what="whole")
@@ -173,7 +176,7 @@ def run_case(rng, execute=True):
                 osecond = orc.decode_beams(x64[h:], lm_start_state=ofirst[0][1], **dkw)
             expd2 = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in osecond]
             try:
-                check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in second], expd2, tol=1e-9, what="stateful")
+                check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in second], expd2, tol=TOL, what="stateful")
             except AssertionError:
                 if x.dtype == np.float16:  # quantised logits: near-ties at cuts (see above)
                     return "near-tie at a cut"
@@ -197,7 +200,7 @@ def run_case(rng, execute=True):
                      bm.logit_score, bm.lm_score) for bm in beams]
             expc = [{"text": o.text + "|" + o.partial, "frames": [[str(k), int(f[0]), int(f[1])] for k, f in enumerate(o.tframes)]
                      + [["p", int(o.pframes[0]), int(o.pframes[1])]], "logit": o.logit, "lm": o.lm} for o in ob]
-            check_beams(gotc, expc, tol=1e-9, what="chunk %d:%d" % (a, b))
+            check_beams(gotc, expc, tol=TOL, what="chunk %d:%d" % (a, b))
         return "ok+chunked"
     return "ok"
 
@@ -218,7 +221,7 @@ def main():
             print("FAILED case %d (seed %d); rng state before the case:\n%r" % (i, seed, state))
             raise
         stats[r] = stats.get(r, 0) + 1
-    print("sim == oracle on %d random cases (seed %d): %s" % (n, seed, stats))
+    print("%s == oracle on %d random cases (seed %d): %s" % ("hip" if HIP else "sim", n, seed, stats))
 
 
 if __name__ == "__main__":
