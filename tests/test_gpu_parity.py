@@ -420,3 +420,12 @@ def test_hip_frame_survivors_in_cpython_set_order():
         border += check_against_cpython(dec, x, tmin, TOL)
         frames += 300
     assert border < frames // 20
+
+
+def test_hip_random_differential_slice():
+    """The same random differential hunt as tests/test_sim_vs_oracle.py, against the HIP build."""
+    from tools import fuzz_sim_vs_oracle as fuzz
+
+    _loaded_native()
+    stats = fuzz.run_many(60, 20260926, tol=TOL)
+    assert sum(stats.values()) == 60 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 57, stats

@@ -232,3 +232,12 @@ def test_decode_calls_from_several_host_threads(sim_library):  # noqa: F811
     for t in threads:
         t.join()
     assert not errs and got == want
+
+
+def test_random_differential_slice(sim_library):  # noqa: F811
+    """A fixed slice of tools/fuzz_sim_vs_oracle.py (random vocabularies / 0-3 language models / hot words /
+    decode arguments / input styles / chunkings / batch + stateful entry points) against the oracle."""
+    from tools import fuzz_sim_vs_oracle as fuzz
+
+    stats = fuzz.run_many(40, 20260925, tol=1e-9)
+    assert sum(stats.values()) == 40 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 38, stats

@@ -10,10 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-warnings.simplefilter("ignore")
 import logging  # noqa: E402
-
-logging.disable(logging.CRITICAL)
 
 import synth  # noqa: E402
 from oracle.arpa_lm import ArpaModel  # noqa: E402
@@ -23,9 +20,13 @@ from tests.golden_util import LM_DIR, TOY_ARPA, check_beams  # noqa: E402
 from tests.sim.build_sim import build  # noqa: E402
 
 HIP = os.environ.get("FUZZ_BACKEND") == "hip"  # the product library on a GPU box instead of the sequential sim
-if not HIP:
-    B._LIB = B.Library(os.environ.get("FUZZ_LIB") or build())  # FUZZ_LIB: e.g. an AddressSanitizer build of the sim
 TOL = 1e-6 if HIP else 1e-9
+
+
+def use_backend():
+    """Command-line use: pick the library (tests choose it themselves before calling run_many)."""
+    if not HIP:
+        B._LIB = B.Library(os.environ.get("FUZZ_LIB") or build())  # FUZZ_LIB: e.g. an AddressSanitizer build of the sim
 from pyctcdecode_amd.alphabet import Alphabet  # noqa: E402
 from pyctcdecode_amd.decoder import BeamSearchDecoderCTC  # noqa: E402
 from pyctcdecode_amd.language_model import HotwordScorer, LanguageModel, MultiLanguageModel, NgramModel  # noqa: E402
@@ -205,7 +206,23 @@ def run_case(rng, execute=True):
     return "ok"
 
 
+def run_many(n, seed, tol=None):
+    """n random cases from `seed` against whatever library pyctcdecode_amd currently uses; returns the outcome counts."""
+    global TOL
+    if tol is not None:
+        TOL = tol
+    rng = np.random.default_rng(seed)
+    stats = {}
+    for _ in range(n):
+        r = run_case(rng)
+        stats[r] = stats.get(r, 0) + 1
+    return stats
+
+
 def main():
+    warnings.simplefilter("ignore")
+    logging.disable(logging.CRITICAL)
+    use_backend()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
