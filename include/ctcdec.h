@@ -222,6 +222,11 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out);
 /* timing of the last call's device stages in milliseconds (HIP events on the decode stream):
  * [0] frame-prune kernel, [1] beam kernel, [2] total device time incl. result copy */
 int ctcdec_result_timing(const ctcdec_result* r, double* ms3);
+/* which beam kernel produced the result: 1 = one wavefront per utterance (csrc/beam_wave.h: one language model
+ * or none, beam_width <= 128, at most 160 survivors per frame), 2 = one workgroup per utterance
+ * (csrc/beam_core.h: everything else), 0 = empty batch. The environment variable CTCDEC_BEAM_KERNEL=group|wave
+ * forces one of them (tests and tuning). */
+int ctcdec_result_beam_kernel(const ctcdec_result* r);
 void ctcdec_result_free(ctcdec_result* r);
 
 /* Diagnostics: the frame-prune stage alone on one [n_frames, V] matrix -- per frame the labels
@@ -234,8 +239,10 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
                            int32_t* ids, double* logps);
 
 /* Diagnostics: enable/disable per-phase tick accumulation (100 MHz wall clock) for utterance 0 of the
- * following decode calls and read the 24 counters of the last one (0 load, 1 modes, 2 completions,
- * 3 keys, 4 merge, 5 score, 6 clear, 7 sort, 8 rebuild, 9 rest, 10 finalise). No reference analogue. */
+ * following decode calls and read the 24 counters of the last one. Workgroup kernel: 0 load, 1 modes,
+ * 2 completions, 3 keys, 4 merge, 5 score, 6 clear, 7 sort, 8 rebuild, 9 rest, 10 finalise (11.. sub-phases).
+ * Wave kernel: 0 load + modes, 1 completions, 2 candidate keys, 3 match, 4 fold, 5 score, 6 rank, 7 rebuild,
+ * 8 finalise, 9 pool compaction. No reference analogue. */
 int ctcdec_profile_phases(ctcdec_decoder* dec, int32_t enable, uint64_t* ticks_out, int32_t n);
 
 const char* ctcdec_last_error(void);

@@ -121,6 +121,7 @@ _PROTOS = {
     "ctcdec_result_lm_state_of": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LmState)]),
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "ctcdec_result_beam_kernel": (C.c_int, [_VP]),
     "ctcdec_result_free": (None, [_VP]),
     "ctcdec_profile_phases": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),
     "ctcdec_last_error": (C.c_char_p, []),

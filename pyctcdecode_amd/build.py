@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctcdec.so")
 SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip"]
-HEADERS = ["common.h", "beam_core.h", "set_order.h", "backend.h", "host_tables.h"]
+HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "backend.h", "host_tables.h"]
 
 
 def hipcc() -> str:

@@ -221,6 +221,7 @@ struct ctcdec_decoder {
 struct ctcdec_result {
   std::vector<std::vector<BeamResult>> utts;
   double ms[3] = {0, 0, 0};
+  int beam_kernel = 0;  // be::last_beam_kernel() of the launch that produced this result
   // packed view (built on demand by ctcdec_result_pack)
   bool packed = false;
   std::vector<int64_t> beam_off, text_off, word_cnt_off;
@@ -898,6 +899,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   }
   auto t_copy = std::chrono::steady_clock::now();
   be::last_timing(&res->ms[0], &res->ms[1]);
+  res->beam_kernel = be::last_beam_kernel();
   if (dec->profile && be::d2h(dec->prof, dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
   for (int32_t u = 0; u < n_utts; ++u)
@@ -1154,6 +1156,7 @@ int ctcdec_result_timing(const ctcdec_result* r, double* ms3) {
   ms3[2] = r->ms[2];
   return CTCDEC_OK;
 }
+int ctcdec_result_beam_kernel(const ctcdec_result* r) { return r ? r->beam_kernel : 0; }
 void ctcdec_result_free(ctcdec_result* r) { delete r; }
 
 }  // extern "C"

@@ -78,6 +78,9 @@ int launch_beam(const BeamArgs& a, std::string* err);
 
 // stage timing (ms) of the last launch_prune / launch_beam pair, measured on the decode stream
 void last_timing(double* prune_ms, double* beam_ms);
+// which beam kernel the last launch_beam used: 1 = one wave per utterance (beam_wave.h), 2 = one workgroup
+// per utterance (beam_core.h), 0 = none yet
+int last_beam_kernel();
 
 }  // namespace be
 }  // namespace ctc

@@ -17,6 +17,7 @@
 
 #include "backend.h"
 #include "beam_core.h"
+#include "beam_wave.h"
 #include "set_order.h"
 
 namespace ctc {
@@ -820,29 +821,153 @@ static int launch_beam_nt(const BeamArgs& a, const LdsShape& shape, size_t lds, 
   }
 }
 
-int launch_beam(const BeamArgs& a, std::string* err) {
-  LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
-  size_t lds = lds_bytes(shape);
-  if (lds > 160 * 1024) {
-    if (err) *err = "beam table does not fit LDS (" + std::to_string(lds) + " bytes)";
-    return -1;
+// ---------------------------------------------------------------------------------------------
+// wave kernel: one wavefront per utterance (beam_wave.h)
+// ---------------------------------------------------------------------------------------------
+struct WaveGpuCtx {
+  int lane;
+  // One wave issues its LDS operations in order: what the lanes exchange through LDS only needs the compiler
+  // to keep the program order of the accesses.
+  __device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  if (a.n_utts > 0) {
-    // Threads per utterance: four waves. Measured on MI355X (512 utterances, beam 100): 256 threads
-    // 16.4 ms, 128 threads 17.6 ms, 64 threads 20.4 ms -- the phases are short but wide enough that the
-    // extra lanes pay for the cross-wave barriers. CTCDEC_BEAM_THREADS overrides (tuning only).
-    int nt = 256;
-    if (const char* env = getenv("CTCDEC_BEAM_THREADS")) {
-      int v = atoi(env);
-      if (v == 64 || v == 128 || v == 256) nt = v;
+  // global stores of this wave complete before anything that follows
+  __device__ __forceinline__ void mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+  __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
+  __device__ __forceinline__ int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+  __device__ __forceinline__ int clz32(uint32_t x) { return __clz((int)x); }
+  __device__ __forceinline__ int ctz32(uint32_t x) { return __builtin_ctz(x); }
+  __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+  __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+  }
+  __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), s);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+    CTC_DPP_REDUCE(v, 0ull, comb_max_u64);
+    return bcast_lane63(v);
+  }
+  __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    // (status bits: rare) any lane with a bit set makes it wave-wide
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (__ballot((v >> b) & 1u)) r |= 1u << b;
+    return r | (v & ~0xFFu);
+  }
+  __device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v) {  // (finalisation only)
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+      if ((int)(threadIdx.x & 63) >= off) incl += o;
     }
+    return incl - v;
+  }
+  __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+  }
+  __device__ __forceinline__ void lds_max_u64(CTC_LDS uint64_t* p, uint64_t v) {
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __device__ __forceinline__ void lds_or_u32(CTC_LDS uint32_t* p, uint32_t v) {
+    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)wall_clock64(); }
+  __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {
+    return atomicAdd(p, v);
+  }
+};
+
+template <int BW>
+__global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int u = blockIdx.x;
+  WaveLds view;
+  wave_lds_carve<BW>(view, (lds_bytes_t)smem);
+  UttIO io;
+  const int64_t r0 = a.utt_row0[u];
+  io.surv_cnt = a.surv_cnt + r0;
+  io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
+  io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
+  io.T = (int32_t)(a.utt_row0[u + 1] - r0);
+  io.text_nodes = a.text_nodes + a.text_off[u];
+  io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
+  io.emit_nodes = a.emit_nodes + a.emit_off[u];
+  io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+  io.start_state = a.start_states ? a.start_states + (size_t)u : nullptr;
+  io.out_xstates = nullptr;
+  io.out = a.out + (size_t)u * a.out_stride;
+  io.n_out = a.n_out + u;
+  io.status = a.status + u;
+  io.tok_pool = a.tok_pool;
+  io.tok_pool_head = a.tok_pool_head;
+  io.tok_pool_cap = a.tok_pool_cap;
+  io.prof = (u == 0) ? a.prof : nullptr;
+  io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+  io.import_xstates = nullptr;
+  io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
+  WaveGpuCtx ctx{(int)threadIdx.x};
+  WaveDecoder<WaveGpuCtx, BW> dec(ctx, view, a.tables, a.params, io);
+  dec.run();
+}
+
+template <int BW>
+static int launch_wave_t(const BeamArgs& a, std::string* err) {
+  const size_t lds = wave_lds_bytes<BW>();
+  HIP_TRY(hipFuncSetAttribute((const void*)beam_wave<BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((beam_wave<BW>), dim3((unsigned)a.n_utts), dim3(64), lds, g_stream, a);
+  return 0;
+}
+
+static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
+int last_beam_kernel() { return g_last_kernel; }
+
+int launch_beam(const BeamArgs& a, std::string* err) {
+  const char* force = getenv("CTCDEC_BEAM_KERNEL");  // tuning / tests: "wave" or "group"
+  const bool want_group = force && force[0] == 'g';
+  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
     int rc;
-    if (a.tables.n_lms > 1) rc = launch_beam_nt<256, true>(a, shape, lds, err);  // MultiLanguageModel
-    else
-      rc = nt == 64 ? launch_beam_nt<64, false>(a, shape, lds, err)
-                    : nt == 128 ? launch_beam_nt<128, false>(a, shape, lds, err) : launch_beam_nt<256, false>(a, shape, lds, err);
+    switch (wave_bucket(a.params.beam_width)) {
+      case 32: rc = launch_wave_t<32>(a, err); break;
+      case 64: rc = launch_wave_t<64>(a, err); break;
+      default: rc = launch_wave_t<128>(a, err); break;
+    }
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
+    g_last_kernel = 1;
+  } else if (a.n_utts > 0) {
+    if (force && force[0] == 'w') {
+      if (err) *err = "CTCDEC_BEAM_KERNEL=wave, but this decode is not eligible for the wave kernel";
+      return -1;
+    }
+    LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
+    size_t lds = lds_bytes(shape);
+    if (lds > 160 * 1024) {
+      if (err) *err = "beam table does not fit LDS (" + std::to_string(lds) + " bytes)";
+      return -1;
+    }
+    // Threads per utterance: four waves (measured on MI355X, 512 utterances, beam 100: 256 threads 13.0 ms,
+    // 128 threads 15.2 ms, 64 threads 19.7 ms for this kernel).
+    int rc;
+    if (a.tables.n_lms > 1) rc = launch_beam_nt<256, true>(a, shape, lds, err);  // MultiLanguageModel
+    else rc = launch_beam_nt<256, false>(a, shape, lds, err);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    g_last_kernel = 2;
   }
   HIP_TRY(hipEventRecord(g_ev[2], g_stream));
   g_timing_valid = true;

@@ -382,6 +382,8 @@ class BeamSearchDecoderCTC:
         self._lib.dll.ctcdec_result_timing(res, ms)
         # [frame-prune kernels, beam kernel (HIP events on the decode stream), whole native call]
         self.last_timing_ms = (float(ms[0]), float(ms[1]), float(ms[2]))
+        # 1: one wavefront per utterance (beam_wave.h), 2: one workgroup per utterance (beam_core.h)
+        self.last_beam_kernel = int(self._lib.dll.ctcdec_result_beam_kernel(res))
         return res
 
     def _unpack(self, res: C.c_void_p, with_state: bool) -> List[List[OutputBeam]]:

@@ -12,6 +12,8 @@
 
 #include "../../pyctcdecode_amd/csrc/backend.h"
 #include "../../pyctcdecode_amd/csrc/beam_core.h"
+#include "../../pyctcdecode_amd/csrc/beam_wave.h"
+#include "wave_fibers.h"
 #include "../../pyctcdecode_amd/csrc/set_order.h"
 
 namespace ctc {
@@ -132,7 +134,73 @@ int launch_prune(const PruneArgs& a, std::string*) {
   return 0;
 }
 
-int launch_beam(const BeamArgs& a, std::string*) {
+static void fill_io(const BeamArgs& a, int u, UttIO& io) {
+  int64_t r0 = a.utt_row0[u];
+  io.surv_cnt = a.surv_cnt + r0;
+  io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
+  io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
+  io.T = (int32_t)(a.utt_row0[u + 1] - r0);
+  io.text_nodes = a.text_nodes + a.text_off[u];
+  io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
+  io.emit_nodes = a.emit_nodes + a.emit_off[u];
+  io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+  const uint32_t n_lms = a.tables.n_lms > 1 ? a.tables.n_lms : 1u;
+  io.start_state = a.start_states ? a.start_states + (size_t)u * n_lms : nullptr;
+  io.out_xstates = a.out_xstates ? a.out_xstates + (size_t)u * a.out_stride * (n_lms - 1) : nullptr;
+  io.out = a.out + (size_t)u * a.out_stride;
+  io.n_out = a.n_out + u;
+  io.status = a.status + u;
+  io.tok_pool = a.tok_pool;
+  io.tok_pool_head = a.tok_pool_head;
+  io.tok_pool_cap = a.tok_pool_cap;
+  io.prof = nullptr;
+  io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+  io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
+  io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
+}
+
+// one wavefront per utterance (beam_wave.h) on 64 cooperative fibers
+template <int BW>
+static void run_wave(const BeamArgs& a) {
+  const size_t bytes = wave_lds_bytes<BW>();
+  std::vector<char> lds(bytes + 64);
+  char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
+  for (int u = 0; u < a.n_utts; ++u) {
+    memset(base, 0xCD, bytes);  // poison: catch reads of never-written LDS
+    WaveLds view;
+    wave_lds_carve<BW>(view, base);
+    UttIO io;
+    fill_io(a, u, io);
+    wavesim::Wave wave;
+    wave.run([&](int lane) {
+      wavesim::SimWaveCtx ctx{lane, &wave};
+      WaveDecoder<wavesim::SimWaveCtx, BW> dec(ctx, view, a.tables, a.params, io);
+      dec.run();
+    });
+  }
+}
+
+static int g_last_kernel = 0;
+int last_beam_kernel() { return g_last_kernel; }
+
+int launch_beam(const BeamArgs& a, std::string* err) {
+  const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend
+  const bool want_group = force && force[0] == 'g';
+  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
+    switch (wave_bucket(a.params.beam_width)) {
+      case 32: run_wave<32>(a); break;
+      case 64: run_wave<64>(a); break;
+      default: run_wave<128>(a); break;
+    }
+    g_last_kernel = 1;
+    return 0;
+  }
+  if (force && force[0] == 'w' && a.n_utts > 0) {
+    if (err) *err = "CTCDEC_BEAM_KERNEL=wave, but this decode is not eligible for the wave kernel";
+    return -1;
+  }
+  if (a.n_utts > 0) g_last_kernel = 2;
   LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
   size_t bytes = lds_bytes(shape);
   std::vector<char> lds(bytes + 64);
@@ -142,29 +210,8 @@ int launch_beam(const BeamArgs& a, std::string*) {
     LdsView view;
     lds_carve(view, base, shape);
     UttIO io;
-    int64_t r0 = a.utt_row0[u];
-    io.surv_cnt = a.surv_cnt + r0;
-    io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
-    io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
-    io.T = (int32_t)(a.utt_row0[u + 1] - r0);
-    io.text_nodes = a.text_nodes + a.text_off[u];
-    io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
-    io.emit_nodes = a.emit_nodes + a.emit_off[u];
-    io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+    fill_io(a, u, io);
     const uint32_t n_lms = a.tables.n_lms > 1 ? a.tables.n_lms : 1u;
-    io.start_state = a.start_states ? a.start_states + (size_t)u * n_lms : nullptr;
-    io.out_xstates = a.out_xstates ? a.out_xstates + (size_t)u * a.out_stride * (n_lms - 1) : nullptr;
-    io.out = a.out + (size_t)u * a.out_stride;
-    io.n_out = a.n_out + u;
-    io.status = a.status + u;
-    io.tok_pool = a.tok_pool;
-    io.tok_pool_head = a.tok_pool_head;
-    io.tok_pool_cap = a.tok_pool_cap;
-    io.prof = nullptr;
-    io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
-    io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
-    io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
-    io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
     SeqCtx ctx;
     if (n_lms > 1) {
       BeamDecoder<SeqCtx, true> dec(ctx, view, shape, a.tables, a.params, io);
