@@ -41,9 +41,9 @@ def build_assets(cache_dir, n_words, n_sent):
     return lm, labels, hot
 
 
-def make_batch(lm, labels, first_utt, n_utts, frames):
+def make_batch(lm, labels, first_utt, n_utts, frames, boost=6.0):
     return [synth.d_words(CONFIG_ID, first_utt + u, frames, labels, True, lm.words, lm.sentences, len(labels),
-                          boost=6.0) for u in range(n_utts)]
+                          boost=boost) for u in range(n_utts)]
 
 
 def cpu_baseline(lm, labels, hot, xs, cores):
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="headline", choices=["headline", "config2"],
                     help="headline = BASELINE metric config; config2 = 29-char alphabet, no LM, D_flat stress (diagnostics)")
+    ap.add_argument("--boost", type=float, default=6.0, help="D_words peak boost (6.0 = headline; diagnostics otherwise)")
     ap.add_argument("--phases", action="store_true", help="print the per-phase tick breakdown of utterance 0")
     ap.add_argument("--cpu-sample", type=int, default=0, help="utterances in the CPU sample (0: eight per core)")
     args = ap.parse_args()
@@ -122,7 +123,7 @@ def main():
         if rank != 0:
             lm, labels, hot = build_assets(cache, args.lm_words, args.lm_sentences)
         log("assets ready")
-        xs = make_batch(lm, labels, rank * args.batch, args.batch, args.frames)
+        xs = make_batch(lm, labels, rank * args.batch, args.batch, args.frames, args.boost)
     log("batch generated")
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -179,6 +180,9 @@ def main():
         names = ["load", "modes", "completions(bar)", "keys", "merge", "score(bar)", "clear", "sort.rank", "rebuild.tail",
                  "rest", "finalise", "comp.src", "comp.probe", "comp.store", "score.fold", "score.probe", "score.push",
                  "sort.zero", "sort.compact", "rebuild.hist", "rebuild.dup", "rebuild.build", "comp.syncmem", "pool.prune"]
+        if getattr(decoder, "last_beam_kernel", 0) == 1:
+            names = ["modes", "comp.end", "keys", "match", "fold", "score", "rank", "build.write", "finalise", "compact",
+                     "push", "prefetch_tok", "build.gather", "fetch", "comp.begin"] + ["-"] * 9
         tot = float(sum(ticks)) or 1.0
         log("phase ticks (utterance 0, 100 MHz): " + ", ".join(
             "%s %.0f us (%.0f%%)" % (n, t / 100.0, 100.0 * t / tot) for n, t in zip(names, ticks) if t))

@@ -844,6 +844,11 @@ struct WaveGpuCtx {
   __device__ __forceinline__ int clz32(uint32_t x) { return __clz((int)x); }
   __device__ __forceinline__ int ctz32(uint32_t x) { return __builtin_ctz(x); }
   __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+  // the value, but nothing computed from it may be scheduled above this point
+  __device__ __forceinline__ uint32_t opaque32(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  }
   __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
   }
@@ -942,8 +947,8 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
     int rc;
     switch (wave_bucket(a.params.beam_width)) {
-      case 32: rc = launch_wave_t<32>(a, err); break;
       case 64: rc = launch_wave_t<64>(a, err); break;
+      case 104: rc = launch_wave_t<104>(a, err); break;
       default: rc = launch_wave_t<128>(a, err); break;
     }
     if (rc) return rc;

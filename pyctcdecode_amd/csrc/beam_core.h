@@ -1025,7 +1025,7 @@ CTC_UNROLL
       // first probe of both tables issued together (one memory round trip instead of two)
       const bool want_p = (m2 & PF_ON_TABLE) && tab.prefixes && new_part_h != 0;
       const bool want_h = (m2 & M2_HOT_ON) && tab.hot && new_part_h != 0;
-      const uint64_t hk = mix64(new_part_h);
+      const uint64_t hk = table_slot(new_part_h);
       uint64_t sp = hk & tab.prefix_mask, sh = hk & tab.hot_mask;
       PrefixEntry ep = {0, 0, 0};
       HotEntry eh = {0, 0, 0};
@@ -1091,7 +1091,7 @@ CTC_UNROLL
         kp = str_concat(kp, tk.pow_raw(), tk.h_raw());
         if (q == (uint32_t)ctx.tid && kp != 0) {
           const uint32_t m2 = b.meta2[i];
-          const uint64_t hk = mix64(kp);
+          const uint64_t hk = table_slot(kp);
           if ((m2 & PF_ON_TABLE) && tab.prefixes) pre_p = tab.prefixes[hk & tab.prefix_mask];
           if ((m2 & M2_HOT_ON) && tab.hot) pre_h = tab.hot[hk & tab.hot_mask];
           have_pre = true;

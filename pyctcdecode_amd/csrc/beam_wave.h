@@ -26,6 +26,7 @@
 namespace ctc {
 
 typedef uint32_t u32x4 __attribute__((vector_size(16)));
+typedef uint32_t u32x4a __attribute__((vector_size(16), may_alias));  // 16-byte view of a structure in global memory
 
 CTC_HD uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 CTC_HD double bits_f64(uint64_t u) {
@@ -38,6 +39,16 @@ CTC_HD uint64_t f64_bits(double d) {
   c.d = d;
   return c.u;
 }
+CTC_HD float bits_f32(uint32_t u) {
+  union { uint32_t u; float f; } c;
+  c.u = u;
+  return c.f;
+}
+CTC_HD uint32_t f32_bits(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  return c.u;
+}
 CTC_HD u32x4 mk4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   u32x4 r = {a, b, c, d};
   return r;
@@ -47,6 +58,19 @@ CTC_HD u32x4 mk4q(uint64_t a, uint64_t b) {
 }
 CTC_HD uint64_t q_lo(u32x4 v) { return pack64(v[0], v[1]); }
 CTC_HD uint64_t q_hi(u32x4 v) { return pack64(v[2], v[3]); }
+
+CTC_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// History of a text: its last n_hist word hashes (newest first) folded to 64 bits. The words are 61-bit
+// polynomial hashes: xor under distinct rotations keeps equal tuples equal and makes unequal ones collide with
+// probability ~2^-61 (no multiplies: this runs for every completed word).
+CTC_HD uint64_t wave_hist_fold(const uint64_t* ring, uint32_t cnt) {
+  uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(cnt + 1u);
+CTC_UNROLL
+  for (int k = 0; k < MAX_CTX; ++k)
+    if ((uint32_t)k < cnt) h ^= rotl64(ring[k], 13 * k + 1);
+  return h;
+}
 
 // bijective 64-bit finaliser (cheaper than mix64: one multiply)
 CTC_HD uint64_t fin64(uint64_t x) {
@@ -60,29 +84,32 @@ CTC_HD uint64_t fin64(uint64_t x) {
 //   0: text_h, part_h          1: logit, meta1, meta2       2: c_text_h, lm_hw     3: c_lm_hw, pscore
 //   4: hist_h, c_hist_h        5: text_node, comp_node, emit_node, word_id         6: pstart, pend, depth, -
 constexpr int BREC = 7;
-constexpr int WAVE_LAB = 64;        // label records staged in LDS (survivors [0, 64) of the frame)
-constexpr int WAVE_SURV_CAP = 160;  // survivors per frame this kernel handles (default token_min_logp: 150)
+constexpr int WAVE_LAB = 64;        // survivors are staged in LDS (ids, modes, label constants) 64 at a time
+constexpr int WAVE_SURV_CAP = 480;  // survivors per frame this kernel handles: arrival = s * N + beam has to fit 16 bits
 
 template <int BW>
 struct WaveShape {
-  static constexpr int SLB = (BW + 63) / 64;  // beam / candidate slots per lane
-  static constexpr int C = 64 * SLB;          // candidates per pass
-  static constexpr int P = BW + C;            // pool capacity: the kept beam_width + one pass of new ones
-  static constexpr int PE = (P + 63) / 64;    // pool entries per lane
-  static constexpr int TS = 2 * C;            // match-table slots
+  static constexpr int SLB = (BW + 63) / 64;      // beam slots per lane (lane = beam phases)
+  static constexpr bool BIG = BW > 64;            // frames with more than 64 live beams can occur
+  static constexpr int C = BIG ? 128 : 64;        // candidates that share one match table
+  static constexpr int P = BW + (BIG ? BW : 64);  // pool capacity: the kept beam_width + one pass of new ones
+  static constexpr int PE = (P + 63) / 64;        // pool entries per lane
+  static constexpr int TS = 2 * C;                // match-table slots
 };
 
 struct WaveLds {
   LPtr<u32x4> beams;     // [BW * BREC]
-  LPtr<u32x4> surv;      // [WAVE_SURV_CAP]  {id, mode word, lp lo, lp hi}
+  LPtr<u32x4> surv;      // [WAVE_LAB]       {id, mode word, lp lo, lp hi}
   LPtr<u32x4> lab;       // [WAVE_LAB * 3]   {h_raw, pow_raw} {h_clean, len_raw, len_clean} {flags, start_flags, start_word_id, hot}
   LPtr<double> c_logit;  // [C]
+  LPtr<uint32_t> c_br;   // [C]   branch of the candidate (the donor's is what the new beam is built from) | representative << 8
   LPtr<uint64_t> table;  // [TS]
   LPtr<u32x4> gmask;     // [C]   members of the group a candidate represents
   LPtr<u32x4> rank_rec;  // [P]   {score key, history key}; aliases c_logit/table/gmask (used between passes only)
-  LPtr<double> p_score, p_logit;
-  LPtr<uint64_t> p_hk;
-  LPtr<uint32_t> p_arr, p_don, p_wid, p_m2;
+  // pool of merged, scored candidates: 3 chunks per entry
+  //   0: score, history key     1: logit, new partial hash     2: arrival | new plen << 16, donor word, word id, meta2
+  // donor word: beam index | label << 8 | label is blank << 29 | donor's branch << 30
+  LPtr<u32x4> pool;      // [P * 3]
   LPtr<uint32_t> sel;    // [BW]
   // scalar views of the beam records
   LPtr<uint64_t> b64;
@@ -100,22 +127,17 @@ CTC_HD size_t wave_lds_carve(WaveLds& o, lds_bytes_t base) {
   o.bf64.p = (CTC_LDS double*)o.beams.p;
   o.b32.p = (CTC_LDS uint32_t*)o.beams.p;
   o.bi32.p = (CTC_LDS int32_t*)o.beams.p;
-  o.surv = lds_take<u32x4>(p, 16 * WAVE_SURV_CAP);
+  o.surv = lds_take<u32x4>(p, 16 * WAVE_LAB);
   o.lab = lds_take<u32x4>(p, 16 * 3 * WAVE_LAB);
-  o.p_score = lds_take<double>(p, 8 * S::P);
-  o.p_logit = lds_take<double>(p, 8 * S::P);
-  o.p_hk = lds_take<uint64_t>(p, 8 * S::P);
-  o.p_arr = lds_take<uint32_t>(p, 4 * S::P);
-  o.p_don = lds_take<uint32_t>(p, 4 * S::P);
-  o.p_wid = lds_take<uint32_t>(p, 4 * S::P);
-  o.p_m2 = lds_take<uint32_t>(p, 4 * S::P);
+  o.pool = lds_take<u32x4>(p, 48 * S::P);
   o.sel = lds_take<uint32_t>(p, 4 * BW);
   lds_bytes_t shared0 = p;
   o.c_logit = lds_take<double>(p, 8 * S::C);
+  o.c_br = lds_take<uint32_t>(p, 4 * S::C);
   o.table = lds_take<uint64_t>(p, 8 * S::TS);
   o.gmask = lds_take<u32x4>(p, 16 * S::C);
   lds_bytes_t q = shared0;
-  o.rank_rec = lds_take<u32x4>(q, 16 * S::P);
+  o.rank_rec = lds_take<u32x4>(q, 16 * S::P + 4 * S::P);  // + the compaction index list
   if (q > p) p = q;
   return (size_t)(p - base);
 }
@@ -129,10 +151,11 @@ CTC_HD size_t wave_lds_bytes() {
 CTC_HD bool wave_eligible(const DeviceTables& t, const DecodeParams& p) {
   return t.n_lms <= 1 && p.beam_width <= 128 && p.max_surv <= WAVE_SURV_CAP;
 }
-CTC_HD int wave_bucket(int beam_width) { return beam_width <= 32 ? 32 : beam_width <= 64 ? 64 : 128; }
+CTC_HD int wave_bucket(int beam_width) { return beam_width <= 64 ? 64 : beam_width <= 104 ? 104 : 128; }
 
 constexpr int W_PROF_LOAD = 0, W_PROF_COMP = 1, W_PROF_GEN = 2, W_PROF_MATCH = 3, W_PROF_FOLD = 4, W_PROF_SCORE = 5,
-              W_PROF_RANK = 6, W_PROF_BUILD = 7, W_PROF_FINAL = 8, W_PROF_COMPACT = 9, W_PROF_N = 10;
+              W_PROF_RANK = 6, W_PROF_BUILD = 7, W_PROF_FINAL = 8, W_PROF_COMPACT = 9, W_PROF_PUSH = 10, W_PROF_PFTOK = 11,
+              W_PROF_GATHER = 12, W_PROF_FETCH = 13, W_PROF_BEGIN = 14, W_PROF_N = 15;
 
 template <class Ctx, int BW>
 struct WaveDecoder {
@@ -164,8 +187,33 @@ struct WaveDecoder {
   bool pf_live = false;
   uint64_t pt_h_raw = 0, pt_pow_raw = 0, pt_h_clean = 0;
   uint32_t pt_len_raw = 0, pt_len_clean = 0, pt_flags = TK_BLANK, pt_start_flags = 0, pt_start_word_id = 0, pt_hot = 0;
-  unsigned long long t_last = 0;
-  unsigned long long t_acc[W_PROF_N] = {};
+  // completions in flight (lane = beam): source node fetched at the start of the frame, n-gram probes issued
+  // before the candidates are generated, everything resolved after the match
+  // What the completion of beam (slot, lane) needs, fetched as raw 16-byte chunks and decoded where it is
+  // used (a loaded register that is repacked or copied right away has to be waited for right away).
+  // Only beam slot 0 (beams 0..63) defers its completion across the candidate generation; slot 1 (more than
+  // 64 live beams: rare) completes on the spot, which keeps ~70 registers per lane out of the long live ranges.
+  bool cp_cand = false, cp_todo = false;
+  uint32_t cp_idx = 0, cp_wid = 0, cp_m2 = 0;
+  uint64_t cp_part = 0, cp_text = 0, cp_ring3 = 0;
+  double cp_raw = 0.0;
+  u32x4 cp_c2, cp_c3, cp_c4, cp_c5, cp_c6;  // TextNode chunks 2..6 of the source node
+  // n-gram probes of slot 0 in flight: unigram entry, first table entry of the orders 2..6, their keys
+  uint64_t cp_u = 0;
+  u32x4 cp_e[MAX_CTX];
+  uint64_t cp_k[MAX_CTX];
+  int cp_max_n = 1;
+  bool comp_pending = false;
+  // emission nodes of the beams built last frame: their stores are issued in the NEXT frame right after its
+  // last load has been consumed -- on gfx9 stores and loads share vmcnt, so a load consumed while a store is
+  // still pending waits for the store's acknowledgement as well (measured: ~5 us per frame when the stores sat
+  // in front of the next loads)
+  bool em_pending = false;
+  bool em_has[SLB];
+  uint32_t em_idx[SLB];
+  u32x4 em_node[SLB];
+  bool tok_pending = false;  // the label constants of the next frame's survivors still have to be fetched
+  unsigned long long t_last = 0;  // (diagnostics: phase ticks are accumulated in global memory, not registers)
 
   CTC_HD WaveDecoder(Ctx& c, WaveLds& l, const DeviceTables& t, const DecodeParams& p, const UttIO& i)
       : ctx(c), L(l), tab(t), prm(p), io(i), lane(c.lane) {}
@@ -174,7 +222,7 @@ struct WaveDecoder {
   CTC_HD void tick() {
     if (io.prof && lane == 0) {
       unsigned long long now = ctx.clock();
-      t_acc[PHASE] += now - t_last;
+      io.prof[PHASE] += now - t_last;
       t_last = now;
     }
   }
@@ -191,46 +239,12 @@ struct WaveDecoder {
   }
   CTC_HD uint32_t prefix_cnt(uint64_t m) const { return (uint32_t)ctx.popc64(m & ((1ull << lane) - 1ull)); }
 
-  struct Lab {  // label constants of one survivor
-    uint64_t h_raw, pow_raw, h_clean;
-    uint32_t len_raw, len_clean, flags, start_flags, start_word_id, hot_min, hot_complete;
-  };
-  // label constants of survivor s whose label id is c: LDS for the staged ones, L2 beyond
-  CTC_HD Lab label_of(uint32_t s, uint32_t c) const {
-    Lab r;
-    if (s < (uint32_t)WAVE_LAB) {
-      const u32x4 a = L.lab[s * 3], b = L.lab[s * 3 + 1], d = L.lab[s * 3 + 2];
-      r.h_raw = q_lo(a);
-      r.pow_raw = q_hi(a);
-      r.h_clean = q_lo(b);
-      r.len_raw = b[2];
-      r.len_clean = b[3];
-      r.flags = d[0];
-      r.start_flags = d[1];
-      r.start_word_id = d[2];
-      r.hot_min = d[3] & 0xFFFFu;
-      r.hot_complete = d[3] >> 31;
-    } else {
-      const TokInfo& g = tab.tok[c];
-      r.h_raw = g.h_raw;
-      r.pow_raw = g.pow_raw;
-      r.h_clean = g.h_clean;
-      r.len_raw = g.len_raw;
-      r.len_clean = g.len_clean;
-      r.flags = g.flags;
-      r.start_flags = g.start_flags;
-      r.start_word_id = g.start_word_id;
-      r.hot_min = tab.tok_hot ? tab.tok_hot[c].min_len : 0u;
-      r.hot_complete = tab.tok_hot ? tab.tok_hot[c].complete : 0u;
-    }
-    return r;
-  }
-
-  CTC_HD static uint32_t branch_of(uint32_t tflags, uint32_t mode_word, uint32_t c, uint32_t i, uint32_t last_char) {
-    if ((tflags & TK_BLANK) || last_char == c) return 0;  // keep prefix (blank / repeat)   decoder.py:452
+  // mode word of a survivor: branch mode | first non-repeating beam << 8 | label flags (TK_*) << 16
+  CTC_HD static uint32_t branch_of(uint32_t mode_word, uint32_t c, uint32_t i, uint32_t last_char) {
+    if ((mode_word & (TK_BLANK << 16)) || last_char == c) return 0;  // keep prefix (blank / repeat)   decoder.py:452
     const uint32_t mode = mode_word & 0xFFu;
     if (mode == MODE_ALL_B) return BR_BOUNDARY;
-    if (mode == MODE_FIRST_B) return i == (mode_word >> 8) ? BR_BOUNDARY : BR_APPEND;
+    if (mode == MODE_FIRST_B) return i == ((mode_word >> 8) & 0xFFu) ? BR_BOUNDARY : BR_APPEND;
     if (mode == MODE_C) return BR_SPACE;
     return BR_APPEND;
   }
@@ -238,15 +252,24 @@ struct WaveDecoder {
   // ---- survivor prefetch (one frame ahead) --------------------------------------------------
   CTC_HD void prefetch(int t) {
     pf_live = t < io.T;
+    tok_pending = pf_live;
     if (!pf_live) return;
-    pf_cnt = ctx.uni32(io.surv_cnt[t]);
-    if ((uint32_t)lane < pf_cnt) {
+    // (every lane loads the same count; it is only read -- and made a scalar -- once it has landed)
+    pf_cnt = io.surv_cnt[t];
+    if (lane < prm.max_surv) {
       pf_id = io.surv_id[(size_t)t * prm.max_surv + lane];
       pf_lp = io.surv_lp[(size_t)t * prm.max_surv + lane];
     }
   }
   CTC_HD void prefetch_tok() {  // second stage, issued once the ids above have landed
-    if (!pf_live || (uint32_t)lane >= pf_cnt) return;
+    tok_pending = false;
+    if (!pf_live) return;
+    // (opaque: keeps the compiler from evaluating anything that depends on the prefetched registers earlier
+    // than here -- it once hoisted `lane < pf_cnt` out of the pass loop to right behind the loads, which put
+    // a full memory round trip at the start of every frame)
+    pf_cnt = ctx.opaque32(pf_cnt);
+    pf_id = ctx.opaque32(pf_id);
+    if ((uint32_t)lane >= pf_cnt) return;
     const TokInfo& g = tab.tok[pf_id];
     pt_h_raw = g.h_raw;
     pt_pow_raw = g.pow_raw;
@@ -268,7 +291,7 @@ struct WaveDecoder {
     if (!tab.is_bpe) {
       const uint32_t mode = blank ? MODE_A : ((fl & TK_SPACE) ? MODE_C : MODE_D);
       if (ctx.ballot(!blank && mode == MODE_C) != 0ull) need = 1u;
-      return mode | ((uint32_t)N << 8);
+      return mode | ((uint32_t)(N & 0xFF) << 8) | (fl << 16);
     }
     uint32_t first = (uint32_t)N;
     if (!blank) first = (c != lc0) ? 0u : f1;
@@ -287,88 +310,247 @@ struct WaveDecoder {
     else if (f_in && any) mode = trail ? MODE_ALL_B : MODE_FIRST_B;
     if (ctx.ballot(any && mode != MODE_D) != 0ull) need = 1u;
     if (m_set) fflag = (uint32_t)((m_one >> (63 - ctx.clz64(m_set))) & 1ull);
-    return mode | (first << 8);
+    return mode | ((first & 0xFFu) << 8) | (fl << 16);  // (first <= 128; only compared with beam indices < N)
   }
 
   // ---- completion of a beam's open word: the (text (+) partial) prefix ------------------------
   // One TextNode per completed prefix (the reference's memo entry, decoder.py:387-396); lane = beam.
-  CTC_HD void completions() {
+  struct CompSrc {  // what a completion needs from the beam's record and its text node
+    uint32_t wid, m2;
+    uint64_t part, text, ring3;
+    double raw;
+    u32x4 c2, c3, c4, c5, c6;
+  };
+  CTC_HD void comp_fetch(CompSrc& q, int i, u32x4 k1, u32x4 k5) {
+    q.wid = k5[3];
+    q.m2 = k1[3];
+    const u32x4 k0 = L.beams[i * BREC];
+    q.text = q_lo(k0);
+    q.part = q_hi(k0);
+    // TextNode as 16-byte chunks: 0 text_h, raw_lm | 2 hw_cnt, ring_cnt, state.len, words[0] | 3 words[1..4]
+    // | 4 backoff[0..3] | 5 backoff[4], pad, ring[0] | 6 ring[1], ring[2] | 7 ring[3], ring[4]
+    const TextNode& sn = io.text_nodes[k5[0]];
+    const u32x4a* src = (const u32x4a*)&sn;
+    q.raw = sn.raw_lm;
+    q.c2 = src[2];
+    q.c3 = src[3];
+    q.c4 = src[4];
+    q.c5 = src[5];
+    q.c6 = src[6];
+    q.ring3 = sn.ring[3];
+  }
+  CTC_HD static LmState comp_state(const CompSrc& q) {
+    LmState st;
+    st.len = (int32_t)q.c2[2];
+    st.words[0] = q.c2[3];
+    st.words[1] = q.c3[0];
+    st.words[2] = q.c3[1];
+    st.words[3] = q.c3[2];
+    st.words[4] = q.c3[3];
+    st.backoff[0] = bits_f32(q.c4[0]);
+    st.backoff[1] = bits_f32(q.c4[1]);
+    st.backoff[2] = bits_f32(q.c4[2]);
+    st.backoff[3] = bits_f32(q.c4[3]);
+    st.backoff[4] = bits_f32(q.c5[0]);
+    return st;
+  }
+  // fetch (beams 0..63): issued at the start of the frame, before it is known whether any label closes a word --
+  // the loads are cheap and land while the branch modes are worked out. Returns the last label of this lane's
+  // beam of slot 0 / 1 through lc[].
+  CTC_HD void completions_fetch(uint32_t* lc) {
+    cp_cand = false;
+    cp_todo = false;
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
-      if (j * 64 >= N) break;
+      lc[j] = 0;
+      if (j * 64 >= N) continue;
       const int i = j * 64 + lane;
-      bool todo = false;
-      uint32_t tnode = 0, wid = 0, m2 = 0;
-      uint64_t part_h = 0;
       if (i < N) {
-        const u32x4 k1 = L.beams[i * BREC + 1], k5 = L.beams[i * BREC + 5];
-        todo = (k1[2] >> 16) > 0 && k5[1] == 0;
-        tnode = k5[0];
-        wid = k5[3];
-        m2 = k1[3];
-        part_h = L.b64[i * 14 + 1];
-      }
-      const uint64_t m = ctx.ballot(todo);
-      if (!m) continue;
-      uint32_t idx = text_next + prefix_cnt(m);
-      text_next += (uint32_t)ctx.popc64(m);
-      if (todo) {
-        if (idx + 1 > io.text_cap) {
-          status |= ST_TEXT_OVERFLOW;  // (made uniform at the end of the frame)
-          idx = io.text_cap - 1;
-        }
-        const TextNode& src = io.text_nodes[tnode];
-        TextNode& dst = io.text_nodes[idx];
-        double raw = src.raw_lm;
-        if (tab.has_lm) {
-          LmState st;
-          st.len = src.state.len;
-CTC_UNROLL
-          for (int k = 0; k < MAX_CTX; ++k) {
-            st.words[k] = src.state.words[k];
-            st.backoff[k] = src.state.backoff[k];
-          }
-          const float base = lm_base_score(tab, st, wid, &dst.state);
-          raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
-        } else {
-          dst.state.len = src.state.len;
-CTC_UNROLL
-          for (int k = 0; k < MAX_CTX; ++k) {
-            dst.state.words[k] = src.state.words[k];
-            dst.state.backoff[k] = src.state.backoff[k];
+        const u32x4 k1 = L.beams[i * BREC + 1];
+        lc[j] = k1[2] & 0xFFFFu;
+        if (j == 0) {
+          const u32x4 k5 = L.beams[i * BREC + 5];
+          cp_cand = (k1[2] >> 16) > 0 && k5[1] == 0;
+          if (cp_cand) {
+            CompSrc q;
+            comp_fetch(q, i, k1, k5);
+            cp_wid = q.wid;
+            cp_m2 = q.m2;
+            cp_text = q.text;
+            cp_part = q.part;
+            cp_ring3 = q.ring3;
+            cp_raw = q.raw;
+            cp_c2 = q.c2;
+            cp_c3 = q.c3;
+            cp_c4 = q.c4;
+            cp_c5 = q.c5;
+            cp_c6 = q.c6;
           }
         }
-        const uint64_t th = text_push(src.text_h, part_h);
-        const uint32_t cnt = src.hw_cnt + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
-        const double lmhw = raw + prm.hot_weight * (double)cnt;
-        const uint32_t rc = src.ring_cnt + 1 > tab.n_hist ? tab.n_hist : src.ring_cnt + 1;
-        uint64_t hh = 0x9E3779B97F4A7C15ull + rc;
-CTC_UNROLL
-        for (int k = MAX_CTX - 1; k >= 0; --k) {
-          const uint64_t rk = k == 0 ? part_h : ((uint32_t)k < rc ? src.ring[k > 0 ? k - 1 : 0] : 0ull);
-          dst.ring[k] = rk;
-          if ((uint32_t)k < rc) hh = mix64(hh ^ rk) + 0x632BE59BD9B4E019ull;
-        }
-        dst.text_h = th;
-        dst.raw_lm = raw;
-        dst.lm_hw = lmhw;
-        dst.hist_h = hh;
-        dst.hw_cnt = cnt;
-        dst.ring_cnt = rc;
-        dst.pad0 = 0;
-        L.b64[i * 14 + 4] = th;      // c_text_h
-        L.bf64[i * 14 + 6] = lmhw;   // c_lm_hw
-        L.b64[i * 14 + 9] = hh;      // c_hist_h
-        L.b32[i * 28 + 21] = idx;    // comp_node
       }
     }
   }
+  CTC_HD CompSrc cp_src() const {
+    CompSrc q;
+    q.wid = cp_wid;
+    q.m2 = cp_m2;
+    q.text = cp_text;
+    q.part = cp_part;
+    q.ring3 = cp_ring3;
+    q.raw = cp_raw;
+    q.c2 = cp_c2;
+    q.c3 = cp_c3;
+    q.c4 = cp_c4;
+    q.c5 = cp_c5;
+    q.c6 = cp_c6;
+    return q;
+  }
+  // node index + the completed text's hash (all the candidate keys need) for the beams of slot j that need it
+  CTC_HD uint32_t comp_alloc(bool todo, int i, uint64_t text, uint64_t part) {
+    const uint64_t m = ctx.ballot(todo);
+    uint32_t idx = text_next + prefix_cnt(m);
+    text_next += (uint32_t)ctx.popc64(m);
+    if (todo) {
+      if (idx + 1 > io.text_cap) {
+        status |= ST_TEXT_OVERFLOW;  // (made wave-wide at the end of the frame)
+        idx = io.text_cap - 1;
+      }
+      L.b64[i * 14 + 4] = text_push(text, part);  // c_text_h
+      L.b32[i * 28 + 21] = idx;                    // comp_node
+    }
+    return idx;
+  }
+  // begin: beams 0..63 get their node index and issue their n-gram probes (resolved by completions_end after
+  // the match); beams 64.. (more than 64 live beams: rare) are completed on the spot
+  CTC_HD void completions_begin() {
+    cp_todo = cp_cand;
+    if (ctx.ballot(cp_todo) != 0ull) {
+      comp_pending = true;
+      cp_idx = comp_alloc(cp_todo, lane, cp_text, cp_part);
+      if (cp_todo && tab.has_lm) {
+        // the keys of all orders share one chain, newest word first (common.h); every first table entry is
+        // loaded as one 16-byte tuple straight into the register quad it stays in until completions_end
+        const LmState in = comp_state(cp_src());
+        const uint32_t wid = cp_wid;
+        const UnigramEntry* up = &tab.unigrams[wid];
+        cp_u = *(const uint64_t*)up;
+        const int in_len = in.len;
+        const int max_n = !tab.ngrams ? 1 : ((int)tab.lm_order < in_len + 1 ? (int)tab.lm_order : in_len + 1);
+        cp_max_n = max_n;
+        uint64_t c = ngram_key_push(ngram_key_begin(), wid);
+CTC_UNROLL
+        for (int k = 0; k < MAX_CTX; ++k) {
+          cp_k[k] = 0;
+          cp_e[k] = mk4(0, 0, 0, 0);
+          if (max_n >= k + 2) {
+            c = ngram_key_push(c, in.words[k]);
+            cp_k[k] = ngram_key_end(c, (uint32_t)(k + 2));
+            cp_e[k] = *(const u32x4a*)&tab.ngrams[cp_k[k] & tab.ngram_mask];
+          }
+        }
+      }
+    }
+    if (SLB > 1 && N > 64) {
+      const int i = 64 + lane;
+      bool todo = false;
+      u32x4 k1 = mk4(0, 0, 0, 0), k5 = mk4(0, 0, 0, 0);
+      if (i < N) {
+        k1 = L.beams[i * BREC + 1];
+        k5 = L.beams[i * BREC + 5];
+        todo = (k1[2] >> 16) > 0 && k5[1] == 0;
+      }
+      if (ctx.ballot(todo) != 0ull) {
+        CompSrc q;
+        q.wid = q.m2 = 0;
+        q.text = q.part = q.ring3 = 0;
+        q.raw = 0.0;
+        q.c2 = q.c3 = q.c4 = q.c5 = q.c6 = mk4(0, 0, 0, 0);
+        if (todo) comp_fetch(q, i, k1, k5);
+        const uint32_t idx = comp_alloc(todo, i, q.text, q.part);
+        if (todo) completion_finish(q, i, idx, false);
+      }
+    }
+  }
+  CTC_HD uint64_t opaque64(uint64_t v) { return pack64(ctx.opaque32((uint32_t)v), ctx.opaque32((uint32_t)(v >> 32))); }
+  CTC_HD static NgramEntry entry_of(u32x4 r) {
+    NgramEntry e;
+    e.key = q_lo(r);
+    e.prob = bits_f32(r[2]);
+    e.backoff = bits_f32(r[3]);
+    return e;
+  }
+  // LM score of the closed word, hot-word count, history ring; the node and the beam's memo fields.
+  // probed: the n-gram probes of this lane were issued by completions_begin.
+  CTC_HD void completion_finish(const CompSrc& q, int i, uint32_t idx, bool probed) {
+    const uint32_t m2 = q.m2;
+    double raw = q.raw;
+    const LmState in = comp_state(q);
+    LmState out = in;
+    if (tab.has_lm) {
+      float base;
+      if (probed) {
+        LmProbe p;
+        // the probe results are used HERE: this call sits in the pass loop, and everything computed from
+        // these loop-invariant registers would otherwise be hoisted to right behind the loads (a memory
+        // round trip in front of the candidate generation instead of hidden behind it)
+        const uint64_t u = opaque64(cp_u);
+        p.u.prob = bits_f32((uint32_t)u);
+        p.u.backoff = bits_f32((uint32_t)(u >> 32));
+        p.max_n = cp_max_n;
+        u32x4 e[MAX_CTX];
+CTC_UNROLL
+        for (int k = 0; k < MAX_CTX; ++k)
+          e[k] = mk4(ctx.opaque32(cp_e[k][0]), ctx.opaque32(cp_e[k][1]), ctx.opaque32(cp_e[k][2]), ctx.opaque32(cp_e[k][3]));
+        p.k2 = cp_k[0]; p.k3 = cp_k[1]; p.k4 = cp_k[2]; p.k5 = cp_k[3]; p.k6 = cp_k[4];
+        p.s2 = p.k2 & tab.ngram_mask; p.s3 = p.k3 & tab.ngram_mask; p.s4 = p.k4 & tab.ngram_mask;
+        p.s5 = p.k5 & tab.ngram_mask; p.s6 = p.k6 & tab.ngram_mask;
+        p.e2 = entry_of(e[0]); p.e3 = entry_of(e[1]); p.e4 = entry_of(e[2]); p.e5 = entry_of(e[3]); p.e6 = entry_of(e[4]);
+        base = lm_probe_finish(tab, in, q.wid, p, &out);
+      } else {
+        base = lm_base_score(tab, in, q.wid, &out);
+      }
+      raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
+    }
+    const uint64_t part_h = q.part;
+    const uint32_t cnt = q.c2[0] + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
+    const double lmhw = raw + prm.hot_weight * (double)cnt;
+    const uint32_t rc0 = q.c2[1];
+    const uint32_t rc = rc0 + 1 > tab.n_hist ? tab.n_hist : rc0 + 1;
+    // history ring, newest first: the closed word, then the source node's (its fifth entry always drops out)
+    const uint64_t old0 = pack64(q.c5[2], q.c5[3]), old1 = q_lo(q.c6), old2 = q_hi(q.c6), old3 = q.ring3;
+    uint64_t ring[MAX_CTX];
+    ring[0] = part_h;
+    ring[1] = 1u < rc ? old0 : 0ull;
+    ring[2] = 2u < rc ? old1 : 0ull;
+    ring[3] = 3u < rc ? old2 : 0ull;
+    ring[4] = 4u < rc ? old3 : 0ull;
+    const uint64_t hh = wave_hist_fold(ring, rc);
+    const uint64_t th = text_push(q.text, part_h);
+    u32x4a* dst = (u32x4a*)&io.text_nodes[idx];
+    dst[0] = mk4q(th, f64_bits(raw));
+    dst[1] = mk4q(f64_bits(lmhw), hh);
+    dst[2] = mk4(cnt, rc, (uint32_t)out.len, out.words[0]);
+    dst[3] = mk4(out.words[1], out.words[2], out.words[3], out.words[4]);
+    dst[4] = mk4(f32_bits(out.backoff[0]), f32_bits(out.backoff[1]), f32_bits(out.backoff[2]), f32_bits(out.backoff[3]));
+    dst[5] = mk4(f32_bits(out.backoff[4]), 0u, (uint32_t)ring[0], (uint32_t)(ring[0] >> 32));
+    dst[6] = mk4q(ring[1], ring[2]);
+    dst[7] = mk4q(ring[3], ring[4]);
+    L.bf64[i * 14 + 6] = lmhw;   // c_lm_hw
+    L.b64[i * 14 + 9] = hh;      // c_hist_h
+  }
+  CTC_HD void completions_end() {
+    if (cp_todo) completion_finish(cp_src(), lane, cp_idx, true);
+    cp_todo = false;
+    comp_pending = false;
+  }
 
-  // The partial word a candidate ends up with, seen through the prefix / hot-word tables.
-  struct PartView {
-    uint32_t pl, m2, wid;
-    double ps;
-  };
+  CTC_HD void flush_emits() {
+    if (!em_pending) return;
+CTC_UNROLL
+    for (int j = 0; j < SLB; ++j)
+      if (em_has[j]) *(u32x4a*)&io.emit_nodes[em_idx[j]] = em_node[j];
+    em_pending = false;
+  }
 
   // ---- pool ranking --------------------------------------------------------------------------
   // Ranks the pool entries with score >= thr by (score desc, arrival asc); L.sel[r] = pool index of rank r
@@ -376,71 +558,134 @@ CTC_UNROLL
   CTC_HD uint32_t rank_pool(double thr, bool with_hist) {
     const uint32_t n = pool_n;
     const uint32_t want = (uint32_t)prm.beam_width;
-    uint64_t key[PE], hk[PE];
-    bool pass[PE];
+    if (n <= 64u) {
+      // the usual frame: one entry per lane, keys stay in registers; each passing entry is broadcast in turn
+      // (readlane) and counted by the lanes it beats -- no LDS round trips at all
+      const uint32_t e = (uint32_t)lane;
+      const bool mine = e < n;
+      u32x4 p0 = mk4(0, 0, 0, 0);
+      if (mine) p0 = L.pool[e * 3];
+      const double sc = bits_f64(q_lo(p0));
+      const bool ok = mine && sc >= thr;
+      const uint64_t key = ok ? score_sort_key(sc) : ~0ull;
+      const uint64_t hk = with_hist ? q_hi(p0) : 0ull;
+      const uint64_t pm = ctx.ballot(ok);
+      uint32_t rank = 0, same = 0, dup = 0;
+      if (with_hist) {
+        for (uint64_t m = pm; m; m &= m - 1ull) {
+          const int j = ctx.ctz64(m);
+          const uint64_t x = ctx.bcast64(key, j), xh = ctx.bcast64(hk, j);
+          const bool better = x < key;
+          rank += better ? 1u : 0u;
+          same += x == key ? 1u : 0u;
+          dup |= (better && xh == hk) ? 1u : 0u;
+        }
+      } else {
+        for (uint64_t m = pm; m; m &= m - 1ull) {
+          const int j = ctx.ctz64(m);
+          const uint64_t x = ctx.bcast64(key, j);
+          rank += x < key ? 1u : 0u;
+          same += x == key ? 1u : 0u;
+        }
+      }
+      if (ctx.ballot(ok && same > 1u) != 0ull) {  // equal scores (rare): the earlier arrival ranks first
+        const uint32_t arr = mine ? (L.pool[e * 3 + 2][0] & 0xFFFFu) : 0u;
+        for (uint64_t m = pm; m; m &= m - 1ull) {
+          const int j = ctx.ctz64(m);
+          const uint64_t x = ctx.bcast64(key, j), xh = ctx.bcast64(hk, j);
+          const uint32_t xa = ctx.bcast32(arr, j);
+          const bool before = ok && x == key && xa < arr;
+          rank += before ? 1u : 0u;
+          dup |= (before && xh == hk) ? 1u : 0u;
+        }
+      }
+      if (ok && rank < want) L.sel[rank] = e | ((with_hist && dup) ? 0u : 0x80000000u);
+      ctx.wsync();
+      return (uint32_t)ctx.popc64(pm);
+    }
+    // Larger pools (heavy frames): the entries that pass the threshold are first compacted (usually far fewer
+    // than the pool holds, and mostly <= 64 again), then ranked out of registers the same way, R compacted
+    // entries per lane.
+    LPtr<uint32_t> ridx;  // pool index of compacted entry q (behind the P rank records)
+    ridx.p = (CTC_LDS uint32_t*)(L.rank_rec.p + P);
     uint32_t n_pass = 0;
 CTC_UNROLL
     for (int k = 0; k < PE; ++k) {
+      if ((uint32_t)(k * 64) >= n) continue;
       const uint32_t e = (uint32_t)(k * 64 + lane);
-      pass[k] = false;
-      key[k] = ~0ull;
-      hk[k] = 0;
-      if ((uint32_t)(k * 64) < n) {
-        if (e < n) {
-          const double sc = L.p_score[e];
-          pass[k] = sc >= thr;
-          if (pass[k]) key[k] = score_sort_key(sc);
-          hk[k] = with_hist ? L.p_hk[e] : 0ull;
-          L.rank_rec[e] = mk4q(key[k], hk[k]);
-        }
-        n_pass += (uint32_t)ctx.popc64(ctx.ballot(pass[k]));
+      u32x4 p0 = mk4(0, 0, 0, 0);
+      if (e < n) p0 = L.pool[e * 3];
+      const double sc = bits_f64(q_lo(p0));
+      const bool ok = e < n && sc >= thr;
+      const uint64_t bm = ctx.ballot(ok);
+      if (ok) {
+        const uint32_t q = n_pass + prefix_cnt(bm);
+        L.rank_rec[q] = mk4q(score_sort_key(sc), with_hist ? q_hi(p0) : 0ull);
+        ridx[q] = e;
       }
+      n_pass += (uint32_t)ctx.popc64(bm);
     }
     ctx.wsync();
+    const uint32_t R = (n_pass + 63u) >> 6;  // compacted entries per lane (1 in all but the heaviest frames)
+    uint64_t key[PE], hk[PE];
     uint32_t rank[PE], same[PE], dup[PE];
 CTC_UNROLL
-    for (int k = 0; k < PE; ++k) rank[k] = same[k] = dup[k] = 0;
-    for (uint32_t j = 0; j < n; ++j) {  // every lane reads the same record: an LDS broadcast
-      const u32x4 r = L.rank_rec[j];
-      const uint64_t x = q_lo(r), xh = q_hi(r);
+    for (int k = 0; k < PE; ++k) {
+      const uint32_t q = (uint32_t)(k * 64 + lane);
+      key[k] = ~0ull;
+      hk[k] = 0;
+      rank[k] = same[k] = dup[k] = 0;
+      if ((uint32_t)k < R && q < n_pass) {
+        const u32x4 r = L.rank_rec[q];
+        key[k] = q_lo(r);
+        hk[k] = q_hi(r);
+      }
+    }
 CTC_UNROLL
-      for (int k = 0; k < PE; ++k) {
-        if ((uint32_t)(k * 64) < n) {
-          const bool better = x < key[k];
-          rank[k] += better ? 1u : 0u;
-          same[k] += x == key[k] ? 1u : 0u;
-          dup[k] |= (better && xh == hk[k]) ? 1u : 0u;
+    for (int kk = 0; kk < PE; ++kk) {  // broadcast every compacted entry in turn
+      if ((uint32_t)kk >= R) continue;
+      const uint32_t cnt = n_pass - (uint32_t)(kk * 64) < 64u ? n_pass - (uint32_t)(kk * 64) : 64u;
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint64_t x = ctx.bcast64(key[kk], (int)j), xh = ctx.bcast64(hk[kk], (int)j);
+CTC_UNROLL
+        for (int k = 0; k < PE; ++k) {
+          if ((uint32_t)k < R) {
+            const bool better = x < key[k];
+            rank[k] += better ? 1u : 0u;
+            same[k] += x == key[k] ? 1u : 0u;
+            dup[k] |= (better && xh == hk[k]) ? 1u : 0u;
+          }
         }
       }
     }
     // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
     bool tie = false;
+    uint32_t eidx[PE];
 CTC_UNROLL
-    for (int k = 0; k < PE; ++k) tie = tie || (pass[k] && same[k] > 1u);
+    for (int k = 0; k < PE; ++k) {
+      const uint32_t q = (uint32_t)(k * 64 + lane);
+      eidx[k] = ((uint32_t)k < R && q < n_pass) ? ridx[q] : 0u;
+      tie = tie || (key[k] != ~0ull && same[k] > 1u);
+    }
     if (ctx.ballot(tie) != 0ull) {
       uint32_t arr[PE];
 CTC_UNROLL
-      for (int k = 0; k < PE; ++k) {
-        const uint32_t e = (uint32_t)(k * 64 + lane);
-        arr[k] = e < n ? L.p_arr[e] : 0u;
-      }
-      for (uint32_t j = 0; j < n; ++j) {
+      for (int k = 0; k < PE; ++k) arr[k] = key[k] != ~0ull ? (L.pool[eidx[k] * 3 + 2][0] & 0xFFFFu) : 0u;
+      for (uint32_t j = 0; j < n_pass; ++j) {
         const u32x4 r = L.rank_rec[j];
         const uint64_t x = q_lo(r), xh = q_hi(r);
-        const uint32_t xa = L.p_arr[j];
+        const uint32_t xa = L.pool[ridx[j] * 3 + 2][0] & 0xFFFFu;
 CTC_UNROLL
         for (int k = 0; k < PE; ++k) {
-          const bool before = pass[k] && x == key[k] && xa < arr[k];
+          const bool before = key[k] != ~0ull && x == key[k] && xa < arr[k];
           rank[k] += before ? 1u : 0u;
           dup[k] |= (before && xh == hk[k]) ? 1u : 0u;
         }
       }
     }
 CTC_UNROLL
-    for (int k = 0; k < PE; ++k) {
-      const uint32_t e = (uint32_t)(k * 64 + lane);
-      if (pass[k] && rank[k] < want) L.sel[rank[k]] = e | ((with_hist && dup[k]) ? 0u : 0x80000000u);
-    }
+    for (int k = 0; k < PE; ++k)
+      if (key[k] != ~0ull && rank[k] < want) L.sel[rank[k]] = eidx[k] | ((with_hist && dup[k]) ? 0u : 0x80000000u);
     ctx.wsync();
     return n_pass;
   }
@@ -450,25 +695,19 @@ CTC_UNROLL
     const double mx = key_to_score(runmax);
     uint32_t n = rank_pool(mx + prm.beam_prune_logp, false);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
-    double g_score[SLB], g_logit[SLB];
-    uint64_t g_hk[SLB];
-    uint32_t g_arr[SLB], g_don[SLB], g_wid[SLB], g_m2[SLB];
+    u32x4 g0[SLB], g1[SLB], g2[SLB];
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const uint32_t r = (uint32_t)(j * 64 + lane);
-      g_score[j] = 0.0;
-      g_logit[j] = 0.0;
-      g_hk[j] = 0;
-      g_arr[j] = g_don[j] = g_wid[j] = g_m2[j] = 0;
+      g0[j] = g1[j] = g2[j] = mk4(0, 0, 0, 0);
       if (r < n) {
         const uint32_t e = L.sel[r] & 0x7FFFFFFFu;
-        g_score[j] = L.p_score[e];
-        g_logit[j] = L.p_logit[e];
-        g_hk[j] = L.p_hk[e];
-        g_arr[j] = L.p_arr[e];
-        g_don[j] = L.p_don[e];
-        g_wid[j] = L.p_wid[e];
-        g_m2[j] = L.p_m2[e];
+#ifdef CTC_SIM_DEBUG
+        if (e >= (uint32_t)P) { fprintf(stderr, "compact: r=%u n=%u pool_n=%u sel=%x N=%d\n", r, n, pool_n, L.sel[r], N); abort(); }
+#endif
+        g0[j] = L.pool[e * 3];
+        g1[j] = L.pool[e * 3 + 1];
+        g2[j] = L.pool[e * 3 + 2];
       }
     }
     ctx.wsync();
@@ -476,13 +715,9 @@ CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const uint32_t r = (uint32_t)(j * 64 + lane);
       if (r < n) {
-        L.p_score[r] = g_score[j];
-        L.p_logit[r] = g_logit[j];
-        L.p_hk[r] = g_hk[j];
-        L.p_arr[r] = g_arr[j];
-        L.p_don[r] = g_don[j];
-        L.p_wid[r] = g_wid[j];
-        L.p_m2[r] = g_m2[j];
+        L.pool[r * 3] = g0[j];
+        L.pool[r * 3 + 1] = g1[j];
+        L.pool[r * 3 + 2] = g2[j];
       }
     }
     pool_n = n;
@@ -493,162 +728,207 @@ CTC_UNROLL
       uint64_t k = 0;
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j)
-        if ((int)(r >> 6) == j) k = ctx.bcast64(asc_key(g_score[j]), (int)(r & 63u));
+        if ((int)(r >> 6) == j) k = ctx.bcast64(asc_key(bits_f64(q_lo(g0[j]))), (int)(r & 63u));
       kth_key = k;
     }
     ctx.wsync();
   }
 
-  // ---- one pass: candidates of the labels [s0, s1) -----------------------------------------------
-  CTC_HD void pass(uint32_t s0, uint32_t s1) {
-    const uint32_t Nn = (uint32_t)N;
-    const uint32_t Q = (s1 - s0) * Nn;
-    const uint32_t rcpN = Nn ? 65536u / Nn + 1u : 0u;  // v / N == (v * rcpN) >> 16 for v * N < 65536
-    bool valid[SLB], is_rep[SLB];
-    uint32_t bi[SLB], ls[SLB], lid[SLB], br[SLB], rep[SLB], pl0[SLB], m2_0[SLB];
-    uint64_t kp[SLB], ck[SLB];
-    double lg[SLB];
-    Lab lb[SLB];
-    uint64_t c_hist_sel[SLB];  // history hash the candidate's text ends up with
-    double lmhw_sel[SLB];
-    PrefixEntry pre_p[SLB];
-    HotEntry pre_h[SLB];
-    bool want_p[SLB], want_h[SLB];
-    // clear the match table and the member masks
-CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
-      const int v = j * 64 + lane;
-      L.gmask[v] = mk4(0, 0, 0, 0);
-      ((CTC_LDS u32x4*)L.table.p)[v] = mk4(0, 0, 0, 0);
-    }
-    // ---- generation: branch, merge key, summed logit
-CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
-      const uint32_t v = (uint32_t)(j * 64 + lane);
-      valid[j] = v < Q;
-      is_rep[j] = false;
-      bi[j] = ls[j] = lid[j] = br[j] = pl0[j] = m2_0[j] = 0;
-      rep[j] = v;
-      kp[j] = ck[j] = 0;
-      lg[j] = 0.0;
-      c_hist_sel[j] = 0;
-      lmhw_sel[j] = 0.0;
-      want_p[j] = want_h[j] = false;
-      pre_p[j].key = 0; pre_p[j].word_id = 0; pre_p[j].flags = 0;
-      pre_h[j].key = 0; pre_h[j].min_len = 0; pre_h[j].complete = 0;
-      if ((uint32_t)(j * 64) >= Q) continue;
-      if (valid[j]) {
-        const uint32_t sl = (v * rcpN) >> 16;
-        const uint32_t i = v - sl * Nn;
-        const uint32_t s = s0 + sl;
-        bi[j] = i;
-        ls[j] = s;
-        const u32x4 sv = L.surv[s];
-        lid[j] = sv[0];
-        lb[j] = label_of(s, sv[0]);
-        const u32x4 k0 = L.beams[i * BREC], k1 = L.beams[i * BREC + 1], k2 = L.beams[i * BREC + 2];
-        const u32x4 k4 = L.beams[i * BREC + 4];
-        const uint32_t meta1 = k1[2];
-        const uint32_t pl = meta1 >> 16;
-        pl0[j] = pl;
-        m2_0[j] = k1[3];
-        const uint32_t b = branch_of(lb[j].flags, sv[1], sv[0], i, meta1 & 0xFFFFu);
-        br[j] = b;
-        uint64_t kt = q_lo(k0), p = q_hi(k0);
-        uint64_t hh = q_lo(k4);
-        double lmhw = bits_f64(q_hi(k2));
-        if (b == BR_BOUNDARY || b == BR_SPACE) {
-          if (pl > 0) {
-            kt = q_lo(k2);                      // c_text_h
-            hh = q_hi(k4);                      // c_hist_h
-            lmhw = L.bf64[i * 14 + 6];          // c_lm_hw
+  // ---- candidates ------------------------------------------------------------------------------------
+  // A pass takes whole labels: floor(64 * SLB / N) of them, candidate v = j * 64 + lane (up to SLB per lane);
+  // with more than 64 live beams that is ONE label and v is the beam index.
+  struct Cand {
+    bool valid, is_rep, want_p, want_h;
+    uint32_t v, bi, ls, ll, lid, mw, br, rep, pl0, m2_0, len_raw, tslot;
+    uint64_t kp, ck, pp_key, ph_key;
+    uint32_t pp_wid, pp_fl, ph_min, ph_cmp;
+    double lg, lmhw;
+  };
+
+  // branch, merge key and summed logit of candidate (label l of the staged block = survivor s, beam i);
+  // FULL: also the first probe of the prefix / hot-word table of an appended partial word
+  template <bool FULL>
+  CTC_HD void gen(Cand& c, bool valid, uint32_t v, uint32_t l, uint32_t s, uint32_t i) {
+    c.valid = valid;
+    c.is_rep = false;
+    c.want_p = c.want_h = false;
+    c.v = v;
+    c.bi = i;
+    c.ls = s;
+    c.ll = l;
+    c.lid = c.mw = c.br = c.pl0 = c.m2_0 = c.len_raw = c.tslot = 0;
+    c.rep = v;
+    c.kp = c.ck = c.pp_key = c.ph_key = 0;
+    c.pp_wid = c.pp_fl = c.ph_min = c.ph_cmp = 0;
+    c.lg = c.lmhw = 0.0;
+    if (valid) {
+      const u32x4 sv = L.surv[l];
+      const u32x4 la = L.lab[l * 3], lb = L.lab[l * 3 + 1];
+      const u32x4 k0 = L.beams[i * BREC], k1 = L.beams[i * BREC + 1], k2 = L.beams[i * BREC + 2];
+      c.lid = sv[0];
+      c.mw = sv[1];
+      c.len_raw = lb[2];
+      const uint32_t meta1 = k1[2];
+      const uint32_t pl = meta1 >> 16;
+      c.pl0 = pl;
+      c.m2_0 = k1[3];
+      const uint32_t b = branch_of(sv[1], sv[0], i, meta1 & 0xFFFFu);
+      c.br = b;
+      uint64_t kt = q_lo(k0), p = q_hi(k0);
+      if (b == BR_BOUNDARY || b == BR_SPACE) {
+        if (pl > 0) kt = q_lo(k2);  // c_text_h (the rest of the completion may still be in flight)
+        p = b == BR_BOUNDARY ? q_lo(lb) : 0;  // h_clean
+      } else if (b == BR_APPEND) {
+        p = str_concat(p, q_hi(la), q_lo(la));  // pow_raw, h_raw
+        if (FULL && p != 0) {
+          c.tslot = (uint32_t)table_slot(p);
+          c.want_p = (k1[3] & PF_ON_TABLE) && tab.prefixes;
+          c.want_h = (k1[3] & M2_HOT_ON) && tab.hot;
+          if (c.want_p) {
+            const PrefixEntry& g = tab.prefixes[c.tslot & tab.prefix_mask];
+            c.pp_key = g.key;
+            c.pp_wid = g.word_id;
+            c.pp_fl = g.flags;
           }
-          p = b == BR_BOUNDARY ? lb[j].h_clean : 0;
-        } else if (b == BR_APPEND) {
-          p = str_concat(p, lb[j].pow_raw, lb[j].h_raw);
-          // first probe of both tables issued here: in flight across the match
-          if (p != 0) {
-            const uint64_t hk = mix64(p);
-            want_p[j] = (k1[3] & PF_ON_TABLE) && tab.prefixes;
-            want_h[j] = (k1[3] & M2_HOT_ON) && tab.hot;
-            if (want_p[j]) pre_p[j] = tab.prefixes[hk & tab.prefix_mask];
-            if (want_h[j]) pre_h[j] = tab.hot[hk & tab.hot_mask];
+          if (c.want_h) {
+            const HotEntry& g = tab.hot[c.tslot & tab.hot_mask];
+            c.ph_key = g.key;
+            c.ph_min = g.min_len;
+            c.ph_cmp = g.complete;
           }
         }
-        kp[j] = p;
-        c_hist_sel[j] = hh;
-        lmhw_sel[j] = lmhw;
-        ck[j] = fin64(kt * 0x9E3779B97F4A7C15ull + p * 0xC2B2AE3D27D4EB4Full + (uint64_t)(sl + 1u) * 0x165667B19E3779F9ull);
-        lg[j] = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
-        L.c_logit[v] = lg[j];
       }
+      c.kp = p;
+      c.lmhw = bits_f64(q_hi(k2));
+      c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
+      c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
     }
-    ctx.wsync();
-    tick<W_PROF_GEN>();
-    // ---- match: the smallest candidate of the largest tag owns a slot; the others of its key join it, the
-    // rest move to their next slot (different key bits, then linear)
-    {
-      bool open[SLB];
-      uint32_t slot[SLB];
+  }
+
+  // wave-wide hash match on 64-bit keys (valid lanes only): rep = smallest candidate index with the same key.
+  // The smallest candidate of the largest tag owns a slot; the others of its key join it, the rest move to their
+  // next slot (other key bits, then linear). A candidates per lane (v = j * 64 + lane), all inserted in the same
+  // round (the members of a key must see the same slot history); table of 128 * A slots, cleared by the caller.
+  template <int A>
+  CTC_HD void match(const bool* valid, const uint64_t* ck, uint32_t* rep) {
+    constexpr uint32_t MASK = (uint32_t)(128 * A - 1);
+    bool open[A];
+    uint32_t slot[A];
 CTC_UNROLL
-      for (int j = 0; j < SLB; ++j) {
-        open[j] = valid[j];
-        slot[j] = (uint32_t)(ck[j] >> 7) & (uint32_t)(TS - 1);
+    for (int j = 0; j < A; ++j) {
+      open[j] = valid[j];
+      rep[j] = (uint32_t)(j * 64 + lane);
+      slot[j] = (uint32_t)(ck[j] >> 7) & MASK;
+    }
+    for (uint32_t round = 0;; ++round) {
+      bool any_open = false;
+CTC_UNROLL
+      for (int j = 0; j < A; ++j) any_open = any_open || open[j];
+      if (ctx.ballot(any_open) == 0ull) break;
+CTC_UNROLL
+      for (int j = 0; j < A; ++j) {
+        const uint32_t v = (uint32_t)(j * 64 + lane);
+        if (open[j]) ctx.lds_max_u64(&L.table[slot[j]], (ck[j] & ~127ull) | (uint64_t)(127u - v));
       }
-      for (uint32_t round = 0;; ++round) {
-        bool any_open = false;
+      ctx.wsync();
+      uint64_t got[A];
 CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) any_open = any_open || open[j];
-        if (ctx.ballot(any_open) == 0ull) break;
+      for (int j = 0; j < A; ++j) got[j] = open[j] ? L.table[slot[j]] : 0ull;
 CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) {
-          const uint32_t v = (uint32_t)(j * 64 + lane);
-          if (open[j]) ctx.lds_max_u64(&L.table[slot[j]], (ck[j] & ~127ull) | (uint64_t)(127u - v));
-        }
-        ctx.wsync();
-CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) {
-          if (open[j]) {
-            const uint64_t got = L.table[slot[j]];
-            if ((got & ~127ull) == (ck[j] & ~127ull)) {
-              rep[j] = 127u - (uint32_t)(got & 127ull);
-              open[j] = false;
-            } else {
-              slot[j] = round < 5u ? ((uint32_t)(ck[j] >> (15 + 8 * round)) & (uint32_t)(TS - 1))
-                                   : ((slot[j] + 1u) & (uint32_t)(TS - 1));
-            }
+      for (int j = 0; j < A; ++j) {
+        if (open[j]) {
+          if ((got[j] & ~127ull) == (ck[j] & ~127ull)) {
+            rep[j] = 127u - (uint32_t)(got[j] & 127ull);
+            open[j] = false;
+          } else {
+            slot[j] = round < 5u ? ((uint32_t)(ck[j] >> (15 + 8 * round)) & MASK) : ((slot[j] + 1u) & MASK);
           }
         }
-        ctx.wsync();
+      }
+      ctx.wsync();
+    }
+  }
+
+  // Everything this frame still reads from global memory is consumed here, before the frame's stores: the
+  // table entries of the appended partials, the ids of the next frame's survivors (their label constants are
+  // requested now) and the n-gram probes of the completions, whose nodes are then written together with the
+  // emission nodes of the previous frame.
+  struct TabView {
+    bool on, hon;
+    uint32_t pf, nw, hmin, hcomp;
+  };
+  CTC_HD TabView resolve_tables(const Cand& c) {
+    TabView t;
+    t.on = t.hon = false;
+    t.pf = t.nw = t.hmin = t.hcomp = 0;
+    if (c.is_rep && c.br == BR_APPEND) {
+      const uint64_t key = c.kp;
+      if (c.want_p) {
+        uint64_t sp = c.tslot & tab.prefix_mask;
+        uint64_t ek = c.pp_key;
+        uint32_t nw = c.pp_wid, pf = c.pp_fl;
+        while (ek != key && ek != 0) {
+          sp = (sp + 1) & tab.prefix_mask;
+          const PrefixEntry& g = tab.prefixes[sp];
+          ek = g.key;
+          nw = g.word_id;
+          pf = g.flags;
+        }
+        t.on = ek == key;
+        t.nw = nw;
+        t.pf = pf;
+      }
+      if (c.want_h) {
+        uint64_t sh = c.tslot & tab.hot_mask;
+        uint64_t ek = c.ph_key;
+        uint32_t hmin = c.ph_min, hcomp = c.ph_cmp;
+        while (ek != key && ek != 0) {
+          sh = (sh + 1) & tab.hot_mask;
+          const HotEntry& g = tab.hot[sh];
+          ek = g.key;
+          hmin = g.min_len;
+          hcomp = g.complete;
+        }
+        t.hon = ek == key;
+        t.hmin = hmin;
+        t.hcomp = hcomp;
       }
     }
-    // members announce themselves to their representative
-CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
-      const uint32_t v = (uint32_t)(j * 64 + lane);
-      if (valid[j] && rep[j] != v) ctx.lds_or_u32(&((CTC_LDS uint32_t*)L.gmask.p)[rep[j] * 4 + (v >> 5)], 1u << (v & 31u));
-      is_rep[j] = valid[j] && rep[j] == v;
+    return t;
+  }
+  CTC_HD void frame_stores() {
+    if (tok_pending) prefetch_tok();
+    if (comp_pending) {
+      completions_end();
+      ctx.wsync();
     }
-    ctx.wsync();
-    tick<W_PROF_MATCH>();
+    flush_emits();
+  }
+
+  // fold, score and push the representatives of one pass; A candidates per lane, W = 32-bit words of a member
+  // mask in use
+  template <int A>
+  CTC_HD void tail(Cand* c, const TabView* t) {
+    constexpr int W = 2 * A;
     // ---- fold the group's logits in ascending beam rank (decoder.py:217-223); donor = last arrival
-    uint32_t imax[SLB];
+    uint32_t imax[A], dbr[A];
     {
-      u32x4 gm[SLB];
+      u32x4 gm[A];
       bool more = false;
 CTC_UNROLL
-      for (int j = 0; j < SLB; ++j) {
-        const uint32_t v = (uint32_t)(j * 64 + lane);
+      for (int j = 0; j < A; ++j) {
         gm[j] = mk4(0, 0, 0, 0);
-        imax[j] = bi[j];
-        if (is_rep[j]) {
-          gm[j] = L.gmask[v];
+        imax[j] = c[j].bi;
+        dbr[j] = c[j].br;
+        if (c[j].is_rep) {
+          gm[j] = L.gmask[c[j].v];
           uint32_t top = 0xFFFFFFFFu;
 CTC_UNROLL
-          for (int w = 0; w < 4; ++w)
+          for (int w = 0; w < W; ++w)
             if (gm[j][w]) top = (uint32_t)(w * 32 + 31 - ctx.clz32(gm[j][w]));
           if (top != 0xFFFFFFFFu) {
-            imax[j] = bi[j] + (top - v);  // members share the label: consecutive beam indices
+            imax[j] = c[j].bi + (top - c[j].v);  // members share the label: consecutive beam indices
+            dbr[j] = L.c_br[top];
             more = true;
           }
         }
@@ -656,18 +936,21 @@ CTC_UNROLL
       while (ctx.ballot(more) != 0ull) {
         more = false;
 CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) {
-          if (is_rep[j]) {
+        for (int j = 0; j < A; ++j) {
+          if (c[j].is_rep) {
             uint32_t mbit = 0xFFFFFFFFu;
 CTC_UNROLL
-            for (int w = 3; w >= 0; --w)
+            for (int w = W - 1; w >= 0; --w)
               if (gm[j][w]) mbit = (uint32_t)(w * 32 + ctx.ctz32(gm[j][w]));
             if (mbit != 0xFFFFFFFFu) {
 CTC_UNROLL
-              for (int w = 0; w < 4; ++w)
+              for (int w = 0; w < W; ++w)
                 if ((int)(mbit >> 5) == w) gm[j][w] &= gm[j][w] - 1u;
-              lg[j] = lse2(lg[j], L.c_logit[mbit]);
-              more = more || (gm[j][0] | gm[j][1] | gm[j][2] | gm[j][3]) != 0u;
+              c[j].lg = lse2(c[j].lg, L.c_logit[mbit]);
+              uint32_t left = 0;
+CTC_UNROLL
+              for (int w = 0; w < W; ++w) left |= gm[j][w];
+              more = more || left != 0u;
             }
           }
         }
@@ -675,71 +958,55 @@ CTC_UNROLL
     }
     tick<W_PROF_FOLD>();
     // ---- score the representatives (decoder.py:346-424)
-    double score[SLB];
-    uint64_t my_key[SLB];
-    PartView pv[SLB];
+    double score[A];
+    uint64_t my_key[A];
+    uint32_t v_pl[A], v_m2[A], v_wid[A];
     uint64_t pass_key = 0;
 CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
+    for (int j = 0; j < A; ++j) {
       score[j] = 0.0;
       my_key[j] = 0;
-      pv[j].pl = pv[j].m2 = pv[j].wid = 0;
-      pv[j].ps = 0.0;
-      if (is_rep[j]) {
-        const uint32_t i = bi[j];
-        const uint32_t b = br[j];
-        PartView q;
+      v_pl[j] = v_m2[j] = v_wid[j] = 0;
+      if (c[j].is_rep) {
+        const uint32_t i = c[j].bi;
+        const uint32_t b = c[j].br;
+        // (computed into scalars and copied out once: with the per-slot arrays written inside the branches,
+        // hipcc 7.2 -O3 lost the store of the last branch in the second unrolled iteration)
+        uint32_t q_pl, q_m2, q_wid;
+        double q_ps;
         if (b == 0) {  // blank / repeat: unchanged
-          q.pl = pl0[j];
-          q.m2 = m2_0[j];
-          q.wid = L.b32[i * 28 + 23];
-          q.ps = L.bf64[i * 14 + 7];
-        } else if (b == BR_BOUNDARY && lb[j].len_clean > 0) {  // a new word starts with the clean label
-          const uint32_t hmin = lb[j].hot_min, hcomp = lb[j].hot_complete;
-          q.pl = lb[j].len_clean;
-          q.m2 = (lb[j].start_flags & (PF_PARTIAL_MASK | PF_ON_TABLE)) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8);
-          q.wid = lb[j].start_word_id;
-          q.ps = partial_score(tab, prm, lb[j].start_flags, hmin, q.pl);
+          q_pl = c[j].pl0;
+          q_m2 = c[j].m2_0;
+          q_wid = L.b32[i * 28 + 23];
+          q_ps = L.bf64[i * 14 + 7];
+        } else if (b == BR_BOUNDARY) {
+          // a new word starts with the clean label (or, for a bare boundary mark, nothing yet)
+          const u32x4 lb = L.lab[c[j].ll * 3 + 1], lc = L.lab[c[j].ll * 3 + 2];
+          const uint32_t len_clean = lb[3];
+          const uint32_t hmin = lc[3] & 0xFFFFu, hcomp = lc[3] >> 31;
+          q_pl = len_clean;
+          q_m2 = len_clean > 0 ? ((lc[1] & (PF_PARTIAL_MASK | PF_ON_TABLE)) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8))
+                               : EMPTY_PARTIAL_M2;
+          q_wid = len_clean > 0 ? lc[2] : 0u;
+          q_ps = len_clean > 0 ? partial_score(tab, prm, lc[1], hmin, q_pl) : 0.0;
         } else if (b == BR_APPEND) {
-          uint32_t pf = 0, nw = 0, hmin = 0, hcomp = 0;
-          bool on = false, hon = false;
-          const uint64_t key = kp[j];
-          const uint64_t hk = mix64(key);
-          if (want_p[j]) {
-            uint64_t sp = hk & tab.prefix_mask;
-            PrefixEntry ep = pre_p[j];
-            while (ep.key != key && ep.key != 0) {
-              sp = (sp + 1) & tab.prefix_mask;
-              ep = tab.prefixes[sp];
-            }
-            on = ep.key == key;
-            nw = ep.word_id;
-            pf = ep.flags;
-          }
-          if (want_h[j]) {
-            uint64_t sh = hk & tab.hot_mask;
-            HotEntry eh = pre_h[j];
-            while (eh.key != key && eh.key != 0) {
-              sh = (sh + 1) & tab.hot_mask;
-              eh = tab.hot[sh];
-            }
-            hon = eh.key == key;
-            hmin = eh.min_len;
-            hcomp = eh.complete;
-          }
-          q.pl = pl0[j] + lb[j].len_raw;
-          q.m2 = (on ? (PF_ON_TABLE | (pf & PF_PARTIAL_MASK)) : 0u) | (hon ? M2_HOT_ON : 0u) | ((hon && hcomp) ? M2_HOT_COMPLETE : 0u) |
-                 ((hon ? hmin : 0u) << 8);
-          q.wid = on ? nw : 0;
-          q.ps = partial_score(tab, prm, on ? pf : 0u, hon ? hmin : 0u, q.pl);
-        } else {  // space, or a bare boundary mark: the open word is empty
-          q.pl = 0;
-          q.m2 = EMPTY_PARTIAL_M2;
-          q.wid = 0;
-          q.ps = 0.0;
+          q_pl = c[j].pl0 + c[j].len_raw;
+          q_m2 = (t[j].on ? (PF_ON_TABLE | (t[j].pf & PF_PARTIAL_MASK)) : 0u) | (t[j].hon ? M2_HOT_ON : 0u) |
+                 ((t[j].hon && t[j].hcomp) ? M2_HOT_COMPLETE : 0u) | ((t[j].hon ? t[j].hmin : 0u) << 8);
+          q_wid = t[j].on ? t[j].nw : 0;
+          q_ps = partial_score(tab, prm, t[j].on ? t[j].pf : 0u, t[j].hon ? t[j].hmin : 0u, q_pl);
+        } else {  // space: the open word is empty
+          q_pl = 0;
+          q_m2 = EMPTY_PARTIAL_M2;
+          q_wid = 0;
+          q_ps = 0.0;
         }
-        pv[j] = q;
-        score[j] = total_score(tab, lg[j], lmhw_sel[j], q.ps, q.pl);
+        v_pl[j] = q_pl;
+        v_m2[j] = q_m2;
+        v_wid[j] = q_wid;
+        double lmhw = c[j].lmhw;
+        if ((b == BR_BOUNDARY || b == BR_SPACE) && c[j].pl0 > 0) lmhw = L.bf64[i * 14 + 6];  // c_lm_hw
+        score[j] = total_score(tab, c[j].lg, lmhw, q_ps, q_pl);
         my_key[j] = asc_key(score[j]);
         if (my_key[j] > pass_key) pass_key = my_key[j];
       }
@@ -750,44 +1017,104 @@ CTC_UNROLL
     tick<W_PROF_SCORE>();
     // ---- push what can still matter into the pool
 CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
-      if ((uint32_t)(j * 64) >= Q) continue;
-      const bool push = is_rep[j] && score[j] >= thr && my_key[j] > kth_key;
+    for (int j = 0; j < A; ++j) {
+      const bool push = c[j].is_rep && score[j] >= thr && my_key[j] > kth_key;
       const uint64_t m = ctx.ballot(push);
       const uint32_t k = pool_n + prefix_cnt(m);
       pool_n += (uint32_t)ctx.popc64(m);
       if (push) {
-        L.p_score[k] = score[j];
-        L.p_logit[k] = lg[j];
-        L.p_arr[k] = ls[j] * Nn + bi[j];
-        L.p_don[k] = (ls[j] << 8) | imax[j];
-        L.p_wid[k] = pv[j].wid;
-        L.p_m2[k] = pv[j].m2;
         // (history, partial, last_char) folded to 64 bits (decoder.py:250-254): equality of the folds stands in
         // for equality of the triple (its members are 61/64-bit string hashes already)
-        L.p_hk[k] = fin64(c_hist_sel[j] * 0x9E3779B97F4A7C15ull + kp[j] * 0xC2B2AE3D27D4EB4Full + (uint64_t)(lid[j] + 1u));
+        uint64_t hk = 0;
+        if (prm.prune_history) {
+          const bool closed = (c[j].br == BR_BOUNDARY || c[j].br == BR_SPACE) && c[j].pl0 > 0;
+          const uint64_t hh = L.b64[c[j].bi * 14 + (closed ? 9 : 8)];  // c_hist_h : hist_h
+          hk = fin64(hh ^ rotl64(c[j].kp, 19) ^ ((uint64_t)(c[j].lid + 1u) << 40));
+        }
+        L.pool[k * 3] = mk4q(f64_bits(score[j]), hk);
+        L.pool[k * 3 + 1] = mk4q(f64_bits(c[j].lg), c[j].kp);
+        const uint32_t blank = (c[j].mw >> 16) & TK_BLANK;
+        L.pool[k * 3 + 2] = mk4((c[j].ls * (uint32_t)N + c[j].bi) | (v_pl[j] << 16),
+                                imax[j] | (c[j].lid << 8) | (blank ? (1u << 29) : 0u) | (dbr[j] << 30), v_wid[j], v_m2[j]);
       }
     }
     ctx.wsync();
+    tick<W_PROF_PUSH>();
+  }
+
+  // One pass: the candidates of the labels [l0, l1) of the staged block (survivors base + l), A candidates per
+  // lane (v = j * 64 + lane; with more than 64 live beams a pass is one label and v the beam index)
+  template <int A>
+  CTC_HD void pass(uint32_t base, uint32_t l0, uint32_t l1) {
+    const uint32_t Nn = (uint32_t)N;
+    const uint32_t Q = (l1 - l0) * Nn;
+    const uint32_t rcpN = Nn ? 65536u / Nn + 1u : 0u;  // v / N == (v * rcpN) >> 16 for v * N < 65536
+    Cand c[A];
+    bool valid[A];
+    uint64_t ck[A];
+    uint32_t rep[A];
+CTC_UNROLL
+    for (int j = 0; j < A; ++j) {
+      const int v = j * 64 + lane;
+      L.gmask[v] = mk4(0, 0, 0, 0);
+      ((CTC_LDS u32x4*)L.table.p)[v] = mk4(0, 0, 0, 0);  // 128 slots per candidate slot
+    }
+CTC_UNROLL
+    for (int j = 0; j < A; ++j) {
+      const uint32_t v = (uint32_t)(j * 64 + lane);
+      const uint32_t sl = (v * rcpN) >> 16;
+      const uint32_t l = l0 + sl;
+      gen<true>(c[j], v < Q, v, l, base + l, v - sl * Nn);
+      valid[j] = c[j].valid;
+      ck[j] = c[j].ck;
+      if (c[j].valid) {
+        L.c_logit[v] = c[j].lg;
+        L.c_br[v] = c[j].br;
+      }
+    }
+    ctx.wsync();
+    tick<W_PROF_GEN>();
+    match<A>(valid, ck, rep);
+    // members announce themselves to their representative
+CTC_UNROLL
+    for (int j = 0; j < A; ++j) {
+      const uint32_t v = (uint32_t)(j * 64 + lane);
+      c[j].rep = rep[j];
+      if (valid[j] && rep[j] != v) ctx.lds_or_u32(&((CTC_LDS uint32_t*)L.gmask.p)[rep[j] * 4 + (v >> 5)], 1u << (v & 31u));
+      c[j].is_rep = valid[j] && rep[j] == v;
+    }
+    ctx.wsync();
+    tick<W_PROF_MATCH>();
+    TabView t[A];
+CTC_UNROLL
+    for (int j = 0; j < A; ++j) t[j] = resolve_tables(c[j]);
+    frame_stores();
+    tick<W_PROF_COMP>();
+    tail<A>(c, t);
   }
 
   // ---- one frame ---------------------------------------------------------------------------------
   CTC_HD void step(int t) {
     const int frame = io.first_frame + t;
-    const uint32_t ns = pf_cnt;
+    const uint32_t ns = ctx.uni32(pf_cnt);
     pool_n = 0;
     runmax = asc_key(-INFINITY);
     kth_key = 0;
     need = 0;
-    // last labels of the live beams: is there a beam that does not end in beam 0's label, and which first?
+    // this lane's beam(s): last label, and -- if its open word has no completion yet -- its text node
+#ifdef CTC_WAVE_TRACE
+    if (lane < N) {
+      const u32x4 t0 = L.beams[lane * BREC], t1 = L.beams[lane * BREC + 1], t5 = L.beams[lane * BREC + 5];
+      printf("TB f=%d N=%d i=%d text=%llx part=%llx logit=%.6f meta1=%x m2=%x tn=%u cn=%u wid=%u\n", frame, N, lane, (unsigned long long)q_lo(t0),
+             (unsigned long long)q_hi(t0), bits_f64(q_lo(t1)), t1[2], t1[3], t5[0], t5[1], t5[3]);
+    }
+#endif
+    uint32_t lc[SLB];
+    completions_fetch(lc);
+    tick<W_PROF_FETCH>();
+    // is there a beam that does not end in beam 0's label, and which is the first?
     uint32_t lc0 = NO_CHAR, f1 = (uint32_t)N;
     {
-      uint32_t lc[SLB];
-CTC_UNROLL
-      for (int j = 0; j < SLB; ++j) {
-        const int i = j * 64 + lane;
-        lc[j] = i < N ? (L.b32[i * 28 + 6] & 0xFFFFu) : 0u;
-      }
       lc0 = ctx.bcast32(lc[0], 0);
 CTC_UNROLL
       for (int j = SLB - 1; j >= 0; --j) {
@@ -796,7 +1123,9 @@ CTC_UNROLL
         if (m) f1 = (uint32_t)(j * 64 + ctx.ctz64(m));
       }
     }
-    // survivors -> LDS (ids, log-probs, branch modes, label constants), 64 labels at a time
+    bool comp_begun = false;
+    // survivors in blocks of 64 labels: ids, log-probs, branch modes and label constants -> LDS, then the
+    // candidates of the block in passes of whole labels
     for (uint32_t base = 0; base < ns; base += 64u) {
       const uint32_t s = base + (uint32_t)lane;
       const bool mine = s < ns;
@@ -807,56 +1136,87 @@ CTC_UNROLL
           id = pf_id;
           lp = pf_lp;
           fl = pt_flags;
-          L.lab[s * 3] = mk4q(pt_h_raw, pt_pow_raw);
-          L.lab[s * 3 + 1] = mk4((uint32_t)pt_h_clean, (uint32_t)(pt_h_clean >> 32), pt_len_raw, pt_len_clean);
-          L.lab[s * 3 + 2] = mk4(pt_flags, pt_start_flags, pt_start_word_id, pt_hot);
+          L.lab[lane * 3] = mk4q(pt_h_raw, pt_pow_raw);
+          L.lab[lane * 3 + 1] = mk4((uint32_t)pt_h_clean, (uint32_t)(pt_h_clean >> 32), pt_len_raw, pt_len_clean);
+          L.lab[lane * 3 + 2] = mk4(pt_flags, pt_start_flags, pt_start_word_id, pt_hot);
         }
-      } else if (mine) {
-        id = io.surv_id[(size_t)t * prm.max_surv + s];
-        lp = io.surv_lp[(size_t)t * prm.max_surv + s];
-        fl = tab.tok[id].flags;
+      } else {
+        // (more than 64 survivors in one frame: rare; fetched on the spot)
+        ctx.wsync();  // the previous block's passes are done with surv / lab
+        if (mine) {
+          id = io.surv_id[(size_t)t * prm.max_surv + s];
+          lp = io.surv_lp[(size_t)t * prm.max_surv + s];
+          const TokInfo& g = tab.tok[id];
+          fl = g.flags;
+          const uint32_t hot = tab.tok_hot ? ((tab.tok_hot[id].min_len & 0xFFFFu) | (tab.tok_hot[id].complete ? 0x80000000u : 0u)) : 0u;
+          L.lab[lane * 3] = mk4q(g.h_raw, g.pow_raw);
+          L.lab[lane * 3 + 1] = mk4((uint32_t)g.h_clean, (uint32_t)(g.h_clean >> 32), g.len_raw, g.len_clean);
+          L.lab[lane * 3 + 2] = mk4(g.flags, g.start_flags, g.start_word_id, hot);
+        }
       }
-      const uint32_t mw = mode_block(fl, id, lc0, f1);
-      if (mine) L.surv[s] = mk4(id, mw, (uint32_t)f64_bits(lp), (uint32_t)(f64_bits(lp) >> 32));
-    }
-    tick<W_PROF_LOAD>();
-    if (need) completions();
-    ctx.wsync();
-    prefetch(t + 1);  // lands while this frame's candidates are processed
-    tick<W_PROF_COMP>();
-    // labels are taken in passes of whole labels (<= C candidates); before a pass that might not fit the
-    // pool, the pool is compacted to its best beam_width entries
-    uint32_t per = (uint32_t)C / (uint32_t)(N > 0 ? N : 1);
-    if (per == 0) per = 1;
-    for (uint32_t s0 = 0; s0 < ns; s0 += per) {
-      const uint32_t s1 = s0 + per < ns ? s0 + per : ns;
-      if (pool_n + (s1 - s0) * (uint32_t)N > (uint32_t)P) {
-        compact_pool();
-        tick<W_PROF_COMPACT>();
+      const uint32_t mwd = mode_block(fl, id, lc0, f1);
+      if (mine) L.surv[lane] = mk4(id, mwd, (uint32_t)f64_bits(lp), (uint32_t)(f64_bits(lp) >> 32));
+      if (base == 0) tick<W_PROF_LOAD>();
+      if (need && !comp_begun) {
+        completions_begin();
+        comp_begun = true;
       }
-      pass(s0, s1);
+      ctx.wsync();
+      if (base == 0) {
+        prefetch(t + 1);  // lands while this frame's candidates are processed
+        tick<W_PROF_BEGIN>();
+      }
+      const uint32_t nb = ns - base < 64u ? ns - base : 64u;
+      // passes of whole labels (<= 64 * SLB candidates); before a pass that might not fit the pool, the pool is
+      // compacted to its best beam_width entries
+      // (a pass never brings more candidates than the pool can take right after a compaction: P - beam_width)
+      uint32_t room = (uint32_t)P - (uint32_t)prm.beam_width;
+      if (room > (uint32_t)(64 * SLB)) room = (uint32_t)(64 * SLB);
+      uint32_t per = room / (uint32_t)(N > 0 ? N : 1);
+      if (per == 0) per = 1;  // (N <= beam_width <= P - beam_width: one label always fits)
+      for (uint32_t l0 = 0; l0 < nb; l0 += per) {
+        const uint32_t l1 = l0 + per < nb ? l0 + per : nb;
+        const uint32_t q = (l1 - l0) * (uint32_t)N;
+        if (pool_n + q > (uint32_t)P) {
+          compact_pool();
+          tick<W_PROF_COMPACT>();
+        }
+        if (SLB == 1 || q <= 64u) pass<1>(base, l0, l1);
+        else pass<SLB>(base, l0, l1);
+      }
     }
-    prefetch_tok();
-    finish_frame(frame);
-  }
-
-  // threshold prune, top-B, history prune, next beam table (decoder.py:545-554)
-  CTC_HD void finish_frame(int frame) {
+    if (comp_pending || em_pending || tok_pending) frame_stores();  // (no pass ran: only without survivors or beams)
+    tick<W_PROF_PFTOK>();
     const double thr = key_to_score(runmax) + prm.beam_prune_logp;
     const bool hist = prm.prune_history != 0;
+#ifdef CTC_WAVE_TRACE
+    if ((uint32_t)lane < pool_n) {
+      const u32x4 t0 = L.pool[lane * 3], t2 = L.pool[lane * 3 + 2];
+      printf("TR f=%d N=%d ns=%u pool=%u e=%d score=%.6f arr=%u don=%x wid=%u m2=%x\n", frame, N, ns, pool_n, lane, bits_f64(q_lo(t0)), t2[0], t2[1], t2[2], t2[3]);
+    }
+#endif
     uint32_t n = rank_pool(thr, hist);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     tick<W_PROF_RANK>();
     // nothing passed the threshold: only possible with non-finite scores (NaN rows) or a positive
     // beam_prune_logp; the reference then dies on max([]) (decoder.py:545) -- reported through the status
     if (n == 0) status |= ST_NO_BEAMS;
+    if (SLB == 1 || n <= 64u) build<1>(frame, n);
+    else build<SLB>(frame, n);
+  }
+
+  // next beam table from the ranked pool (decoder.py:548-554); A = rank slots per lane in use
+  template <int A>
+  CTC_HD void build(int frame, uint32_t n) {
     // gather everything the new records need, then write them (one table, no double buffer)
-    bool kept[SLB];
-    uint32_t dst[SLB];
-    u32x4 o0[SLB], o1[SLB], o2[SLB], o3[SLB], o4[SLB], o5[SLB], o6[SLB];
+    bool kept[A];
+    uint32_t dst[A];
+    u32x4 o0[A], o1[A], o2[A], o3[A], o4[A], o5[A], o6[A];
     uint32_t n_new = 0;
 CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
+    for (int j = 0; j < SLB; ++j) em_has[j] = false;
+CTC_UNROLL
+    for (int j = 0; j < A; ++j) {
       const uint32_t r = (uint32_t)(j * 64 + lane);
       kept[j] = false;
       dst[j] = 0;
@@ -868,41 +1228,37 @@ CTC_UNROLL
       const uint64_t km = ctx.ballot(kept[j]);
       dst[j] = n_new + prefix_cnt(km);
       n_new += (uint32_t)ctx.popc64(km);
-      // the payload is the donor's (the last-arriving duplicate, decoder.py:221-223): its branch, not the
-      // representative's. Emission nodes: one per kept beam whose label is not a blank / repeat.
-      uint32_t b = 0, s = 0, i = 0, idx = 0, c = 0;
-      Lab lb;
-      u32x4 k1 = mk4(0, 0, 0, 0);
+      // the payload is the donor's (the last-arriving duplicate, decoder.py:221-223), its branch included.
+      // Emission nodes: one per kept beam whose label is not a blank / repeat.
+      u32x4 e1 = mk4(0, 0, 0, 0), e2 = mk4(0, 0, 0, 0);
       if (kept[j]) {
-        idx = w & 0x7FFFFFFFu;
-        const uint32_t don = L.p_don[idx];
-        s = don >> 8;
-        i = don & 0xFFu;
-        const u32x4 sv = L.surv[s];
-        c = sv[0];
-        lb = label_of(s, c);
-        k1 = L.beams[i * BREC + 1];
-        b = branch_of(lb.flags, sv[1], c, i, k1[2] & 0xFFFFu);
+        const uint32_t idx = w & 0x7FFFFFFFu;
+        e1 = L.pool[idx * 3 + 1];
+        e2 = L.pool[idx * 3 + 2];
       }
+      const uint32_t don = e2[1];
+      const uint32_t b = don >> 30, i = don & 0xFFu, c = (don >> 8) & 0xFFFFu;
       const uint64_t em = ctx.ballot(kept[j] && b != 0);
       uint32_t e = emit_next + prefix_cnt(em);
       emit_next += (uint32_t)ctx.popc64(em);
+      if (em) em_pending = true;
       if (kept[j]) {
-        const u32x4 k0 = L.beams[i * BREC], k2 = L.beams[i * BREC + 2];
+        const u32x4 k0 = L.beams[i * BREC], k1 = L.beams[i * BREC + 1], k2 = L.beams[i * BREC + 2];
         const u32x4 k3 = L.beams[i * BREC + 3], k4 = L.beams[i * BREC + 4], k5 = L.beams[i * BREC + 5];
         const u32x4 k6 = L.beams[i * BREC + 6];
         const uint32_t pl = k1[2] >> 16;
-        uint64_t th = q_lo(k0), ph = q_hi(k0), hh = q_lo(k4);
+        uint64_t th = q_lo(k0), hh = q_lo(k4);
+        const uint64_t ph = q_hi(e1);  // the new partial word's hash (unchanged for a blank / repeat)
         const uint64_t cth = q_lo(k2), chh = q_hi(k4);
         double lmhw = bits_f64(q_hi(k2));
         const double clm = bits_f64(q_lo(k3));
         uint32_t tnode = k5[0], cnode = k5[1], enode = k5[2];
         int32_t pst = (int32_t)k6[0], pen = (int32_t)k6[1];
         uint32_t depth = k6[2];
-        const uint32_t m2 = L.p_m2[idx], wid = L.p_wid[idx];
-        uint32_t npl = pl;
+        const uint32_t m2 = e2[3], wid = e2[2];
+        const uint32_t npl = e2[0] >> 16;
         if (b == 0) {
-          if (!(lb.flags & TK_BLANK)) pen = frame + 1;  // decoder.py:453-461
+          if (!(don & (1u << 29))) pen = frame + 1;  // a repeated label extends the open word (decoder.py:453-461)
         } else {
           const int32_t wst = pst, wen = pen;
           if (b == BR_BOUNDARY || b == BR_SPACE) {
@@ -913,19 +1269,13 @@ CTC_UNROLL
               tnode = cnode;
             }
             if (b == BR_BOUNDARY) {
-              ph = lb.h_clean;
-              npl = lb.len_clean;
               pst = frame;
               pen = frame + 1;
             } else {
-              ph = 0;
-              npl = 0;
               pst = -1;
               pen = -1;
             }
           } else {  // BR_APPEND (decoder.py:518-534)
-            ph = str_concat(ph, lb.pow_raw, lb.h_raw);
-            npl = pl + lb.len_raw;
             pst = pst < 0 ? frame : pst;
             pen = frame + 1;
           }
@@ -934,20 +1284,17 @@ CTC_UNROLL
             status |= ST_EMIT_OVERFLOW;
             e = io.emit_cap - 1;
           }
-          EmitNode en;
-          en.parent = enode;
-          en.tok_branch = c | (b << 16);
-          en.wstart = wst;
-          en.wend = wen;
-          io.emit_nodes[e] = en;
+          // (stored by flush_emits() in the next frame, or before the final back-trace)
+          em_has[j] = true;
+          em_idx[j] = e;
+          em_node[j] = mk4(enode, c | (b << 16), (uint32_t)wst, (uint32_t)wen);
           enode = e;
           depth += 1;
         }
         double ps = 0.0;
         if (npl > 0) ps = partial_score(tab, prm, m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
         o0[j] = mk4q(th, ph);
-        const uint64_t lgb = f64_bits(L.p_logit[idx]);
-        o1[j] = mk4((uint32_t)lgb, (uint32_t)(lgb >> 32), c | (npl << 16), m2);
+        o1[j] = mk4(e1[0], e1[1], c | (npl << 16), m2);
         o2[j] = mk4q(cth, f64_bits(lmhw));
         o3[j] = mk4q(f64_bits(clm), f64_bits(ps));
         o4[j] = mk4q(hh, chh);
@@ -956,8 +1303,9 @@ CTC_UNROLL
       }
     }
     ctx.wsync();
+    tick<W_PROF_GATHER>();
 CTC_UNROLL
-    for (int j = 0; j < SLB; ++j) {
+    for (int j = 0; j < A; ++j) {
       if (kept[j]) {
         const uint32_t d = dst[j];
         L.beams[d * BREC] = o0[j];
@@ -1004,7 +1352,7 @@ CTC_UNROLL
       root.hw_cnt = 0;
       root.ring_cnt = 0;
       for (int k = 0; k < MAX_CTX; ++k) root.ring[k] = 0;
-      root.hist_h = hist_hash(root.ring, 0);
+      root.hist_h = wave_hist_fold(root.ring, 0);
       root.pad0 = 0;
       LmState st;
       st.len = 0;
@@ -1038,12 +1386,9 @@ CTC_UNROLL
       tn.raw_lm = m.raw_lm;
       const double lmhw = m.raw_lm + prm.hot_weight * (double)m.hw_cnt;
       tn.lm_hw = lmhw;
-      uint64_t hh = 0x9E3779B97F4A7C15ull + m.ring_cnt;
+      const uint64_t hh = wave_hist_fold(m.ring, m.ring_cnt);
 CTC_UNROLL
-      for (int k = MAX_CTX - 1; k >= 0; --k) {
-        tn.ring[k] = m.ring[k];
-        if ((uint32_t)k < m.ring_cnt) hh = mix64(hh ^ m.ring[k]) + 0x632BE59BD9B4E019ull;
-      }
+      for (int k = 0; k < MAX_CTX; ++k) tn.ring[k] = m.ring[k];
       tn.hist_h = hh;
       tn.hw_cnt = m.hw_cnt;
       tn.ring_cnt = m.ring_cnt;
@@ -1075,8 +1420,14 @@ CTC_UNROLL
     pool_n = 0;
     runmax = asc_key(-INFINITY);
     kth_key = 0;
+    flush_emits();
     ctx.mem_sync();
-    if (fold) completions();
+    if (fold) {
+      uint32_t lc_unused[SLB];
+      completions_fetch(lc_unused);
+      completions_begin();
+      completions_end();
+    }
     ctx.mem_sync();
     const uint32_t Q = (uint32_t)N;  // one candidate per beam: N <= BW <= C
     bool valid[SLB], is_rep[SLB];
@@ -1101,46 +1452,14 @@ CTC_UNROLL
       if (valid[j]) {
         const uint32_t pl = L.b32[v * 28 + 6] >> 16;
         const uint64_t kt = pl > 0 ? L.b64[v * 14 + 4] : L.b64[v * 14];
-        ck[j] = fin64(kt * 0x9E3779B97F4A7C15ull + 0x165667B19E3779F9ull);
+        ck[j] = fin64(kt ^ 0x165667B19E3779F9ull);
         lg[j] = L.bf64[v * 14 + 2];
         L.c_logit[v] = lg[j];
       }
     }
     ctx.wsync();
     if (fold) {
-      bool open[SLB];
-      uint32_t slot[SLB];
-CTC_UNROLL
-      for (int j = 0; j < SLB; ++j) {
-        open[j] = valid[j];
-        slot[j] = (uint32_t)(ck[j] >> 7) & (uint32_t)(TS - 1);
-      }
-      for (uint32_t round = 0;; ++round) {
-        bool any_open = false;
-CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) any_open = any_open || open[j];
-        if (ctx.ballot(any_open) == 0ull) break;
-CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) {
-          const uint32_t v = (uint32_t)(j * 64 + lane);
-          if (open[j]) ctx.lds_max_u64(&L.table[slot[j]], (ck[j] & ~127ull) | (uint64_t)(127u - v));
-        }
-        ctx.wsync();
-CTC_UNROLL
-        for (int j = 0; j < SLB; ++j) {
-          if (open[j]) {
-            const uint64_t got = L.table[slot[j]];
-            if ((got & ~127ull) == (ck[j] & ~127ull)) {
-              rep[j] = 127u - (uint32_t)(got & 127ull);
-              open[j] = false;
-            } else {
-              slot[j] = round < 5u ? ((uint32_t)(ck[j] >> (15 + 8 * round)) & (uint32_t)(TS - 1))
-                                   : ((slot[j] + 1u) & (uint32_t)(TS - 1));
-            }
-          }
-        }
-        ctx.wsync();
-      }
+      match<SLB>(valid, ck, rep);
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
         const uint32_t v = (uint32_t)(j * 64 + lane);
@@ -1222,13 +1541,9 @@ CTC_UNROLL
       const uint32_t k = pool_n + prefix_cnt(m);
       pool_n += (uint32_t)ctx.popc64(m);
       if (is_rep[j]) {
-        L.p_score[k] = score[j];
-        L.p_logit[k] = lg[j];
-        L.p_arr[k] = (uint32_t)(j * 64 + lane);
-        L.p_don[k] = donor[j];
-        L.p_wid[k] = 0;
-        L.p_m2[k] = 0;
-        L.p_hk[k] = 0;
+        L.pool[k * 3] = mk4q(f64_bits(score[j]), 0);
+        L.pool[k * 3 + 1] = mk4q(f64_bits(lg[j]), 0);
+        L.pool[k * 3 + 2] = mk4((uint32_t)(j * 64 + lane), donor[j], 0u, 0u);  // arrival = beam rank, donor beam
       }
     }
     ctx.wsync();
@@ -1247,7 +1562,7 @@ CTC_UNROLL
       off[j] = 0;
       if (r < n_out) {
         const uint32_t idx = L.sel[r] & 0x7FFFFFFFu;
-        const uint32_t d = L.p_don[idx];
+        const uint32_t d = L.pool[idx * 3 + 2][1];
         len[j] = L.b32[d * 28 + 26] + ((fold && (L.b32[d * 28 + 6] >> 16) > 0) ? 1u : 0u);
       }
       off[j] = total + ctx.wave_excl_sum_u32(len[j]);
@@ -1269,10 +1584,11 @@ CTC_UNROLL
       const uint32_t r = (uint32_t)(j * 64 + lane);
       if (r >= n_out) continue;
       const uint32_t idx = L.sel[r] & 0x7FFFFFFFu;
-      const uint32_t d = L.p_don[idx];
+      const u32x4 e0 = L.pool[idx * 3], e1 = L.pool[idx * 3 + 1];
+      const uint32_t d = L.pool[idx * 3 + 2][1];
       OutBeam& ob = io.out[r];
-      ob.logit_score = L.p_logit[idx];
-      ob.lm_score = L.p_score[idx];
+      ob.logit_score = bits_f64(q_lo(e1));
+      ob.lm_score = bits_f64(q_lo(e0));
       const uint32_t meta1 = L.b32[d * 28 + 6];
       const uint32_t pl = meta1 >> 16;
       const bool closes = fold && pl > 0;
@@ -1346,10 +1662,6 @@ CTC_UNROLL
     for (int t = 0; t < io.T; ++t) step(t);
     finalise();
     tick<W_PROF_FINAL>();
-    if (io.prof && lane == 0) {
-CTC_UNROLL
-      for (int k = 0; k < W_PROF_N; ++k) io.prof[k] = t_acc[k];
-    }
   }
 };
 

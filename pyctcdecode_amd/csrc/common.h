@@ -74,10 +74,25 @@ CTC_HD uint32_t key_slot_hash(uint64_t text_h, uint64_t part_h, uint32_t ch) {
   return (uint32_t)(mix64(text_h * 0x9E3779B97F4A7C15ull + part_h * 0xC2B2AE3D27D4EB4Full + ch) >> 32);
 }
 
-// n-gram key: word ids oldest..newest (n >= 2).  Never 0 (0 marks an empty slot).
-CTC_HD uint64_t ngram_key_begin(uint32_t n) { return 0x243F6A8885A308D3ull ^ n; }
+// n-gram key: a chain over the word ids NEWEST FIRST (the scored word, then its context going back), so the
+// keys of all orders of one query share their prefix: key_n = end(push(...push(push(begin, w_n), w_{n-1})..., w_1), n)
+// costs one mix per order instead of one per word per order.  Never 0 (0 marks an empty slot).  The key is a
+// mixed value already: its low bits are the table slot.
+CTC_HD uint64_t ngram_key_begin() { return 0x243F6A8885A308D3ull; }
 CTC_HD uint64_t ngram_key_push(uint64_t k, uint32_t id) { return mix64(k ^ (uint64_t)id) + 0x13198A2E03707344ull; }
-CTC_HD uint64_t ngram_key_end(uint64_t k) { return k == 0 ? 1 : k; }
+CTC_HD uint64_t ngram_key_end(uint64_t k, uint32_t n) {
+  k ^= (uint64_t)n << 56;
+  return k == 0 ? 1 : k;
+}
+
+// slot hash of the prefix / hot-word tables (keys are 61-bit polynomial string hashes): fold to 32 bits, one
+// multiply, one xor-shift so that the low bits used for the slot depend on all of the key
+CTC_HD uint64_t table_slot(uint64_t key) {
+  uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  return (uint64_t)x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Device tables (all open addressing, linear probing, power-of-two sizes, empty key = 0)
@@ -258,7 +273,7 @@ struct DecodeParams {
 CTC_HD bool prefix_lookup(const PrefixEntry* tab, uint64_t mask, uint64_t key, uint32_t* word_id,
                           uint32_t* flags) {
   if (!tab || key == 0) return false;
-  uint64_t s = mix64(key) & mask;
+  uint64_t s = table_slot(key) & mask;
   for (;;) {
     PrefixEntry e = tab[s];
     if (e.key == key) {
@@ -274,7 +289,7 @@ CTC_HD bool prefix_lookup(const PrefixEntry* tab, uint64_t mask, uint64_t key, u
 CTC_HD bool hot_lookup(const HotEntry* tab, uint64_t mask, uint64_t key, uint32_t* min_len,
                        uint32_t* complete) {
   if (!tab || key == 0) return false;
-  uint64_t s = mix64(key) & mask;
+  uint64_t s = table_slot(key) & mask;
   for (;;) {
     HotEntry e = tab[s];
     if (e.key == key) {
@@ -288,7 +303,7 @@ CTC_HD bool hot_lookup(const HotEntry* tab, uint64_t mask, uint64_t key, uint32_
 }
 
 CTC_HD bool ngram_lookup(const NgramEntry* tab, uint64_t mask, uint64_t key, float* prob, float* backoff) {
-  uint64_t s = mix64(key) & mask;
+  uint64_t s = key & mask;
   for (;;) {
     NgramEntry e = tab[s];
     if (e.key == key) {
@@ -303,15 +318,6 @@ CTC_HD bool ngram_lookup(const NgramEntry* tab, uint64_t mask, uint64_t key, flo
 
 // kenlm GenericModel::FullScore restated on the flat hashed trie (see oracle/arpa_lm.py for the
 // CPU restatement and DESIGN.md for the state convention).  Returns log10 p as fp32.
-// key of the n-gram (in.words[n-2] ... in.words[0], wid)
-template <int N>
-CTC_HD uint64_t lm_key(const LmState& in, uint32_t wid) {
-  uint64_t k = ngram_key_begin((uint32_t)N);
-CTC_UNROLL
-  for (int c = N - 2; c >= 0; --c) k = ngram_key_push(k, in.words[c]);
-  return ngram_key_end(ngram_key_push(k, wid));
-}
-
 // finish the probe of one order: first entry `e` was loaded from slot `s`; walk on collisions (rare)
 template <class Tab>
 CTC_HD bool lm_resolve(const Tab& t, uint64_t key, uint64_t s, NgramEntry e, float* prob, float* bo) {
@@ -326,34 +332,52 @@ CTC_HD bool lm_resolve(const Tab& t, uint64_t key, uint64_t s, NgramEntry e, flo
 }
 
 // Tab: DeviceTables (LM 0) or LmExtra (a further model): unigrams, ngrams, ngram_mask, lm_order
+// One word scored in two halves so that a caller can put other work between the probes and their use:
+// lm_probe_issue computes the n-gram keys and loads the first slot of every order (independent loads overlap
+// their latency; kenlm walks the orders one after the other, the longest match is the same), lm_probe_finish
+// resolves them. Scalars only: no run-time indexed temporaries (they would live in scratch memory).
+struct LmProbe {
+  UnigramEntry u;
+  int max_n;
+  uint64_t k2, k3, k4, k5, k6, s2, s3, s4, s5, s6;
+  NgramEntry e2, e3, e4, e5, e6;
+};
+
 template <class Tab>
-CTC_HD float lm_base_score(const Tab& t, const LmState& in, uint32_t wid, LmState* out) {
-  const UnigramEntry u = t.unigrams[wid];
+CTC_HD void lm_probe_issue(const Tab& t, const LmState& in, uint32_t wid, LmProbe& p) {
+  p.u = t.unigrams[wid];
   const int in_len = in.len;
   const int max_n = !t.ngrams ? 1 : ((int)t.lm_order < in_len + 1 ? (int)t.lm_order : in_len + 1);
-  // The first probe of every order is issued up front (independent loads overlap their latency);
-  // kenlm walks the orders one after the other, the longest match is the same. Scalars only: no
-  // run-time indexed temporaries (they would live in scratch memory).
+  p.max_n = max_n;
   const NgramEntry none = {0, 0.f, 0.f};
-  uint64_t k2 = 0, k3 = 0, k4 = 0, k5 = 0, k6 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0;
-  NgramEntry e2 = none, e3 = none, e4 = none, e5 = none, e6 = none;
-  if (max_n >= 2) { k2 = lm_key<2>(in, wid); s2 = mix64(k2) & t.ngram_mask; e2 = t.ngrams[s2]; }
-  if (max_n >= 3) { k3 = lm_key<3>(in, wid); s3 = mix64(k3) & t.ngram_mask; e3 = t.ngrams[s3]; }
-  if (max_n >= 4) { k4 = lm_key<4>(in, wid); s4 = mix64(k4) & t.ngram_mask; e4 = t.ngrams[s4]; }
-  if (max_n >= 5) { k5 = lm_key<5>(in, wid); s5 = mix64(k5) & t.ngram_mask; e5 = t.ngrams[s5]; }
-  if (max_n >= 6) { k6 = lm_key<6>(in, wid); s6 = mix64(k6) & t.ngram_mask; e6 = t.ngrams[s6]; }
-  float prob = u.prob;
-  float b0 = u.backoff, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
+  p.k2 = p.k3 = p.k4 = p.k5 = p.k6 = 0;
+  p.s2 = p.s3 = p.s4 = p.s5 = p.s6 = 0;
+  p.e2 = p.e3 = p.e4 = p.e5 = p.e6 = none;
+  // one chain, newest word first: the key of order n extends the key of order n-1 by one word
+  uint64_t c = ngram_key_push(ngram_key_begin(), wid);
+  if (max_n >= 2) { c = ngram_key_push(c, in.words[0]); p.k2 = ngram_key_end(c, 2); p.s2 = p.k2 & t.ngram_mask; p.e2 = t.ngrams[p.s2]; }
+  if (max_n >= 3) { c = ngram_key_push(c, in.words[1]); p.k3 = ngram_key_end(c, 3); p.s3 = p.k3 & t.ngram_mask; p.e3 = t.ngrams[p.s3]; }
+  if (max_n >= 4) { c = ngram_key_push(c, in.words[2]); p.k4 = ngram_key_end(c, 4); p.s4 = p.k4 & t.ngram_mask; p.e4 = t.ngrams[p.s4]; }
+  if (max_n >= 5) { c = ngram_key_push(c, in.words[3]); p.k5 = ngram_key_end(c, 5); p.s5 = p.k5 & t.ngram_mask; p.e5 = t.ngrams[p.s5]; }
+  if (max_n >= 6) { c = ngram_key_push(c, in.words[4]); p.k6 = ngram_key_end(c, 6); p.s6 = p.k6 & t.ngram_mask; p.e6 = t.ngrams[p.s6]; }
+}
+
+template <class Tab>
+CTC_HD float lm_probe_finish(const Tab& t, const LmState& in, uint32_t wid, const LmProbe& p, LmState* out) {
+  const int in_len = in.len;
+  const int max_n = p.max_n;
+  float prob = p.u.prob;
+  float b0 = p.u.backoff, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f, b5 = 0.f;
   int matched = 1;
-  if (max_n >= 2 && lm_resolve(t, k2, s2, e2, &prob, &b1)) {
+  if (max_n >= 2 && lm_resolve(t, p.k2, p.s2, p.e2, &prob, &b1)) {
     matched = 2;
-    if (max_n >= 3 && lm_resolve(t, k3, s3, e3, &prob, &b2)) {
+    if (max_n >= 3 && lm_resolve(t, p.k3, p.s3, p.e3, &prob, &b2)) {
       matched = 3;
-      if (max_n >= 4 && lm_resolve(t, k4, s4, e4, &prob, &b3)) {
+      if (max_n >= 4 && lm_resolve(t, p.k4, p.s4, p.e4, &prob, &b3)) {
         matched = 4;
-        if (max_n >= 5 && lm_resolve(t, k5, s5, e5, &prob, &b4)) {
+        if (max_n >= 5 && lm_resolve(t, p.k5, p.s5, p.e5, &prob, &b4)) {
           matched = 5;
-          if (max_n >= 6 && lm_resolve(t, k6, s6, e6, &prob, &b5)) matched = 6;
+          if (max_n >= 6 && lm_resolve(t, p.k6, p.s6, p.e6, &prob, &b5)) matched = 6;
         }
       }
     }
@@ -381,6 +405,13 @@ CTC_HD float lm_base_score(const Tab& t, const LmState& in, uint32_t wid, LmStat
   out->backoff[3] = keep > 3 ? b3 : 0.f;
   out->backoff[4] = keep > 4 ? b4 : 0.f;
   return prob;
+}
+
+template <class Tab>
+CTC_HD float lm_base_score(const Tab& t, const LmState& in, uint32_t wid, LmState* out) {
+  LmProbe p;
+  lm_probe_issue(t, in, wid, p);
+  return lm_probe_finish(t, in, wid, p, out);
 }
 
 }  // namespace ctc

@@ -115,7 +115,7 @@ struct RawGram {
 };
 
 static void table_put(std::vector<NgramEntry>& tab, uint64_t mask, uint64_t key, float p, float b) {
-  uint64_t s = mix64(key) & mask;
+  uint64_t s = key & mask;
   for (;;) {
     if (tab[s].key == 0 || tab[s].key == key) {
       tab[s].key = key;
@@ -219,9 +219,9 @@ std::string HostLM::load_arpa(const std::string& path) {
       }
       unigrams[id] = UnigramEntry{prob, backoff};
     } else {
-      uint64_t k = ngram_key_begin((uint32_t)section);
-      for (int j = 0; j < section; ++j) k = ngram_key_push(k, index(toks[j]));
-      raw.push_back(RawGram{ngram_key_end(k), prob, backoff});
+      uint64_t k = ngram_key_begin();  // newest word first (common.h)
+      for (int j = section - 1; j >= 0; --j) k = ngram_key_push(k, index(toks[j]));
+      raw.push_back(RawGram{ngram_key_end(k, (uint32_t)section), prob, backoff});
     }
   }
   free(buf);
@@ -247,7 +247,7 @@ std::string HostLM::load_arpa(const std::string& path) {
 
 // ---- flat model file: "CTCDLM01" | order, n_words, bos, eos (u32) | n_ngrams, table_size, blob_bytes (u64)
 //      | word end offsets u64[n_words] | word bytes | UnigramEntry[n_words] | NgramEntry[table_size] | "CTCDEND1"
-static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '1'};
+static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '2'};  // 02: n-gram keys newest-first, slot = key & mask
 static const char kCacheEnd[8] = {'C', 'T', 'C', 'D', 'E', 'N', 'D', '1'};
 
 std::string HostLM::save_cache(const std::string& path) const {
@@ -369,7 +369,7 @@ void HostLM::build_prefix_table() {
   prefix_mask = size - 1;
   for (auto& kv : m) {
     if (kv.first == 0) continue;
-    uint64_t s = mix64(kv.first) & prefix_mask;
+    uint64_t s = table_slot(kv.first) & prefix_mask;
     while (prefix_table[s].key != 0) s = (s + 1) & prefix_mask;
     prefix_table[s] = kv.second;
   }
@@ -435,7 +435,7 @@ void HostMulti::build() {
   prefix_mask = size - 1;
   for (auto& kv : m) {
     if (kv.first == 0) continue;
-    uint64_t s = mix64(kv.first) & prefix_mask;
+    uint64_t s = table_slot(kv.first) & prefix_mask;
     while (prefix_table[s].key != 0) s = (s + 1) & prefix_mask;
     prefix_table[s] = kv.second;
   }
@@ -495,7 +495,7 @@ void HostHotwords::build(const std::vector<std::string>& uni, const HostAlphabet
     mask = size - 1;
     for (auto& kv : m) {
       if (kv.first == 0) continue;
-      uint64_t s = mix64(kv.first) & mask;
+      uint64_t s = table_slot(kv.first) & mask;
       while (table[s].key != 0) s = (s + 1) & mask;
       table[s] = kv.second;
     }

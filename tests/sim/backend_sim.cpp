@@ -189,8 +189,8 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   const bool want_group = force && force[0] == 'g';
   if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
     switch (wave_bucket(a.params.beam_width)) {
-      case 32: run_wave<32>(a); break;
       case 64: run_wave<64>(a); break;
+      case 104: run_wave<104>(a); break;
       default: run_wave<128>(a); break;
     }
     g_last_kernel = 1;

@@ -151,6 +151,7 @@ struct SimWaveCtx {
       }
     return (uint32_t)s[0];
   }
+  uint32_t opaque32(uint32_t v) { return v; }
   uint32_t bcast32(uint32_t v, int src) {
     const uint64_t* s = all(((uint64_t)(uint32_t)src << 32) | v, 5);
     const int from = (int)(s[0] >> 32);
