@@ -99,6 +99,12 @@ int ctcdec_lm_set_unigrams(ctcdec_decoder* dec, int32_t has_unigrams, const char
  * BeamSearchDecoderCTC(alphabet, language_model) (decoder.py:275-290) is parsed only once. */
 int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src);
 
+/* Give `dst` a private COPY of the language model loaded into `src`. The reference builds many LanguageModels with
+ * different unigram sets on one immutable kenlm.Model (tests/test_decoder.py:188-280); here the unigram set lives
+ * in the model's prefix table, so every LanguageModel after the first gets its own copy instead of rewriting the
+ * tables under the decoders that share the first one. */
+int ctcdec_lm_clone(ctcdec_decoder* dst, const ctcdec_decoder* src);
+
 /* Replaces MultiLanguageModel (language_model.py:455-502): `dst` scores every word with the n
  * (2..CTCDEC_MAX_LMS) language models loaded into srcs[0..n) -- each from its own state, the scores
  * averaged (language_model.py:483-502), partial words by the mean of the models' unigram-trie scores
@@ -106,8 +112,8 @@ int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src);
  * unk_score_offset / lm_score_boundary from ctcdec_params like a single model; models 1.. take theirs
  * from ctcdec_lm_set_params (each reference LanguageModel carries its own, language_model.py:266-269).
  * With several models every "LM state" of the decode calls is n consecutive ctcdec_lm_state entries
- * in model order: start_states holds n per utterance, ctcdec_result_lm_state_of reads model k's.
- * Streaming (ctcdec_decode_stream_batch) is not available with several models (CTCDEC_ERR_LIMIT). */
+ * in model order: start_states holds n per utterance, ctcdec_result_lm_state_of reads model k's; a streaming
+ * beam (ctcdec_decode_stream_batch) carries the states of models 1.. in ctcdec_beam_in.more_states. */
 int ctcdec_lm_share_multi(ctcdec_decoder* dst, const ctcdec_decoder* const* srcs, int32_t n);
 int ctcdec_lm_set_params(ctcdec_decoder* dec, int32_t k /* 1..n-1 */, double alpha, double beta,
                          double unk_score_offset, int32_t lm_score_boundary);
@@ -227,6 +233,9 @@ int ctcdec_result_timing(const ctcdec_result* r, double* ms3);
  * (csrc/beam_core.h: everything else), 0 = empty batch. The environment variable CTCDEC_BEAM_KERNEL=group|wave
  * forces one of them (tests and tuning). */
 int ctcdec_result_beam_kernel(const ctcdec_result* r);
+/* HIP device index every decoder of this process runs on (-1 before the first ctcdec_create). One process drives one
+ * GPU: a ctcdec_create for a different device is refused (CTCDEC_ERR_DEVICE). */
+int ctcdec_device(void);
 void ctcdec_result_free(ctcdec_result* r);
 
 /* Diagnostics: the frame-prune stage alone on one [n_frames, V] matrix -- per frame the labels

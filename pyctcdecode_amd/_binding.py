@@ -93,6 +93,7 @@ _PROTOS = {
     "ctcdec_lm_set_unigrams": (C.c_int, [_VP, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
                                          C.POINTER(C.c_int64)]),
     "ctcdec_lm_share": (C.c_int, [_VP, _VP]),
+    "ctcdec_lm_clone": (C.c_int, [_VP, _VP]),
     "ctcdec_lm_share_multi": (C.c_int, [_VP, C.POINTER(_VP), C.c_int32]),
     "ctcdec_lm_set_params": (C.c_int, [_VP, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32]),
     "ctcdec_lm_count": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
@@ -122,6 +123,7 @@ _PROTOS = {
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "ctcdec_result_beam_kernel": (C.c_int, [_VP]),
+    "ctcdec_device": (C.c_int, []),
     "ctcdec_result_free": (None, [_VP]),
     "ctcdec_profile_phases": (C.c_int, [_VP, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]),
     "ctcdec_last_error": (C.c_char_p, []),

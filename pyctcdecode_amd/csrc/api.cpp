@@ -378,6 +378,16 @@ int ctcdec_lm_share(ctcdec_decoder* dst, const ctcdec_decoder* src) {
   return CTCDEC_OK;
 }
 
+int ctcdec_lm_clone(ctcdec_decoder* dst, const ctcdec_decoder* src) {
+  if (!dst || !src || !src->has_lm) return fail(CTCDEC_ERR_ARG, "source has no language model");
+  if (src->multi) return fail(CTCDEC_ERR_ARG, "source holds several language models");
+  dst->lm_ptr = std::make_shared<HostLM>(*src->lm_ptr);  // own tables: own unigram set, own prefix flags
+  dst->multi.reset();
+  dst->has_lm = true;
+  dst->tables_dirty = true;
+  return CTCDEC_OK;
+}
+
 int ctcdec_lm_share_multi(ctcdec_decoder* dst, const ctcdec_decoder* const* srcs, int32_t n) {
   if (!dst || !srcs || n < 2) return fail(CTCDEC_ERR_ARG, "a MultiLanguageModel holds at least 2 language models");
   if (n > CTCDEC_MAX_LMS) return fail(CTCDEC_ERR_LIMIT, "more language models than CTCDEC_MAX_LMS");
@@ -470,7 +480,9 @@ int ctcdec_lm_base_score(const ctcdec_decoder* dec, const ctcdec_lm_state* in, u
 
 int ctcdec_set_hotwords(ctcdec_decoder* dec, const char* blob, const int64_t* off, int64_t n_words) {
   if (!dec) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  std::string err;
   std::lock_guard<std::mutex> device_lock(g_device_mu);
+  if (be::bind_thread(&err)) return fail(CTCDEC_ERR_DEVICE, err);
   std::vector<std::string> uni;
   for (int64_t i = 0; i < n_words; ++i) uni.emplace_back(blob + off[i], (size_t)(off[i + 1] - off[i]));
   dec->hot.build(uni, dec->alpha);
@@ -653,6 +665,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   }
   const int K = dec->has_lm ? dec->n_lms() : 1;
   std::lock_guard<std::mutex> device_lock(g_device_mu);
+  if (be::bind_thread(&err)) return fail(CTCDEC_ERR_DEVICE, err);
   if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
@@ -975,6 +988,7 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   if (n_frames == 0) return CTCDEC_OK;
   std::string err;
   std::lock_guard<std::mutex> device_lock(g_device_mu);
+  if (be::bind_thread(&err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
   const size_t rows = (size_t)n_frames;
@@ -1157,6 +1171,7 @@ int ctcdec_result_timing(const ctcdec_result* r, double* ms3) {
   return CTCDEC_OK;
 }
 int ctcdec_result_beam_kernel(const ctcdec_result* r) { return r ? r->beam_kernel : 0; }
+int ctcdec_device(void) { return be::current_device(); }
 void ctcdec_result_free(ctcdec_result* r) { delete r; }
 
 }  // extern "C"

@@ -15,6 +15,8 @@ namespace be {
 
 const char* name();
 int init(int device, std::string* err);
+int bind_thread(std::string* err);  // make the decoder's device current for the calling host thread
+int current_device();               // device index all decoders of this process run on (-1: none yet)
 void* alloc(size_t bytes, std::string* err);
 void release(void* p);
 void* alloc_host(size_t bytes, std::string* err);  // page-locked staging memory for result copies

@@ -26,6 +26,7 @@ namespace be {
 static hipStream_t g_stream = nullptr;
 static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 static int g_device = -1;
+static int g_cus = 256;  // compute units of the device (MI355X: 256)
 static bool g_timing_valid = false;
 
 #define HIP_TRY(expr)                                                                    \
@@ -39,8 +40,21 @@ static bool g_timing_valid = false;
 
 const char* name() { return "hip-gfx950"; }
 
+// One process drives ONE GPU (the multi-GPU layout is one process per GPU): the stream, the
+// timing events and every workspace belong to the device of the first decoder. A later decoder asking for a
+// different device is refused instead of silently mixing that device's kernels with this device's stream.
 int init(int device, std::string* err) {
-  if (g_stream && device == g_device) return 0;
+  if (g_stream) {
+    int n = 0;
+    (void)hipGetDeviceCount(&n);
+    if (device < 0 || device >= n) device = 0;
+    if (device != g_device) {
+      if (err) *err = "this process already decodes on device " + std::to_string(g_device) + "; device " + std::to_string(device) +
+                      " needs its own process (one process per GPU)";
+      return -1;
+    }
+    return bind_thread(err);
+  }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) {
@@ -54,8 +68,18 @@ int init(int device, std::string* err) {
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreate(&g_ev[k]));
   }
   g_device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
   return 0;
 }
+
+// Host threads other than the one that created the decoder start with device 0 current: every entry point that
+// allocates, copies or launches binds the calling thread to the decoder's device first.
+int bind_thread(std::string* err) {
+  if (g_device >= 0) HIP_TRY(hipSetDevice(g_device));
+  return 0;
+}
+int current_device() { return g_device; }
 
 void* alloc(size_t bytes, std::string* err) {
   void* p = nullptr;
@@ -942,8 +966,14 @@ static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
 int last_beam_kernel() { return g_last_kernel; }
 
 int launch_beam(const BeamArgs& a, std::string* err) {
-  const char* force = getenv("CTCDEC_BEAM_KERNEL");  // tuning / tests: "wave" or "group"
-  const bool want_group = force && force[0] == 'g';
+  // Two kernels for the same recursion. One workgroup (4 waves) per utterance has the shorter frame
+  // (13.0 vs 14.9 us on the bench input) but only two utterances fit a CU; one wave per utterance keeps four
+  // (beam_width <= 104: five by LDS) resident and needs a quarter of the issue slots per utterance, so it wins as
+  // soon as there are more utterances than the workgroup kernel can hold at once (measured at 2048 utterances:
+  // 31 vs 48 ms). CTCDEC_BEAM_KERNEL=wave|group overrides the
+  // batch-size rule (tests, tuning; `wave` still falls back when the decode is not eligible for it).
+  const char* force = getenv("CTCDEC_BEAM_KERNEL");
+  const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
   if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
     int rc;
     switch (wave_bucket(a.params.beam_width)) {
@@ -955,10 +985,6 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     HIP_TRY(hipGetLastError());
     g_last_kernel = 1;
   } else if (a.n_utts > 0) {
-    if (force && force[0] == 'w') {
-      if (err) *err = "CTCDEC_BEAM_KERNEL=wave, but this decode is not eligible for the wave kernel";
-      return -1;
-    }
     LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
     size_t lds = lds_bytes(shape);
     if (lds > 160 * 1024) {

@@ -92,7 +92,7 @@ struct WaveShape {
   static constexpr int SLB = (BW + 63) / 64;      // beam slots per lane (lane = beam phases)
   static constexpr bool BIG = BW > 64;            // frames with more than 64 live beams can occur
   static constexpr int C = BIG ? 128 : 64;        // candidates that share one match table
-  static constexpr int P = BW + (BIG ? BW : 64);  // pool capacity: the kept beam_width + one pass of new ones
+  static constexpr int P = BW + C;                // pool capacity: the kept beam_width + one pass of new ones
   static constexpr int PE = (P + 63) / 64;        // pool entries per lane
   static constexpr int TS = 2 * C;                // match-table slots
 };

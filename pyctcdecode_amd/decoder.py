@@ -125,6 +125,7 @@ class _Batch:
         self.ptrs: List[int] = []
         self.frames: List[int] = []
         self.is_device = False
+        self.device_index: Optional[int] = None  # device of the logits when they are device tensors
         self.dtype = 0
         if getattr(logits_list, "ndim", 0) == 3 and self._from_3d(logits_list, n_labels):
             return
@@ -147,8 +148,6 @@ class _Batch:
         if self.is_device:
             import torch
 
-            # our kernels run on their own stream: make sure the producer of the logits is done
-            torch.cuda.current_stream().synchronize()
             native = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
             dtypes = {x.dtype for x in logits_list}
             if len(dtypes) == 1 and next(iter(dtypes)) in native:
@@ -164,6 +163,15 @@ class _Batch:
                 ptrs.append(t.data_ptr())
                 frames.append(t.shape[0])
             self.dtype = native[target]
+            # Our kernels run on their own stream: the producer of the logits AND the dtype / layout conversions
+            # enqueued just above (they run asynchronously on torch's stream) must be done before the native call
+            # reads them -- so synchronise AFTER the conversions, on the stream of the tensors' own device.
+            devs = {x.device for x in logits_list}
+            if len(devs) != 1:
+                raise ValueError("the logits of one batch must live on one device")
+            dev = next(iter(devs))
+            self.device_index = dev.index
+            torch.cuda.current_stream(dev).synchronize()
         else:
             arrs = [x.detach().cpu().numpy() if _is_device_tensor(x) else np.asarray(x) for x in logits_list]
             want32 = len(arrs) > 0 and all(a.dtype == np.float32 or a.dtype == np.float16 for a in arrs)
@@ -189,8 +197,10 @@ class _Batch:
             native = {torch.float32: 0, torch.float64: 1, torch.float16: 2, torch.bfloat16: 3}
             if batch.dtype not in native:
                 return False
-            torch.cuda.current_stream().synchronize()
             t = batch if batch.is_contiguous() else batch.contiguous()
+            # (after the possible layout copy, on the batch's own device: see the generic path)
+            torch.cuda.current_stream(batch.device).synchronize()
+            self.device_index = batch.device.index
             base, step = t.data_ptr(), t.stride(0) * t.element_size()
             self.dtype = native[batch.dtype]
             self.is_device = True
@@ -235,13 +245,14 @@ class BeamSearchDecoderCTC:
                 "(there is deliberately no CPU fallback)"
             )
         self._members = members
+        self._device = _default_device()  # one process per GPU: LOCAL_RANK, or CTCDEC_DEVICE when set
         lib = B.get_library()
         self._lib = lib
         blob, off = B.pack_strings(self._alphabet.labels)
         handle = C.c_void_p()
         lib.check(
             lib.dll.ctcdec_create(blob, B.off_ptr(off), len(self._alphabet.labels), int(self._is_bpe),
-                                  _default_device(), C.byref(handle))
+                                  self._device, C.byref(handle))
         )
         self._handle = handle
         if len(members) == 1:
@@ -347,6 +358,9 @@ class BeamSearchDecoderCTC:
     def _run_locked(self, logits_list: Sequence[Any], params: B.Params, hotwords, start_states=None):
         self._set_hotwords(hotwords)
         batch = _Batch(logits_list, len(self._idx2vocab))
+        if batch.is_device and batch.device_index is not None and batch.device_index != self._device:
+            raise ValueError("the logits live on cuda:%d but this decoder was built for cuda:%d (one process per GPU: "
+                             "LOCAL_RANK / CTCDEC_DEVICE pick the device)" % (batch.device_index, self._device))
         n = len(batch.ptrs)
         ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
         frames = (C.c_int32 * max(n, 1))(*batch.frames)
@@ -709,6 +723,9 @@ class BeamSearchDecoderCTC:
         blob = b"".join(pieces) or b"\0"
         params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, weight, 0)
         batch = _Batch(logits_list, len(self._idx2vocab))
+        if batch.is_device and batch.device_index is not None and batch.device_index != self._device:
+            raise ValueError("the logits live on cuda:%d but this decoder was built for cuda:%d (one process per GPU: "
+                             "LOCAL_RANK / CTCDEC_DEVICE pick the device)" % (batch.device_index, self._device))
         ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
         frames = (C.c_int32 * max(n, 1))(*batch.frames)
         first = (C.c_int32 * max(n, 1))(*[int(p) for p in processed_frames_list])

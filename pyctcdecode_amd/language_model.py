@@ -96,10 +96,19 @@ class NgramModel:
 
     FLAT_SUFFIX = ".ctcdec"
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, _clone_of: Optional["NgramModel"] = None):
         lib = B.get_library()
         self._lib = lib
         self.path = path.encode("utf-8")
+        self._unigrams_owned = False  # a LanguageModel has configured this model's unigram set
+        if _clone_of is not None:
+            blob, off = B.pack_strings([""])
+            handle = C.c_void_p()
+            lib.check(lib.dll.ctcdec_create(blob, B.off_ptr(off), 1, 0, _default_device(), C.byref(handle)))
+            self._handle = handle
+            lib.check(lib.dll.ctcdec_lm_clone(handle, _clone_of._handle))
+            self.order = _clone_of.order
+            return
         flat = path.endswith(self.FLAT_SUFFIX)
         if not flat and not path.endswith(".arpa"):
             raise NotImplementedError(
@@ -173,6 +182,10 @@ class NgramModel:
         s = NgramState.from_c(cout)
         out_state.length, out_state.words, out_state.backoff = s.length, s.words, s.backoff
         return float(p.value)
+
+    def private_copy(self) -> "NgramModel":
+        """The same n-gram tables under a handle of their own (its unigram set can differ)."""
+        return NgramModel(self.path.decode("utf-8"), _clone_of=self)
 
     def set_unigrams(self, unigrams: Optional[Collection[str]]) -> int:
         kept = C.c_int64()
@@ -316,6 +329,13 @@ class LanguageModel(AbstractLanguageModel):
             if path is None:
                 raise TypeError("kenlm_model must be an NgramModel or expose a .path")
             kenlm_model = NgramModel(path.decode("utf-8") if isinstance(path, bytes) else path)
+        # The reference treats kenlm.Model as immutable and builds many LanguageModels with different unigram sets
+        # on one (tests/test_decoder.py:188-280). Here the unigram set is part of the model's tables: the first
+        # LanguageModel configures the model it was given, every further one works on a private copy, so that
+        # earlier LanguageModels (and the decoders sharing their tables) keep their own OOV / partial-word scoring.
+        if kenlm_model._unigrams_owned:
+            kenlm_model = kenlm_model.private_copy()
+        kenlm_model._unigrams_owned = True
         self._kenlm_model = kenlm_model
         if unigrams is None:
             logger.warning("No known unigrams provided, decoding results might be a lot worse.")

@@ -1,69 +1,155 @@
 """Multi-GPU shell: utterances are independent (the reference's batch path is a plain map,
 decoder.py:856,944), so a batch is sharded one contiguous slice per rank with NO exchange during
-decoding; the only collective is the final gather of the decoded texts (sizes first, payload
-second) over torch.distributed (backend "nccl" == RCCL over xGMI on MI355X, "gloo" in CPU tests)."""
+decoding; the only collective is the final gather of the results over torch.distributed (backend
+"nccl" == RCCL over xGMI on MI355X, "gloo" in CPU tests).
+
+One collective per step: every rank packs [count, payload bytes, item lengths, payload] into one byte
+buffer of an agreed capacity and a single all_gather moves all of them; only when some rank's results do not
+fit the agreed capacity (every rank sees that in the gathered headers) a second all_gather with the exact
+maximum follows.  Without an agreed capacity the sizes go first (two collectives).
+"""
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+import pickle
+from typing import Any, List, Optional, Sequence
 
 import numpy as np
 
+_HDR = 16  # int64 item count, int64 payload bytes
+
 
 def shard_bounds(n_items: int, world_size: int, rank: int):
-    """Contiguous, balanced slice [lo, hi) of rank `rank`."""
+    """Contiguous, balanced-by-count slice [lo, hi) of rank `rank`."""
     base, rem = divmod(n_items, world_size)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_texts(texts: Sequence[str], device=None, group=None) -> Optional[List[str]]:
-    """All ranks call this with their shard's texts (in shard order); every rank gets the full list in
-    global order (all_gather keeps the call symmetric and needs no rank-0 special case)."""
-    import torch
-    import torch.distributed as dist
+def shard_bounds_by_frames(frames: Sequence[int], world_size: int, rank: int):
+    """Contiguous slice [lo, hi) of rank `rank`, balanced by the SUM OF FRAMES (ragged batches: the decode time of
+    a shard is proportional to its frames). Slice r ends at the first utterance whose cumulative
+    frame count reaches (r + 1) / world of the total; every rank computes the same bounds from the same list."""
+    n = len(frames)
+    if n == 0:
+        return 0, 0
+    cum = np.cumsum(np.asarray(frames, dtype=np.int64))
+    total = int(cum[-1])
+    if total == 0:
+        return shard_bounds(n, world_size, rank)
+    cuts = [0]
+    for r in range(1, world_size):
+        c = int(np.searchsorted(cum, total * r / world_size, side="left")) + 1
+        cuts.append(min(max(c, cuts[-1]), n))
+    cuts.append(n)
+    return cuts[rank], cuts[rank + 1]
 
-    if not dist.is_available() or not dist.is_initialized():
-        return list(texts)
-    world = dist.get_world_size(group)
-    enc = [t.encode("utf-8") for t in texts]
-    lens = np.array([len(e) for e in enc], dtype=np.int64)
-    payload = np.frombuffer(b"".join(enc), dtype=np.uint8)
-    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    meta = torch.tensor([len(enc), payload.size], dtype=torch.int64, device=dev)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    metas = [m.cpu().numpy() for m in metas]
-    max_n = int(max(m[0] for m in metas))
-    max_b = int(max(m[1] for m in metas))
-    lens_t = torch.zeros(max(max_n, 1), dtype=torch.int64, device=dev)
-    if len(enc):
-        lens_t[: len(enc)] = torch.from_numpy(lens).to(dev)
-    pay_t = torch.zeros(max(max_b, 1), dtype=torch.uint8, device=dev)
-    if payload.size:
-        pay_t[: payload.size] = torch.from_numpy(payload.copy()).to(dev)
-    all_lens = [torch.zeros_like(lens_t) for _ in range(world)]
-    all_pay = [torch.zeros_like(pay_t) for _ in range(world)]
-    dist.all_gather(all_lens, lens_t, group=group)
-    dist.all_gather(all_pay, pay_t, group=group)
-    out: List[str] = []
-    for r in range(world):
-        n, _ = int(metas[r][0]), int(metas[r][1])
-        ls = all_lens[r].cpu().numpy()[:n]
-        buf = all_pay[r].cpu().numpy().tobytes()
-        pos = 0
-        for ln in ls:
-            out.append(buf[pos : pos + int(ln)].decode("utf-8"))
-            pos += int(ln)
+
+def _pack(items: Sequence[bytes]) -> np.ndarray:
+    lens = np.array([len(b) for b in items], dtype=np.int32)
+    payload = b"".join(items)
+    buf = np.zeros(_HDR + 4 * len(items) + len(payload), dtype=np.uint8)
+    buf[:_HDR].view(np.int64)[:] = (len(items), len(payload))
+    buf[_HDR:_HDR + 4 * len(items)].view(np.int32)[:] = lens
+    buf[_HDR + 4 * len(items):] = np.frombuffer(payload, dtype=np.uint8)
+    return buf
+
+
+def _unpack(buf: np.ndarray) -> List[bytes]:
+    n, nbytes = (int(v) for v in buf[:_HDR].view(np.int64))
+    lens = buf[_HDR:_HDR + 4 * n].view(np.int32)
+    raw = buf[_HDR + 4 * n:_HDR + 4 * n + nbytes].tobytes()
+    out, pos = [], 0
+    for ln in lens:
+        out.append(raw[pos:pos + int(ln)])
+        pos += int(ln)
     return out
 
 
+def _all_gather_bytes(mine: np.ndarray, cap: int, world: int, dev, group) -> np.ndarray:
+    """One all_gather of `cap` bytes per rank; returns a [world, cap] uint8 array (host)."""
+    import torch
+    import torch.distributed as dist
+
+    send = torch.zeros(cap, dtype=torch.uint8)
+    k = min(cap, mine.size)
+    send[:k] = torch.from_numpy(mine[:k])
+    send = send.to(dev)
+    recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    return recv.cpu().numpy().reshape(world, cap)
+
+
+def gather_blobs(items: Sequence[bytes], capacity: Optional[int] = None, device=None, group=None) -> List[bytes]:
+    """All ranks call this with their shard's byte strings (in shard order); every rank gets all of them in rank
+    order. `capacity`: bytes per rank every rank agrees on WITHOUT talking (same value everywhere) -- then this is
+    one collective unless a rank overflows it."""
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        return list(items)
+    world = dist.get_world_size(group)
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    mine = _pack(items)
+    if capacity is None:  # sizes first: 16 bytes per rank, then the payload at the exact maximum
+        heads = _all_gather_bytes(mine, _HDR, world, dev, group)
+        need = max(_HDR + 4 * int(h[:8].view(np.int64)[0]) + int(h[8:16].view(np.int64)[0]) for h in heads)
+        got = _all_gather_bytes(mine, need, world, dev, group)
+    else:
+        cap = max(int(capacity), _HDR)
+        got = _all_gather_bytes(mine, cap, world, dev, group)
+        need = max(_HDR + 4 * int(g[:8].view(np.int64)[0]) + int(g[8:16].view(np.int64)[0]) for g in got)
+        if need > cap:  # (every rank sees the same headers, so every rank takes this branch together)
+            got = _all_gather_bytes(mine, need, world, dev, group)
+    out: List[bytes] = []
+    for r in range(world):
+        out.extend(_unpack(got[r]))
+    return out
+
+
+def text_capacity(n_items: int, frames: int) -> int:
+    """Bytes per rank that hold the texts of `n_items` utterances of about `frames` frames in all ordinary cases
+    (a decoded text is far shorter than its frame count; an overflow only costs the second collective)."""
+    return _HDR + n_items * (4 + 64 + max(0, int(frames)) // 2)
+
+
+def gather_texts(texts: Sequence[str], device=None, group=None, capacity: Optional[int] = None) -> List[str]:
+    """Every rank gets the texts of all ranks, in rank order (= global order for contiguous shards)."""
+    return [b.decode("utf-8") for b in gather_blobs([t.encode("utf-8") for t in texts], capacity, device, group)]
+
+
+def gather_objects(objs: Sequence[Any], device=None, group=None, capacity: Optional[int] = None) -> List[Any]:
+    """The same for arbitrary picklable results (decode_beams_batch: lists of OutputBeam)."""
+    return [pickle.loads(b) for b in gather_blobs([pickle.dumps(o, protocol=4) for o in objs], capacity, device, group)]
+
+
+def _frames_of(logits_list) -> List[int]:
+    return [int(x.shape[0]) for x in logits_list]
+
+
 def decode_batch_sharded(decoder, logits_list, group=None, **kwargs) -> List[str]:
-    """Each rank decodes its contiguous slice of `logits_list` on its own GPU; all ranks return the
-    texts of the whole batch in input order."""
+    """Each rank decodes its contiguous slice of `logits_list` (balanced by frames) on its own GPU; all ranks return
+    the texts of the whole batch in input order. One collective."""
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized():
         return decoder.decode_batch(None, logits_list, **kwargs)
-    lo, hi = shard_bounds(len(logits_list), dist.get_world_size(group), dist.get_rank(group))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    frames = _frames_of(logits_list)
+    spans = [shard_bounds_by_frames(frames, world, r) for r in range(world)]
+    lo, hi = spans[rank]
     local = decoder.decode_batch(None, logits_list[lo:hi], **kwargs)
-    return gather_texts(local, group=group)
+    cap = max(text_capacity(b - a, 0) + sum(frames[a:b]) // 2 for a, b in spans)  # the same on every rank
+    return gather_texts(local, group=group, capacity=cap)
+
+
+def decode_beams_batch_sharded(decoder, logits_list, group=None, **kwargs) -> List[List[Any]]:
+    """decode_beams_batch over the ranks (decoder.py:801-857): every rank returns the beams of the whole batch in
+    input order (beams carry last_lm_state=None, as in the reference's pool path)."""
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        return decoder.decode_beams_batch(None, logits_list, **kwargs)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds_by_frames(_frames_of(logits_list), world, rank)
+    local = decoder.decode_beams_batch(None, logits_list[lo:hi], **kwargs)
+    return gather_objects(local, group=group)

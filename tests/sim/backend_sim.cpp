@@ -42,6 +42,8 @@ struct SeqCtx {
 
 const char* name() { return "sim"; }
 int init(int, std::string*) { return 0; }
+int bind_thread(std::string*) { return 0; }
+int current_device() { return 0; }
 void* alloc(size_t bytes, std::string* err) {
   void* p = malloc(bytes ? bytes : 1);
   if (!p && err) *err = "out of host memory";
@@ -184,8 +186,8 @@ static void run_wave(const BeamArgs& a) {
 static int g_last_kernel = 0;
 int last_beam_kernel() { return g_last_kernel; }
 
-int launch_beam(const BeamArgs& a, std::string* err) {
-  const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend
+int launch_beam(const BeamArgs& a, std::string*) {
+  const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend (default here: wave)
   const bool want_group = force && force[0] == 'g';
   if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
     switch (wave_bucket(a.params.beam_width)) {
@@ -195,10 +197,6 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     }
     g_last_kernel = 1;
     return 0;
-  }
-  if (force && force[0] == 'w' && a.n_utts > 0) {
-    if (err) *err = "CTCDEC_BEAM_KERNEL=wave, but this decode is not eligible for the wave kernel";
-    return -1;
   }
   if (a.n_utts > 0) g_last_kernel = 2;
   LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);

@@ -8,7 +8,7 @@ import pytest
 import synth
 from tests.golden_util import LM_DIR, check_beams, lm_path, load_cases
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_beam_kernels")]
 
 CASES, INPUTS = load_cases()
 TOL = 1e-6
@@ -429,3 +429,44 @@ def test_hip_random_differential_slice():
     _loaded_native()
     stats = fuzz.run_many(60, 20260926, tol=TOL)
     assert sum(stats.values()) == 60 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 57, stats
+
+
+def test_hip_device_binding_and_kernel_choice(lm, monkeypatch):
+    """One process drives one GPU (LOCAL_RANK / CTCDEC_DEVICE), logits on another device are refused, and the two
+    beam kernels are chosen by batch size unless CTCDEC_BEAM_KERNEL says otherwise."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.language_model import _default_device
+
+    lib = _loaded_native()
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, lm.path)
+    assert lib.dll.ctcdec_device() == _default_device() == dec._device
+    x = torch.from_numpy(synth.d_flat(2, 0, 20, 29)).to("cuda:%d" % dec._device)
+    for kernel, code in (("wave", 1), ("group", 2)):
+        monkeypatch.setenv("CTCDEC_BEAM_KERNEL", kernel)
+        dec.decode_beams(x)
+        assert dec.last_beam_kernel == code
+    monkeypatch.delenv("CTCDEC_BEAM_KERNEL")
+    dec.decode_batch(None, [x] * 8)
+    assert dec.last_beam_kernel == 2  # a handful of utterances: one workgroup each
+    if torch.cuda.device_count() > 1:
+        other = torch.from_numpy(synth.d_flat(2, 0, 20, 29)).to("cuda:%d" % ((dec._device + 1) % torch.cuda.device_count()))
+        with pytest.raises(ValueError):
+            dec.decode_beams(other)
+
+
+def test_hip_permuted_and_mixed_dtype_device_batches(lm):
+    """Layout / dtype conversions of device tensors run on torch's stream; the native call must only start after
+    them (the synchronisation used to come BEFORE the conversions)."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, lm.path)
+    xs = np.stack([synth.d_words(2, u, 300, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=6.0) for u in range(24)])
+    want = dec.decode_batch(None, [x for x in xs])
+    tbv = torch.from_numpy(xs).cuda().permute(1, 0, 2).contiguous()      # [T, B, V] as a model would hold it
+    assert dec.decode_batch(None, tbv.permute(1, 0, 2)) == want          # non-contiguous [B, T, V] view
+    mixed = [torch.from_numpy(x).cuda().to(torch.float64 if u % 2 else torch.float32) for u, x in enumerate(xs)]
+    assert dec.decode_batch(None, mixed) == want

@@ -1,20 +1,35 @@
-"""CPU: the N>1 path (utterance sharding + the one text gather) on world_size=2 with gloo."""
+"""CPU: the N>1 path (utterance sharding + the one result gather) on world_size=2 with gloo."""
 import os
 import socket
 
+import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pyctcdecode_amd.parallel import decode_batch_sharded, gather_texts, shard_bounds
+from pyctcdecode_amd.parallel import (decode_batch_sharded, decode_beams_batch_sharded, gather_blobs, gather_texts,
+                                      shard_bounds, shard_bounds_by_frames, text_capacity)
+
+
+class _Item:
+    """A stand-in logits matrix: only .shape[0] (frames) and its identity matter here."""
+
+    def __init__(self, ident, frames):
+        self.ident, self.shape = ident, (frames, 4)
 
 
 class _FakeDecoder:
-    """Stands in for the GPU decoder: the text of an utterance is a function of its content only."""
+    """Stands in for the GPU decoder: the result of an utterance is a function of its content only."""
 
     def decode_batch(self, pool, logits_list, **kw):
-        return ["utt-%d-é%s" % (int(x[0]), "x" * int(x[0] % 5)) for x in logits_list]
+        return ["utt-%d-é%s" % (x.ident, "x" * (x.ident % 5)) for x in logits_list]
+
+    def decode_beams_batch(self, pool, logits_list, **kw):
+        return [[("beam", x.ident, k, float(x.shape[0])) for k in range(1 + x.ident % 3)] for x in logits_list]
+
+
+def _items(n):
+    return [_Item(i, 10 + 37 * (i % 4)) for i in range(n)]
 
 
 def _free_port():
@@ -25,17 +40,40 @@ def _free_port():
     return p
 
 
+_CALLS = []
+
+
 def _worker(rank, world, port, n_items, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    orig = dist.all_gather_into_tensor
+
+    def counting(*a, **k):
+        _CALLS.append(1)
+        return orig(*a, **k)
+
+    dist.all_gather_into_tensor = counting
     try:
-        items = [[i] for i in range(n_items)]
+        items = _items(n_items)
         texts = decode_batch_sharded(_FakeDecoder(), items)
+        n_text_calls = len(_CALLS)
+        beams = decode_beams_batch_sharded(_FakeDecoder(), items)
         lo, hi = shard_bounds(n_items, world, rank)
-        mine = gather_texts(["r%d-%d" % (rank, k) for k in range(lo, hi)])
+        mine = ["r%d-%d" % (rank, k) for k in range(lo, hi)]
+        del _CALLS[:]
+        agreed = gather_texts(mine, capacity=text_capacity(n_items, 100))       # fits: exactly one collective
+        one = len(_CALLS)
+        del _CALLS[:]
+        tight = gather_texts(mine, capacity=16)                                 # overflows: a second one follows
+        two = len(_CALLS)
+        del _CALLS[:]
+        sized = gather_texts(mine)                                              # no agreed capacity: sizes first
+        three = len(_CALLS)
+        blobs = gather_blobs([bytes([rank]) * (rank + 1)])
         with open(os.path.join(out_dir, "r%d.txt" % rank), "w") as f:
-            f.write("\n".join(texts) + "\n--\n" + "\n".join(mine))
+            f.write(repr({"texts": texts, "beams": beams, "agreed": agreed, "tight": tight, "sized": sized,
+                          "calls": [n_text_calls, one, two, three], "blobs": blobs}))
     finally:
         dist.destroy_process_group()
 
@@ -44,12 +82,17 @@ def _worker(rank, world, port, n_items, out_dir):
 def test_sharded_decode_world2(tmp_path, n_items):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
-    expect = _FakeDecoder().decode_batch(None, [[i] for i in range(n_items)])
+    items = _items(n_items)
+    expect = _FakeDecoder().decode_batch(None, items)
+    expect_beams = _FakeDecoder().decode_beams_batch(None, items)
+    mine = ["r%d-%d" % (rr, k) for rr in range(world) for k in range(*shard_bounds(n_items, world, rr))]
     for r in range(world):
-        a, b = open(tmp_path / ("r%d.txt" % r)).read().split("\n--\n")
-        assert a.split("\n") == expect
-        got = [s for s in b.split("\n") if s]
-        assert got == ["r%d-%d" % (rr, k) for rr in range(world) for k in range(*shard_bounds(n_items, world, rr))]
+        got = eval(open(tmp_path / ("r%d.txt" % r)).read())  # noqa: S307 (our own repr)
+        assert got["texts"] == expect
+        assert got["beams"] == expect_beams
+        assert got["agreed"] == mine and got["tight"] == mine and got["sized"] == mine
+        assert got["calls"] == [1, 1, 2, 2]  # decode_batch_sharded and an agreed capacity: ONE collective
+        assert got["blobs"] == [b"\x00", b"\x01\x01"]
 
 
 def test_shard_bounds_cover_everything():
@@ -59,3 +102,19 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_shard_bounds_by_frames_balance_ragged_batches():
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 5, 64, 257):
+        frames = [int(f) for f in rng.integers(0, 2000, size=n)]
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds_by_frames(frames, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            if n >= 8 * w:
+                loads = [sum(frames[a:b]) for a, b in spans]
+                assert max(loads) <= sum(frames) / w + max(frames)  # never worse than one utterance over the mean
+    # equal lengths: the same as the count-balanced split up to one utterance
+    spans = [shard_bounds_by_frames([100] * 10, 3, r) for r in range(3)]
+    assert [b - a for a, b in spans] in ([4, 3, 3], [3, 4, 3], [3, 3, 4], [4, 4, 2])

@@ -7,6 +7,8 @@ import pytest
 from tests.golden_util import check_beams, lm_path, load_cases
 from tests.sim_util import sim_library  # noqa: F401
 
+pytestmark = pytest.mark.usefixtures("both_beam_kernels")
+
 CASES, INPUTS = load_cases()
 
 

@@ -11,6 +11,8 @@ from pyctcdecode_amd.language_model import HotwordScorer
 from tests.golden_util import LM_DIR, TOY_ARPA, load_cases
 from tests.sim_util import sim_library  # noqa: F401
 
+pytestmark = pytest.mark.usefixtures("both_beam_kernels")
+
 CASES, INPUTS = load_cases()
 BY_NAME = {c["name"]: c for c in CASES}
 SAMPLE_LABELS = BY_NAME["toy_nolm_16beams"]["labels"]

@@ -10,6 +10,8 @@ from pyctcdecode_amd.alphabet import Alphabet
 from tests.golden_util import LM_DIR, check_beams
 from tests.sim_util import sim_library  # noqa: F401
 
+pytestmark = pytest.mark.usefixtures("both_beam_kernels")
+
 
 def _expected(orc, x, kw):
     with np.errstate(all="ignore"):
@@ -241,3 +243,42 @@ def test_random_differential_slice(sim_library):  # noqa: F811
 
     stats = fuzz.run_many(40, 20260925, tol=1e-9)
     assert sum(stats.values()) == 40 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 38, stats
+
+
+def test_language_models_on_one_ngram_model_keep_their_own_unigram_sets(sim_library):  # noqa: F811
+    """The reference builds many LanguageModels with different unigram sets on ONE kenlm.Model
+    (tests/test_decoder.py:188-280): building the second must not change how the first scores."""
+    from pyctcdecode_amd.decoder import BeamSearchDecoderCTC
+    from pyctcdecode_amd.language_model import LanguageModel, NgramModel
+
+    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
+    x = synth.d_words(2, 3, 40, synth.LIBRI_LABELS, False, LM.words, LM.sentences, 28, boost=5.0).astype(np.float64)
+    model = NgramModel(LM.path)
+    half = sorted(LM.words)[: len(LM.words) // 2]
+    lm_a = LanguageModel(model, LM.words)
+    dec_a = BeamSearchDecoderCTC(alpha, lm_a)
+    before = [(o.text, o.lm_score) for o in dec_a.decode_beams(x)]
+    lm_b = LanguageModel(model, half)            # same NgramModel, a different unigram set
+    dec_b = BeamSearchDecoderCTC(alpha, lm_b)
+    got_b = [(o.text, o.lm_score) for o in dec_b.decode_beams(x)]
+    after = [(o.text, o.lm_score) for o in dec_a.decode_beams(x)]
+    assert after == before
+    orc_a = build_oracle(alpha.labels, alpha.is_bpe, LM.path, LM.words)
+    orc_b = build_oracle(alpha.labels, alpha.is_bpe, LM.path, half)
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in dec_a.decode_beams(x)], _expected(orc_a, x, {}), what="lm_a")
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in dec_b.decode_beams(x)], _expected(orc_b, x, {}), what="lm_b")
+    assert got_b != before or half == sorted(LM.words)
+
+
+def test_kernel_selection_is_reported(sim_library, monkeypatch):  # noqa: F811
+    from pyctcdecode_amd import build_ctcdecoder
+
+    x = synth.d_flat(2, 0, 12, 29).astype(np.float64)
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, LM.path)
+    for kernel, code in (("wave", 1), ("group", 2)):
+        monkeypatch.setenv("CTCDEC_BEAM_KERNEL", kernel)
+        dec.decode_beams(x)
+        assert dec.last_beam_kernel == code
+    monkeypatch.setenv("CTCDEC_BEAM_KERNEL", "wave")
+    dec.decode_beams(x, beam_width=200)  # not eligible (beam_width > 128): the workgroup kernel takes it
+    assert dec.last_beam_kernel == 2
