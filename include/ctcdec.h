@@ -224,6 +224,9 @@ typedef struct ctcdec_packed {
   const double* raw_lm_score;      /* [n_beams] LM score sum of the beam's text (memo value) */
 } ctcdec_packed;
 int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out);
+/* Only the texts of all beams (utterance-major, the order of ctcdec_result_pack): UTF-8 blob + n+1 byte offsets. What
+ * decode_batch needs (decoder.py:895-945) without packing word frames and states. Owned by the result. */
+int ctcdec_result_texts(ctcdec_result* r, const char** blob_out, const int64_t** off_out, int64_t* n_out);
 
 /* timing of the last call's device stages in milliseconds (HIP events on the decode stream):
  * [0] frame-prune kernel, [1] beam kernel, [2] total device time incl. result copy */

@@ -25,6 +25,18 @@ int h2d(void* dst, const void* src, size_t bytes, std::string* err);
 int d2h(void* dst, const void* src, size_t bytes, std::string* err);
 int zero(void* dst, size_t bytes, std::string* err);
 int sync(std::string* err);
+// streams and events for the chunked pipeline of large batches (api.cpp: decode_pipelined). Every call above and the
+// launches below act on the current stream; stream 0 is the default.
+void use_stream(int idx);
+int n_events();
+int ev_record(int id, std::string* err);
+int ev_wait(int id, std::string* err);
+int ev_sync(int id, std::string* err);
+double ev_elapsed_ms(int a, int b);
+int d2h_async(void* dst, const void* src, size_t bytes, std::string* err);
+int sync_all(std::string* err);
+int cus();  // compute units of the device
+void set_last_timing(double prune_ms, double beam_ms);
 
 // Frame-prune stage: input normalisation (decoder.py:759-765), token prune (decoder.py:444-445)
 // and CPython-set ordering of the survivors, for every frame of every utterance.
@@ -45,6 +57,7 @@ struct PruneArgs {
   uint32_t* overflow;    // [2] [0]: a row had more than max_surv survivors, [1]: a probability-like utterance exists
   int32_t pass;          // 0: all utterances as logits + row sums + sniff; 1: redo the probability-like ones
   int32_t rows_aligned16; // every utterance base pointer is 16-byte aligned
+  int64_t row_base;      // first row of this launch (utt_row0 and the row-indexed arrays are absolute); n_rows rows follow
 };
 int launch_prune(const PruneArgs& a, std::string* err);
 

@@ -23,8 +23,16 @@
 namespace ctc {
 namespace be {
 
-static hipStream_t g_stream = nullptr;
+// Stream 0 is the decode stream of small batches; large batches are cut into chunks whose frame-prune kernels
+// (stream 0), beam kernels (stream 1) and result copies (stream 2) overlap (api.cpp: decode_pipelined). Every
+// backend call acts on the CURRENT stream (use_stream); calls are serialised by the caller's device mutex.
+constexpr int N_STREAMS = 3;
+constexpr int N_EVENTS = 80;
+static hipStream_t g_streams[N_STREAMS] = {nullptr, nullptr, nullptr};
+static hipStream_t g_stream = nullptr;  // the current one
 static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static hipEvent_t g_pool_ev[N_EVENTS] = {};
+static double g_timing_override[2] = {-1.0, -1.0};
 static int g_device = -1;
 static int g_cus = 256;  // compute units of the device (MI355X: 256)
 static bool g_timing_valid = false;
@@ -64,8 +72,10 @@ int init(int device, std::string* err) {
   if (device < 0 || device >= n) device = 0;
   HIP_TRY(hipSetDevice(device));
   if (!g_stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    for (int k = 0; k < N_STREAMS; ++k) HIP_TRY(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
+    g_stream = g_streams[0];
     for (int k = 0; k < 3; ++k) HIP_TRY(hipEventCreate(&g_ev[k]));
+    for (int k = 0; k < N_EVENTS; ++k) HIP_TRY(hipEventCreate(&g_pool_ev[k]));
   }
   g_device = device;
   hipDeviceProp_t prop;
@@ -120,9 +130,46 @@ int sync(std::string* err) {
   return 0;
 }
 
+void use_stream(int idx) { g_stream = g_streams[idx >= 0 && idx < N_STREAMS ? idx : 0]; }
+int n_events() { return N_EVENTS; }
+int ev_record(int id, std::string* err) {
+  HIP_TRY(hipEventRecord(g_pool_ev[id], g_stream));
+  return 0;
+}
+int ev_wait(int id, std::string* err) {  // the current stream waits for the event
+  HIP_TRY(hipStreamWaitEvent(g_stream, g_pool_ev[id], 0));
+  return 0;
+}
+int ev_sync(int id, std::string* err) {  // the host waits for the event
+  HIP_TRY(hipEventSynchronize(g_pool_ev[id]));
+  return 0;
+}
+double ev_elapsed_ms(int a, int b) {
+  float ms = 0.f;
+  return hipEventElapsedTime(&ms, g_pool_ev[a], g_pool_ev[b]) == hipSuccess ? (double)ms : 0.0;
+}
+int d2h_async(void* d, const void* s, size_t n, std::string* err) {
+  HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
+  return 0;
+}
+int sync_all(std::string* err) {
+  for (int k = 0; k < N_STREAMS; ++k) HIP_TRY(hipStreamSynchronize(g_streams[k]));
+  return 0;
+}
+int cus() { return g_cus; }
+void set_last_timing(double prune_ms, double beam_ms) {
+  g_timing_override[0] = prune_ms;
+  g_timing_override[1] = beam_ms;
+}
+
 void last_timing(double* prune_ms, double* beam_ms) {
   *prune_ms = 0;
   *beam_ms = 0;
+  if (g_timing_override[0] >= 0.0) {
+    *prune_ms = g_timing_override[0];
+    *beam_ms = g_timing_override[1];
+    return;
+  }
   if (!g_timing_valid) return;
   float a = 0, b = 0;
   if (hipEventSynchronize(g_ev[2]) != hipSuccess) return;
@@ -467,8 +514,8 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + wave;
-  if (row >= a.n_rows) return;
+  const int64_t row = a.row_base + (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  if (row >= a.row_base + a.n_rows) return;
   const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
   const int V = a.n_labels;
   const int u = find_utt(a.utt_row0, a.n_utts, row);
@@ -552,8 +599,8 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * PRUNE_WAVES + wave;
-  if (row >= a.n_rows) return;
+  const int64_t row = a.row_base + (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  if (row >= a.row_base + a.n_rows) return;
   const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
   const int V = a.n_labels;
   const int u = find_utt(a.utt_row0, a.n_utts, row);
@@ -690,6 +737,7 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
 int launch_prune(const PruneArgs& a, std::string* err) {
   if (a.pass == 0) {
     g_timing_valid = false;
+    g_timing_override[0] = g_timing_override[1] = -1.0;
     HIP_TRY(hipEventRecord(g_ev[0], g_stream));
   }
   if (a.n_rows > 0) {

@@ -496,11 +496,11 @@ class BeamSearchDecoderCTC:
         params = self._params(beam_width, beam_prune_logp, token_min_logp, True, hotword_weight, 1)
         res = self._run(logits_list, params, hotwords)
         try:
-            pk = B.Packed()
-            self._lib.check(self._lib.dll.ctcdec_result_pack(res, C.byref(pk)))
-            nb = int(pk.n_beams)
-            text_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
-            blob = C.string_at(pk.text_blob, int(text_off[nb])) if text_off[nb] else b""
+            blob_p, off_p, n = C.c_void_p(), C.POINTER(C.c_int64)(), C.c_int64()
+            self._lib.check(self._lib.dll.ctcdec_result_texts(res, C.byref(blob_p), C.byref(off_p), C.byref(n)))
+            nb = int(n.value)
+            text_off = np.ctypeslib.as_array(off_p, shape=(nb + 1,))
+            blob = C.string_at(blob_p, int(text_off[nb])) if text_off[nb] else b""
             off = text_off.tolist()
             if blob.isascii():  # byte offsets == character offsets: decode once, slice the str
                 text = blob.decode("ascii")

@@ -470,3 +470,28 @@ def test_hip_permuted_and_mixed_dtype_device_batches(lm):
     assert dec.decode_batch(None, tbv.permute(1, 0, 2)) == want          # non-contiguous [B, T, V] view
     mixed = [torch.from_numpy(x).cuda().to(torch.float64 if u % 2 else torch.float32) for u, x in enumerate(xs)]
     assert dec.decode_batch(None, mixed) == want
+
+
+def test_hip_chunked_pipeline_equals_the_sequential_path(lm, monkeypatch):
+    """More than 2 x 1024 utterances: chunks whose frame-prune / beam / copy-back stages overlap on three streams
+    (api.cpp). Same texts and beams as the sequential path; a probability-like utterance makes the optimistic
+    pipeline fall back."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, lm.path)
+    base = [synth.d_words(2, u, 14 + (7 * u) % 19, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=6.0) for u in range(64)]
+    xs = [torch.from_numpy(base[u % 64]).cuda() for u in range(2500)]
+    piped = dec.decode_batch(None, xs)
+    assert dec.last_beam_kernel == 1
+    monkeypatch.setenv("CTCDEC_NO_PIPELINE", "1")
+    plain = dec.decode_batch(None, xs)
+    monkeypatch.delenv("CTCDEC_NO_PIPELINE")
+    assert piped == plain and piped[:64] == piped[64:128]
+    e = np.exp(base[5].astype(np.float64))
+    ys = list(xs)
+    ys[2400] = torch.from_numpy((e / e.sum(axis=1, keepdims=True)).astype(np.float32)).cuda()
+    got = dec.decode_batch(None, ys)
+    assert got[:2400] == piped[:2400] and got[2401:] == piped[2401:]
+    assert got[2400] == dec.decode(ys[2400])
