@@ -857,19 +857,22 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   // queued right behind it on the same stream: the host never sits between the two kernels. The two
   // rare events the prune stage can report (probability-like input, survivor overflow) are read back
   // afterwards and simply redo the affected stage(s).
-  // ---- large batches: chunked pipeline -------------------------------------------------------------------
+  // ---- large batches: chunked pipeline (opt-in: CTCDEC_PIPELINE=1) -------------------------------------------
   // The batch is cut into chunks of as many utterances as the beam kernel keeps resident at once; chunk k's
   // frame-prune kernel (stream 0), chunk k-1's beam kernel (stream 1) and the copy-back + host replay of chunk
-  // k-2 overlap: the beam waves leave about half of the issue slots and most of the registers / LDS of a CU idle,
-  // which is where the frame-prune waves run. Optimistic: if a chunk reports one of the two rare prune events
-  // (probability-like input, survivor overflow) the whole batch is redone by the sequential path below.
+  // k-2 overlap. Optimistic: if a chunk reports one of the two rare prune events (probability-like input, survivor
+  // overflow) the whole batch is redone by the sequential path below.
+  // MEASURED AND LEFT OFF BY DEFAULT (MI355X, 4096 x T=1000): 83.5 ms per step against 78.6 ms sequential. The beam
+  // kernel is a per-utterance latency chain with one wave per SIMD; frame-prune waves sharing its CUs slow every
+  // chain (beam 58.8 -> 75.9 ms in total, prune 10.9 -> 21.6 ms), which costs more than the ~6 ms of hidden
+  // prune + host tail.
   bool pipelined_done = false;
   {
     const int32_t max_chunks = (be::n_events() - 1) / 4;  // four events per chunk
     int32_t chunk = 4 * be::cus();
     if ((n_utts + chunk - 1) / chunk > max_chunks) chunk = (n_utts + max_chunks - 1) / max_chunks;
     const int32_t n_chunks = (n_utts + chunk - 1) / chunk;
-    if (!stream && n_chunks >= 2 && !dec->profile && getenv("CTCDEC_NO_PIPELINE") == nullptr) {
+    if (!stream && n_chunks >= 2 && !dec->profile && getenv("CTCDEC_PIPELINE") != nullptr) {
       size_t rows = (size_t)std::max<int64_t>(R, 1);
       if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
           dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
@@ -1165,7 +1168,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   // host replay is independent per utterance: a few threads once there is enough of it
   if (head > 50000 && n_utts >= 16) {
     if (!dec->replay_pool) {
-      unsigned want = 15u;  // + the calling thread
+      unsigned want = 31u;  // + the calling thread
       if (const char* env = getenv("CTCDEC_REPLAY_THREADS")) want = (unsigned)std::max(0, atoi(env) - 1);
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
       dec->replay_pool.reset(new ReplayPool((int)std::min(want, hw > 1 ? hw - 1 : 0u)));
@@ -1433,6 +1436,15 @@ int ctcdec_result_timing(const ctcdec_result* r, double* ms3) {
 }
 int ctcdec_result_beam_kernel(const ctcdec_result* r) { return r ? r->beam_kernel : 0; }
 int ctcdec_device(void) { return be::current_device(); }
-void ctcdec_result_free(ctcdec_result* r) { delete r; }
+void ctcdec_result_free(ctcdec_result* r) {
+  if (!r) return;
+  // tearing down the per-beam strings and vectors of a large batch takes about as long as copying the results back
+  // from the device did: off the caller's thread
+  if (r->utts.size() >= 256) {
+    std::thread([r] { delete r; }).detach();
+  } else {
+    delete r;
+  }
+}
 
 }  // extern "C"

@@ -952,9 +952,15 @@ struct WaveGpuCtx {
     return incl - v;
   }
   __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-    return v;
+    // DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): six VALU steps, no LDS round trips
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
   }
   __device__ __forceinline__ void lds_max_u64(CTC_LDS uint64_t* p, uint64_t v) {
     __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

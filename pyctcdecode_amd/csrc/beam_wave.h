@@ -111,6 +111,7 @@ struct WaveLds {
   // donor word: beam index | label << 8 | label is blank << 29 | donor's branch << 30
   LPtr<u32x4> pool;      // [P * 3]
   LPtr<uint32_t> sel;    // [BW]
+  LPtr<unsigned long long> prof;  // [W_PROF_N] phase tick accumulators (diagnostics)
   // scalar views of the beam records
   LPtr<uint64_t> b64;
   LPtr<double> bf64;
@@ -131,6 +132,7 @@ CTC_HD size_t wave_lds_carve(WaveLds& o, lds_bytes_t base) {
   o.lab = lds_take<u32x4>(p, 16 * 3 * WAVE_LAB);
   o.pool = lds_take<u32x4>(p, 48 * S::P);
   o.sel = lds_take<uint32_t>(p, 4 * BW);
+  o.prof = lds_take<unsigned long long>(p, 8 * 16);
   lds_bytes_t shared0 = p;
   o.c_logit = lds_take<double>(p, 8 * S::C);
   o.c_br = lds_take<uint32_t>(p, 4 * S::C);
@@ -222,7 +224,7 @@ struct WaveDecoder {
   CTC_HD void tick() {
     if (io.prof && lane == 0) {
       unsigned long long now = ctx.clock();
-      io.prof[PHASE] += now - t_last;
+      L.prof[PHASE] += now - t_last;
       t_last = now;
     }
   }
@@ -365,28 +367,29 @@ CTC_UNROLL
       lc[j] = 0;
       if (j * 64 >= N) continue;
       const int i = j * 64 + lane;
-      if (i < N) {
-        const u32x4 k1 = L.beams[i * BREC + 1];
-        lc[j] = k1[2] & 0xFFFFu;
-        if (j == 0) {
-          const u32x4 k5 = L.beams[i * BREC + 5];
-          cp_cand = (k1[2] >> 16) > 0 && k5[1] == 0;
-          if (cp_cand) {
-            CompSrc q;
-            comp_fetch(q, i, k1, k5);
-            cp_wid = q.wid;
-            cp_m2 = q.m2;
-            cp_text = q.text;
-            cp_part = q.part;
-            cp_ring3 = q.ring3;
-            cp_raw = q.raw;
-            cp_c2 = q.c2;
-            cp_c3 = q.c3;
-            cp_c4 = q.c4;
-            cp_c5 = q.c5;
-            cp_c6 = q.c6;
-          }
-        }
+      if (j == 0) {
+        // Every lane loads (a lane without a beam, or whose beam needs no completion, reads the node of beam 0):
+        // behind a divergent branch the compiler cannot count the loads in flight, and the first wait for any OLDER
+        // load -- the prefetched label constants, a few lines on -- would turn into a wait for these as well.
+        const int ii = i < N ? i : 0;
+        const u32x4 k1 = L.beams[ii * BREC + 1], k5 = L.beams[ii * BREC + 5];
+        lc[0] = i < N ? (k1[2] & 0xFFFFu) : 0u;
+        cp_cand = i < N && (k1[2] >> 16) > 0 && k5[1] == 0;
+        CompSrc q;
+        comp_fetch(q, ii, k1, k5);
+        cp_wid = q.wid;
+        cp_m2 = q.m2;
+        cp_text = q.text;
+        cp_part = q.part;
+        cp_ring3 = q.ring3;
+        cp_raw = q.raw;
+        cp_c2 = q.c2;
+        cp_c3 = q.c3;
+        cp_c4 = q.c4;
+        cp_c5 = q.c5;
+        cp_c6 = q.c6;
+      } else if (i < N) {
+        lc[j] = L.b32[i * 28 + 6] & 0xFFFFu;
       }
     }
   }
@@ -570,28 +573,39 @@ CTC_UNROLL
       const uint64_t key = ok ? score_sort_key(sc) : ~0ull;
       const uint64_t hk = with_hist ? q_hi(p0) : 0ull;
       const uint64_t pm = ctx.ballot(ok);
-      uint32_t rank = 0, same = 0, dup = 0;
+      const uint32_t np = (uint32_t)ctx.popc64(pm);
+      uint32_t rank = 0, dup = 0;
+      // two passing entries per iteration (their readlanes and compares interleave)
+      uint64_t m = pm;
       if (with_hist) {
-        for (uint64_t m = pm; m; m &= m - 1ull) {
-          const int j = ctx.ctz64(m);
-          const uint64_t x = ctx.bcast64(key, j), xh = ctx.bcast64(hk, j);
-          const bool better = x < key;
-          rank += better ? 1u : 0u;
-          same += x == key ? 1u : 0u;
-          dup |= (better && xh == hk) ? 1u : 0u;
+        while (m) {
+          const int j0 = ctx.ctz64(m);
+          m &= m - 1ull;
+          const int j1 = m ? ctx.ctz64(m) : j0;
+          m &= m - 1ull;
+          const uint64_t x0 = ctx.bcast64(key, j0), h0 = ctx.bcast64(hk, j0);
+          const uint64_t x1 = ctx.bcast64(key, j1), h1 = ctx.bcast64(hk, j1);
+          const bool b0 = x0 < key, b1 = x1 < key && j1 != j0;
+          rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
+          dup |= ((b0 && h0 == hk) || (b1 && h1 == hk)) ? 1u : 0u;
         }
       } else {
-        for (uint64_t m = pm; m; m &= m - 1ull) {
-          const int j = ctx.ctz64(m);
-          const uint64_t x = ctx.bcast64(key, j);
-          rank += x < key ? 1u : 0u;
-          same += x == key ? 1u : 0u;
+        while (m) {
+          const int j0 = ctx.ctz64(m);
+          m &= m - 1ull;
+          const int j1 = m ? ctx.ctz64(m) : j0;
+          m &= m - 1ull;
+          const uint64_t x0 = ctx.bcast64(key, j0), x1 = ctx.bcast64(key, j1);
+          rank += (x0 < key ? 1u : 0u) + ((x1 < key && j1 != j0) ? 1u : 0u);
         }
       }
-      if (ctx.ballot(ok && same > 1u) != 0ull) {  // equal scores (rare): the earlier arrival ranks first
+      // Without equal scores the ranks of the passing entries are a permutation of 0 .. np-1; an equal pair shares
+      // a rank and makes their sum smaller -- one wave sum instead of an equality count per broadcast entry.
+      if (ctx.wave_sum_u32(ok ? rank : 0u) != np * (np - 1u) / 2u) {
+        // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
         const uint32_t arr = mine ? (L.pool[e * 3 + 2][0] & 0xFFFFu) : 0u;
-        for (uint64_t m = pm; m; m &= m - 1ull) {
-          const int j = ctx.ctz64(m);
+        for (uint64_t t = pm; t; t &= t - 1ull) {
+          const int j = ctx.ctz64(t);
           const uint64_t x = ctx.bcast64(key, j), xh = ctx.bcast64(hk, j);
           const uint32_t xa = ctx.bcast32(arr, j);
           const bool before = ok && x == key && xa < arr;
@@ -1656,12 +1670,17 @@ CTC_UNROLL
 
   CTC_HD void run() {
     init();
-    if (io.prof && lane == 0) t_last = ctx.clock();
+    if (io.prof && lane == 0) {
+      for (int k = 0; k < 16; ++k) L.prof[k] = 0;
+      t_last = ctx.clock();
+    }
     prefetch(0);
     prefetch_tok();
     for (int t = 0; t < io.T; ++t) step(t);
     finalise();
     tick<W_PROF_FINAL>();
+    if (io.prof && lane == 0)
+      for (int k = 0; k < W_PROF_N; ++k) io.prof[k] = L.prof[k];
   }
 };
 
