@@ -555,6 +555,52 @@ CTC_UNROLL
     em_pending = false;
   }
 
+  // One entry per lane (`ok` lanes, mask pm; e = the lane's pool index): rank by (key asc = score desc, arrival asc),
+  // history duplicates flagged; writes L.sel for the ranks below `want`.
+  CTC_HD void rank_lanes(uint64_t key, uint64_t hk, bool ok, uint64_t pm, uint32_t e, bool with_hist, uint32_t want) {
+    const uint32_t np = (uint32_t)ctx.popc64(pm);
+    uint32_t rank = 0, dup = 0;
+    // two passing entries per iteration (their readlanes and compares interleave)
+    uint64_t m = pm;
+    if (with_hist) {
+      while (m) {
+        const int j0 = ctx.ctz64(m);
+        m &= m - 1ull;
+        const int j1 = m ? ctx.ctz64(m) : j0;
+        m &= m - 1ull;
+        const uint64_t x0 = ctx.bcast64(key, j0), h0 = ctx.bcast64(hk, j0);
+        const uint64_t x1 = ctx.bcast64(key, j1), h1 = ctx.bcast64(hk, j1);
+        const bool b0 = x0 < key, b1 = x1 < key && j1 != j0;
+        rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
+        dup |= ((b0 && h0 == hk) || (b1 && h1 == hk)) ? 1u : 0u;
+      }
+    } else {
+      while (m) {
+        const int j0 = ctx.ctz64(m);
+        m &= m - 1ull;
+        const int j1 = m ? ctx.ctz64(m) : j0;
+        m &= m - 1ull;
+        const uint64_t x0 = ctx.bcast64(key, j0), x1 = ctx.bcast64(key, j1);
+        rank += (x0 < key ? 1u : 0u) + ((x1 < key && j1 != j0) ? 1u : 0u);
+      }
+    }
+    // Without equal scores the ranks of the passing entries are a permutation of 0 .. np-1; an equal pair shares
+    // a rank and makes their sum smaller -- one wave sum instead of an equality count per broadcast entry.
+    if (ctx.wave_sum_u32(ok ? rank : 0u) != np * (np - 1u) / 2u) {
+      // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
+      const uint32_t arr = ok ? (L.pool[e * 3 + 2][0] & 0xFFFFu) : 0u;
+      for (uint64_t t = pm; t; t &= t - 1ull) {
+        const int j = ctx.ctz64(t);
+        const uint64_t x = ctx.bcast64(key, j), xh = ctx.bcast64(hk, j);
+        const uint32_t xa = ctx.bcast32(arr, j);
+        const bool before = ok && x == key && xa < arr;
+        rank += before ? 1u : 0u;
+        dup |= (before && xh == hk) ? 1u : 0u;
+      }
+    }
+    if (ok && rank < want) L.sel[rank] = e | ((with_hist && dup) ? 0u : 0x80000000u);
+  }
+
   // ---- pool ranking --------------------------------------------------------------------------
   // Ranks the pool entries with score >= thr by (score desc, arrival asc); L.sel[r] = pool index of rank r
   // (bit 31: kept by the history prune) for r < min(count, beam_width). Returns the count.
@@ -570,50 +616,8 @@ CTC_UNROLL
       if (mine) p0 = L.pool[e * 3];
       const double sc = bits_f64(q_lo(p0));
       const bool ok = mine && sc >= thr;
-      const uint64_t key = ok ? score_sort_key(sc) : ~0ull;
-      const uint64_t hk = with_hist ? q_hi(p0) : 0ull;
       const uint64_t pm = ctx.ballot(ok);
-      const uint32_t np = (uint32_t)ctx.popc64(pm);
-      uint32_t rank = 0, dup = 0;
-      // two passing entries per iteration (their readlanes and compares interleave)
-      uint64_t m = pm;
-      if (with_hist) {
-        while (m) {
-          const int j0 = ctx.ctz64(m);
-          m &= m - 1ull;
-          const int j1 = m ? ctx.ctz64(m) : j0;
-          m &= m - 1ull;
-          const uint64_t x0 = ctx.bcast64(key, j0), h0 = ctx.bcast64(hk, j0);
-          const uint64_t x1 = ctx.bcast64(key, j1), h1 = ctx.bcast64(hk, j1);
-          const bool b0 = x0 < key, b1 = x1 < key && j1 != j0;
-          rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
-          dup |= ((b0 && h0 == hk) || (b1 && h1 == hk)) ? 1u : 0u;
-        }
-      } else {
-        while (m) {
-          const int j0 = ctx.ctz64(m);
-          m &= m - 1ull;
-          const int j1 = m ? ctx.ctz64(m) : j0;
-          m &= m - 1ull;
-          const uint64_t x0 = ctx.bcast64(key, j0), x1 = ctx.bcast64(key, j1);
-          rank += (x0 < key ? 1u : 0u) + ((x1 < key && j1 != j0) ? 1u : 0u);
-        }
-      }
-      // Without equal scores the ranks of the passing entries are a permutation of 0 .. np-1; an equal pair shares
-      // a rank and makes their sum smaller -- one wave sum instead of an equality count per broadcast entry.
-      if (ctx.wave_sum_u32(ok ? rank : 0u) != np * (np - 1u) / 2u) {
-        // equal scores (rare): the earlier arrival ranks first (heapq.nlargest is stable)
-        const uint32_t arr = mine ? (L.pool[e * 3 + 2][0] & 0xFFFFu) : 0u;
-        for (uint64_t t = pm; t; t &= t - 1ull) {
-          const int j = ctx.ctz64(t);
-          const uint64_t x = ctx.bcast64(key, j), xh = ctx.bcast64(hk, j);
-          const uint32_t xa = ctx.bcast32(arr, j);
-          const bool before = ok && x == key && xa < arr;
-          rank += before ? 1u : 0u;
-          dup |= (before && xh == hk) ? 1u : 0u;
-        }
-      }
-      if (ok && rank < want) L.sel[rank] = e | ((with_hist && dup) ? 0u : 0x80000000u);
+      rank_lanes(ok ? score_sort_key(sc) : ~0ull, with_hist ? q_hi(p0) : 0ull, ok, pm, e, with_hist, want);
       ctx.wsync();
       return (uint32_t)ctx.popc64(pm);
     }
@@ -640,7 +644,19 @@ CTC_UNROLL
       n_pass += (uint32_t)ctx.popc64(bm);
     }
     ctx.wsync();
-    const uint32_t R = (n_pass + 63u) >> 6;  // compacted entries per lane (1 in all but the heaviest frames)
+    if (n_pass <= 64u) {  // (all but the heaviest frames) one compacted entry per lane: the register loop of the small pool
+      const bool ok = (uint32_t)lane < n_pass;
+      u32x4 r = mk4(~0u, ~0u, 0, 0);
+      uint32_t e = 0;
+      if (ok) {
+        r = L.rank_rec[lane];
+        e = ridx[lane];
+      }
+      rank_lanes(q_lo(r), q_hi(r), ok, n_pass >= 64u ? ~0ull : ((1ull << n_pass) - 1ull), e, with_hist, want);
+      ctx.wsync();
+      return n_pass;
+    }
+    const uint32_t R = (n_pass + 63u) >> 6;  // compacted entries per lane
     uint64_t key[PE], hk[PE];
     uint32_t rank[PE], same[PE], dup[PE];
 CTC_UNROLL
