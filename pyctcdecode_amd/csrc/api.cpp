@@ -826,6 +826,8 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   dp.score_boundary = p->lm_score_boundary ? 1 : 0;
   dp.fold = stream ? stream->fold : 1;
   dp.eos = stream ? stream->eos : 1;
+  dp.no_label_runs = getenv("CTCDEC_NO_LABEL_RUNS") != nullptr ? 1 : 0;
+  dp.pad_ = 0;
   ba.n_utts = n_utts;
   ba.utt_row0 = (const int64_t*)dec->w_row0.p;
   ba.surv_cnt = (const uint32_t*)dec->w_scnt.p;

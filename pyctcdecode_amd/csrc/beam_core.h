@@ -309,6 +309,7 @@ struct BeamDecoder {
   double pf_lp = 0.0;
   bool pf_live = false;
   bool flush_nodes = false;        // TextNode stores of this frame still to be completed behind a barrier
+  bool run_ok = false;             // the beam table is the output of a full frame of this launch (label_run)
   TokLite pf_tok;                  // ... and the label constants of this thread's survivor
   unsigned long long t_last = 0;
   unsigned long long t_acc[N_PROF] = {};
@@ -1289,8 +1290,87 @@ CTC_UNROLL
     *cc = c;
   }
 
-  CTC_HD void step(int t) {
+  // ---- runs of single-label frames ----------------------------------------------------------------
+  // A frame whose only survivor is the label every live beam already ends in (a blank after blanks, a held token)
+  // extends every beam in place (decoder.py:452-471): logit += p and, for a token, the end frame of the open word.
+  // Nothing merges (the merge and history keys are those of the previous frame, which left them distinct), no word
+  // completes, every score moves by the same p -- up to fp rounding, so each frame's new scores are checked to be
+  // still sorted and above the threshold; the first frame where they are not, or with another survivor set, ends the
+  // run and takes the full path. Same rule as WaveDecoder::label_run (beam_wave.h). Returns the first frame not
+  // consumed (t: none). Scratch: c_logit / p_score (new logits / scores), p_logit (look-ahead window),
+  // scal[14] (stop flag), scal[15] (window length).
+  CTC_HD int label_run(int t) {
+    const BeamSoA b = beams_at(cur);
+    if (ctx.tid == 0) {
+      L.surv[0].id = pf_id;
+      L.surv[0].lp = pf_lp;
+      L.stok[0].flags = pf_tok.flags;
+      L.scal[14] = 0;
+    }
+    ctx.sync();
+    const uint32_t lab = L.surv[0].id;
+    for (int i = ctx.tid; i < N; i += ctx.nt)
+      if (last_char(b, i) != lab) L.scal[14] = 1u;
+    ctx.sync();
+    if (L.scal[14]) return t;
+    const bool lab_is_blank = (L.stok[0].flags & TK_BLANK) != 0u;
+    double p = L.surv[0].lp;
+    uint32_t w_n = 0, w_pos = 0;
+    int tt = t;
+    for (;;) {
+      for (int i = ctx.tid; i < N; i += ctx.nt) {
+        const double nl = b.logit[i] + p;
+        L.c_logit[i] = nl;
+        L.p_score[i] = total_score(tab, nl, b.lm_hw[i], b.pscore[i], plen(b, i));
+      }
+      ctx.sync();
+      const double thr = L.p_score[0] + prm.beam_prune_logp;
+      for (int i = ctx.tid; i < N; i += ctx.nt) {
+        const double sc = L.p_score[i];
+        bool bad = !(sc >= thr);
+        if (i + 1 < N) bad = bad || !(sc >= L.p_score[i + 1]);
+        if (bad) L.scal[14] = 1u;
+      }
+      ctx.sync();
+      if (L.scal[14]) break;
+      for (int i = ctx.tid; i < N; i += ctx.nt) b.logit[i] = L.c_logit[i];
+      ++tt;
+      if (tt >= io.T) break;
+      if (w_pos == w_n) {  // look ahead: up to 64 frames, one per thread
+        if (ctx.tid == 0) L.scal[15] = 64u;
+        ctx.sync();
+        for (int k = ctx.tid; k < 64; k += ctx.nt) {
+          const int f = tt + k;
+          bool q = false;
+          if (f < io.T) {
+            q = io.surv_cnt[f] == 1u && io.surv_id[(size_t)f * prm.max_surv] == lab;
+            L.p_logit[k] = io.surv_lp[(size_t)f * prm.max_surv];
+          }
+          if (!q) ctx.atomic_min(&L.scal[15], (uint32_t)k);
+        }
+        ctx.sync();
+        w_n = L.scal[15];
+        w_pos = 0;
+        if (w_n == 0) break;
+      }
+      p = L.p_logit[w_pos];
+      ++w_pos;
+    }
+    if (tt == t) return t;
+    if (!lab_is_blank)
+      for (int i = ctx.tid; i < N; i += ctx.nt) b.pend[i] = io.first_frame + tt;  // last held frame + 1
+    ctx.sync();
+    prefetch(tt);
+    prefetch_tok();
+    return tt;
+  }
+
+  CTC_HD int step(int t) {
     int frame = io.first_frame + t;
+    if (run_ok && pf_cnt == 1u && N > 0 && !prm.no_label_runs) {
+      const int t2 = label_run(t);
+      if (t2 > t) return t2;
+    }
     if (ctx.tid == 0) {
       L.scal[0] = 0;
       L.scal[4] = 0;
@@ -1341,6 +1421,8 @@ CTC_UNROLL
     }
     prefetch_tok();
     finish_frame(frame, false);
+    run_ok = true;
+    return t + 1;
   }
 
   // threshold prune, top-B, history prune, next beam table (decoder.py:545-554)
@@ -1732,7 +1814,7 @@ CTC_UNROLL
     if (io.prof && ctx.tid == 0) t_last = ctx.clock();
     prefetch(0);
     prefetch_tok();
-    for (int t = 0; t < io.T; ++t) step(t);
+    for (int t = 0; t < io.T;) t = step(t);
     tick<9>();
     finalise();
     tick<10>();

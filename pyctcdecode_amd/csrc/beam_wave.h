@@ -157,7 +157,7 @@ CTC_HD int wave_bucket(int beam_width) { return beam_width <= 64 ? 64 : beam_wid
 
 constexpr int W_PROF_LOAD = 0, W_PROF_COMP = 1, W_PROF_GEN = 2, W_PROF_MATCH = 3, W_PROF_FOLD = 4, W_PROF_SCORE = 5,
               W_PROF_RANK = 6, W_PROF_BUILD = 7, W_PROF_FINAL = 8, W_PROF_COMPACT = 9, W_PROF_PUSH = 10, W_PROF_PFTOK = 11,
-              W_PROF_GATHER = 12, W_PROF_FETCH = 13, W_PROF_BEGIN = 14, W_PROF_N = 15;
+              W_PROF_GATHER = 12, W_PROF_FETCH = 13, W_PROF_BEGIN = 14, W_PROF_RUN = 15, W_PROF_N = 16;
 
 template <class Ctx, int BW>
 struct WaveDecoder {
@@ -215,6 +215,7 @@ struct WaveDecoder {
   uint32_t em_idx[SLB];
   u32x4 em_node[SLB];
   bool tok_pending = false;  // the label constants of the next frame's survivors still have to be fetched
+  bool run_ok = false;       // the beam table is the output of a full frame of this launch (label_run's precondition)
   unsigned long long t_last = 0;  // (diagnostics: phase ticks are accumulated in global memory, not registers)
 
   CTC_HD WaveDecoder(Ctx& c, WaveLds& l, const DeviceTables& t, const DecodeParams& p, const UttIO& i)
@@ -1124,9 +1125,114 @@ CTC_UNROLL
   }
 
   // ---- one frame ---------------------------------------------------------------------------------
-  CTC_HD void step(int t) {
+  // ---- runs of single-label frames ----------------------------------------------------------------
+  // A frame whose only survivor is the label every live beam already ends in -- a blank after blanks, a token
+  // that is held -- extends every beam in place (decoder.py:452-471): logit += p and, for a token, the end frame of
+  // the open word. Nothing merges (the merge and history keys are those of the previous frame, which left them
+  // distinct), no word completes, and every score moves by the same p: the threshold prune and the stable sort keep
+  // each beam where it is. "The same p" holds only up to fp rounding, so each frame's new scores are CHECKED to be
+  // still sorted and above the threshold; the first frame where they are not, or that has another survivor set,
+  // ends the run and goes through the full path. Real CTC posteriors are mostly such frames (the reference's
+  // libri sample: 327 of 371 frames have one survivor). Returns the first frame not consumed (t: none was).
+  CTC_HD int label_run(int t, uint32_t lab, bool lab_is_blank) {
+    double lg[SLB], rest[SLB], psc[SLB];
+    uint32_t pl[SLB];
+    bool live[SLB];
+CTC_UNROLL
+    for (int j = 0; j < SLB; ++j) {
+      const int i = j * 64 + lane;
+      live[j] = i < N;
+      lg[j] = rest[j] = psc[j] = 0.0;
+      pl[j] = 0;
+      if (live[j]) {
+        lg[j] = L.bf64[i * 14 + 2];
+        rest[j] = L.bf64[i * 14 + 5];
+        psc[j] = L.bf64[i * 14 + 7];
+        pl[j] = L.b32[i * 28 + 6] >> 16;
+      }
+    }
+    double p = bits_f64(ctx.bcast64(f64_bits(pf_lp), 0));
+    double w_lp = 0.0;  // look-ahead window: lane k holds the survivor of frame tt + k
+    uint32_t w_n = 0, w_pos = 0;
+    int tt = t;
+    for (;;) {
+      double nl[SLB], sc[SLB];
+CTC_UNROLL
+      for (int j = 0; j < SLB; ++j) {
+        nl[j] = lg[j] + p;
+        sc[j] = total_score(tab, nl[j], rest[j], psc[j], pl[j]);
+        if (live[j]) L.c_logit[j * 64 + lane] = sc[j];
+      }
+      ctx.wsync();
+      const double thr = L.c_logit[0] + prm.beam_prune_logp;
+      bool bad = false;
+CTC_UNROLL
+      for (int j = 0; j < SLB; ++j) {
+        const int i = j * 64 + lane;
+        if (live[j]) {
+          if (i + 1 < N) bad = bad || !(sc[j] >= L.c_logit[i + 1]);
+          bad = bad || !(sc[j] >= thr);
+        }
+      }
+      const bool stop = ctx.ballot(bad) != 0ull;
+      ctx.wsync();  // (the next frame's scores go to the same LDS words)
+      if (stop) break;
+CTC_UNROLL
+      for (int j = 0; j < SLB; ++j) lg[j] = nl[j];
+      ++tt;
+      if (tt >= io.T) break;
+      if (w_pos == w_n) {  // look ahead: up to 64 frames, one per lane
+        const int f = tt + lane;
+        bool q = false;
+        if (f < io.T) {
+          const uint32_t cnt = io.surv_cnt[f];
+          const uint32_t id = io.surv_id[(size_t)f * prm.max_surv];
+          w_lp = io.surv_lp[(size_t)f * prm.max_surv];
+          q = cnt == 1u && id == lab;
+        }
+        const uint64_t qm = ctx.ballot(q);
+        w_n = ~qm ? (uint32_t)ctx.ctz64(~qm) : 64u;
+        w_pos = 0;
+        if (w_n == 0) break;
+      }
+      p = bits_f64(ctx.bcast64(f64_bits(w_lp), (int)w_pos));
+      ++w_pos;
+    }
+    if (tt == t) return t;
+#ifdef CTC_RUN_TRACE
+    if (lane == 0) fprintf(stderr, "label_run: frames %d..%d label %u N=%d\n", t, tt - 1, lab, N);
+#endif
+CTC_UNROLL
+    for (int j = 0; j < SLB; ++j) {
+      const int i = j * 64 + lane;
+      if (live[j]) {
+        L.bf64[i * 14 + 2] = lg[j];
+        if (!lab_is_blank) L.bi32[i * 28 + 25] = io.first_frame + tt;  // end frame of the open word: last held frame + 1
+      }
+    }
+    ctx.wsync();
+    prefetch(tt);
+    prefetch_tok();
+    tick<W_PROF_RUN>();
+    return tt;
+  }
+
+  CTC_HD int step(int t) {
     const int frame = io.first_frame + t;
     const uint32_t ns = ctx.uni32(pf_cnt);
+    if (run_ok && ns == 1u && N > 0 && !prm.no_label_runs) {
+      const uint32_t lab = ctx.bcast32(pf_id, 0);
+      bool same = true;
+CTC_UNROLL
+      for (int j = 0; j < SLB; ++j) {
+        const int i = j * 64 + lane;
+        if (i < N) same = same && (L.b32[i * 28 + 6] & 0xFFFFu) == lab;
+      }
+      if (ctx.ballot(!same) == 0ull) {
+        const int t2 = label_run(t, lab, (ctx.bcast32(pt_flags, 0) & TK_BLANK) != 0u);
+        if (t2 > t) return t2;
+      }
+    }
     pool_n = 0;
     runmax = asc_key(-INFINITY);
     kth_key = 0;
@@ -1233,6 +1339,8 @@ CTC_UNROLL
     if (n == 0) status |= ST_NO_BEAMS;
     if (SLB == 1 || n <= 64u) build<1>(frame, n);
     else build<SLB>(frame, n);
+    run_ok = true;
+    return t + 1;
   }
 
   // next beam table from the ranked pool (decoder.py:548-554); A = rank slots per lane in use
@@ -1692,7 +1800,7 @@ CTC_UNROLL
     }
     prefetch(0);
     prefetch_tok();
-    for (int t = 0; t < io.T; ++t) step(t);
+    for (int t = 0; t < io.T;) t = step(t);
     finalise();
     tick<W_PROF_FINAL>();
     if (io.prof && lane == 0)

@@ -265,6 +265,8 @@ struct DecodeParams {
   int32_t max_surv;  // stride of the survivor arrays
   int32_t fold;      // finalisation closes the open word (force_next_word or is_end, decoder.py:570)
   int32_t eos;       // finalisation scores end of sentence (is_end, decoder.py:597)
+  int32_t no_label_runs;  // diagnostics (CTCDEC_NO_LABEL_RUNS=1): every frame takes the full path
+  int32_t pad_;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -208,6 +208,59 @@ def ctc_stretch(path: Sequence[int], T: int, blank: int, rng: np.random.Generato
     return np.asarray(frames, dtype=np.int64)
 
 
+def ctc_stretch_peaky(path: Sequence[int], T: int, blank: int, rng: np.random.Generator, hold: float = 0.35,
+                      gap: float = 2.2) -> np.ndarray:
+    """Frame-level alignment shaped like a trained CTC model's: a token is one frame (held a second / third one
+    with probability `hold` each), tokens are separated by blank runs of geometric length (mean `gap`)."""
+    frames: List[int] = []
+    for tok in path:
+        frames += [blank] * int(rng.geometric(1.0 / (1.0 + gap)) - 1 + (1 if frames and frames[-1] == tok else 0))
+        frames.append(tok)
+        while rng.random() < hold and len(frames) % 7:
+            frames.append(tok)
+        if len(frames) >= T:
+            break
+    frames = frames[:T]
+    frames += [blank] * (T - len(frames))
+    return np.asarray(frames, dtype=np.int64)
+
+
+def d_peaky(
+    config: int,
+    utt: int,
+    T: int,
+    labels: Sequence[str],
+    is_bpe: bool,
+    words: Sequence[str],
+    sentences: Sequence[Sequence[int]],
+    blank: int,
+    boost: float = 16.0,
+    unsure: float = 0.12,
+    space_label: str = " ",
+) -> np.ndarray:
+    """Real-posterior-like case (statistics of the reference's tests/sample_data/libri_logits.json: 327 of 371
+    frames have ONE label above token_min_logp, 43 % of all frames only the blank, blank-only runs of 3.3 frames on
+    average, the other 12 % of the frames carry one or two competitors 0.02-4 nats below the best): a confident
+    one-hot of a peaky alignment, plus competitors on a fraction `unsure` of the frames."""
+    rng = np.random.default_rng(1_000_003 * config + utt)
+    V = len(labels) if blank < len(labels) else len(labels) + 1
+    path: List[int] = []
+    while len(path) * 3 < T:
+        s = sentences[int(rng.integers(0, len(sentences)))]
+        p = words_to_path([words[i] for i in s], labels, is_bpe, space_label)
+        if path and not is_bpe:
+            path.append(labels.index(space_label))
+        path += p
+    ali = ctc_stretch_peaky(path, T, blank, rng)
+    x = rng.standard_normal((T, V)).astype(np.float32)
+    x[np.arange(T), ali] += np.float32(boost)
+    soft = np.nonzero(rng.random(T) < unsure)[0]
+    for t in soft:
+        for _ in range(1 if rng.random() < 0.9 else 2):
+            x[t, int(rng.integers(0, V))] = x[t, ali[t]] - np.float32(rng.uniform(0.0, 4.0))
+    return x
+
+
 def d_flat(config: int, utt: int, T: int, V: int) -> np.ndarray:
     """Stress case: raw N(0,1) logits (the reference's own fuzz generator)."""
     rng = np.random.default_rng(1_000_003 * config + utt)

@@ -495,3 +495,36 @@ def test_hip_chunked_pipeline_equals_the_sequential_path(lm, monkeypatch):
     got = dec.decode_batch(None, ys)
     assert got[:2400] == piped[:2400] and got[2401:] == piped[2401:]
     assert got[2400] == dec.decode(ys[2400])
+
+
+def test_hip_peaky_posteriors_single_label_runs(lm, bpe, monkeypatch):
+    """Real-posterior-like logits (synth.d_peaky: most frames have one survivor, the label every beam ends in): both
+    kernels consume such frames in runs (label_run). Same beams as the oracle; identical output with the runs
+    switched off; fp32 device input; long utterances so that runs span look-ahead windows."""
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    hot = lm.hotwords(6, 2)
+    for labels, is_bpe, boost in ((bpe, True, 16.0), (synth.LIBRI_LABELS, False, 12.0)):
+        dec = build_ctcdecoder(labels, lm.path)
+        alpha = Alphabet.build_alphabet(labels)
+        orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+        xs = [synth.d_peaky(9, u, 150 + 40 * u, labels, is_bpe, lm.words, lm.sentences, len(labels), boost=boost) for u in range(3)]
+        # a long all-blank stretch: one run across several 64-frame windows, to the end of the utterance
+        tail = np.full((200, xs[0].shape[1]), -8.0, dtype=np.float32)
+        tail[:, len(labels)] = 8.0
+        xs.append(np.concatenate([xs[0][:60], tail]))
+        kw = {"hotwords": hot, "prune_history": True}
+        got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], **kw)
+        for u, x in enumerate(xs):
+            exp = _oracle_expected(orc, x.astype(np.float64), kw)
+            check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL, what="peaky%d" % u)
+        monkeypatch.setenv("CTCDEC_NO_LABEL_RUNS", "1")
+        plain = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], **kw)
+        monkeypatch.delenv("CTCDEC_NO_LABEL_RUNS")
+        for g, q in zip(got, plain):
+            assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g] == \
+                   [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in q]

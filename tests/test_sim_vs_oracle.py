@@ -312,3 +312,38 @@ def test_large_batches_go_through_the_chunked_pipeline(sim_library, monkeypatch)
     ys = [y.astype(np.float64) for y in ys]
     got = dec.decode_batch(None, ys)
     assert got[37] == orc.decode(ys[37]) and got[5] == piped[5]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_peaky_posteriors_take_the_single_label_runs(seed, sim_library, monkeypatch):  # noqa: F811
+    """Real-posterior-like input (most frames: one survivor, the label every beam already ends in): the wave
+    kernel consumes such frames in runs without the full per-frame pipeline -- same beams, frames and scores as
+    the oracle, with and without the shortcut."""
+    if seed % 2:
+        x = synth.d_peaky(8, seed, 120, BPE, True, LM.words, LM.sentences, len(BPE)).astype(np.float64)
+        labels = BPE
+    else:
+        x = synth.d_peaky(8, seed, 120, synth.LIBRI_LABELS, False, LM.words, LM.sentences, len(synth.LIBRI_LABELS),
+                          boost=12.0).astype(np.float64)
+        labels = synth.LIBRI_LABELS
+    hot = LM.hotwords(4, 2) if seed % 3 == 0 else None
+    dkw = {"prune_history": seed % 3 != 1, "hotwords": hot, "beam_width": 100 if seed < 4 else 25}
+    dec, _ = _compare(labels, LM.path if seed != 4 else None, x, dkw=dkw, what="peaky%d" % seed)
+    with_runs = dec.decode_beams(x, **dkw)
+    monkeypatch.setenv("CTCDEC_NO_LABEL_RUNS", "1")
+    without = dec.decode_beams(x, **dkw)
+    assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in with_runs] == \
+           [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in without]
+
+
+def test_label_run_across_look_ahead_windows_to_the_end(sim_library):  # noqa: F811
+    """A 200-frame blank stretch (several 64-frame look-ahead windows) up to the last frame, and a held token."""
+    labels = synth.LIBRI_LABELS
+    V = len(labels) + 1
+    head = synth.d_peaky(8, 3, 40, labels, False, LM.words, LM.sentences, len(labels), boost=12.0).astype(np.float64)
+    tail = np.full((200, V), -8.0)
+    tail[:, V - 1] = 8.0
+    held = np.full((70, V), -8.0)
+    held[:, 5] = 8.0
+    for x, what in ((np.concatenate([head, tail]), "blank-tail"), (np.concatenate([head, held, tail[:3]]), "held")):
+        _compare(labels, LM.path, x, dkw={"prune_history": True}, what=what)
