@@ -591,6 +591,14 @@ __device__ __forceinline__ double exp_nonpos(double d) {
   return ldexp(p, (int)kf);
 }
 
+// log(s) for 1 <= s < 2^24, fp64: one Newton step on the fp32 logarithm -- y0 = logf(s), r = s * exp(-y0) - 1
+// (|r| ~ 1e-6), log(s) = y0 + log1p(r) = y0 + r - r^2/2 (next term < 1e-18). A third of ocml's double-double log.
+__device__ __forceinline__ double log_ge1(double s) {
+  const double y0 = (double)__logf((float)s);
+  const double r = fma(s, exp_nonpos(-y0), -1.0);
+  return y0 + (r - 0.5 * r * r);
+}
+
 // Register-resident frame-prune for fp32 rows with V % 4 == 0 and V <= 1024*... (NC chunks of 256
 // labels): each lane pulls its 4*NC logits with 16-byte loads ONCE (1 KiB per wave-instruction, fully
 // coalesced) and all three sweeps run out of registers: the logits cross HBM exactly once.
@@ -632,18 +640,24 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
     if (lane == 0) a.row_sum[row] = rs;
     // ---- the clean row (finite maximum, no NaN: -inf masks are fine): everything below in its cheapest form
     if (isfinite(m) && rs == rs) {
-      double s = 0.0;
+      // The reference computes the log-softmax of float32 logits IN float32 (decoder.py:180-197: np.exp / np.sum
+      // on the float32 array), so the exponentials are taken at that precision here too -- v_exp_f32, one
+      // instruction instead of the 21 of the fp64 routine, which made this kernel VALU-bound -- and summed in fp64 (a
+      // float32 accumulator loses the small terms next to the maximum's 1.0 the same way in every frame of a steady
+      // stretch, which adds up over T). Everything downstream (lse, the clipped log-probs, all
+      // score arithmetic) stays fp64. float64 inputs go through frame_prune<double>, which is fp64 throughout.
+      const float mfw = (float)m;  // exact: m is the maximum of float32 values
+      double sl = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         if (k * 64 + lane < n4)
-          s += (exp_nonpos((double)r[k].x - m) + exp_nonpos((double)r[k].y - m)) +
-               (exp_nonpos((double)r[k].z - m) + exp_nonpos((double)r[k].w - m));
+          sl += ((double)__expf(r[k].x - mfw) + (double)__expf(r[k].y - mfw)) +
+                ((double)__expf(r[k].z - mfw) + (double)__expf(r[k].w - mfw));
       }
-      s = wave_sum(s);
-      lse = log(s);
+      const double s = wave_sum(sl);
+      lse = log_ge1(s);
       // argmax of the log-probs = first maximum of the logits (x -> clip(x - m - lse) is monotone, and two
       // different fp32 logits never round to the same fp64 value after the two subtractions)
-      const float mfw = (float)m;
       int first = 0x7FFFFFFF;
 #pragma unroll
       for (int k = NC - 1; k >= 0; --k) {

@@ -282,7 +282,7 @@ def test_hip_config5_streaming_64_streams(lm, bpe):
 
 def test_hip_half_precision_logits_in_place(lm, bpe):
     """fp16 / bf16 device logits are read in place (exact widening); the result must equal decoding the
-    same values handed over as fp32."""
+    same values handed over as fp32 (beams exactly, scores to 1e-6)."""
     import torch
 
     from pyctcdecode_amd import build_ctcdecoder
@@ -293,8 +293,12 @@ def test_hip_half_precision_logits_in_place(lm, bpe):
         xh = torch.from_numpy(x).cuda().to(dt)
         a = dec.decode_beams(xh, prune_history=True)
         b = dec.decode_beams(xh.to(torch.float32), prune_history=True)
-        assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a] == [
-            (o.text, o.text_frames, o.logit_score, o.lm_score) for o in b]
+        # (same beams; the scores agree to the precision of the float32 path's exponentials -- the half types go
+        # through the generic kernel, whose log-softmax is fp64 throughout)
+        assert [(o.text, o.text_frames) for o in a] == [(o.text, o.text_frames) for o in b]
+        for o, q in zip(a, b):
+            assert abs(o.logit_score - q.logit_score) <= TOL * max(1.0, abs(q.logit_score))
+            assert abs(o.lm_score - q.lm_score) <= TOL * max(1.0, abs(q.lm_score))
 
 
 def test_hip_probability_rows_overflowing_the_survivor_bound():
