@@ -532,3 +532,37 @@ def test_hip_peaky_posteriors_single_label_runs(lm, bpe, monkeypatch):
         for g, q in zip(got, plain):
             assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g] == \
                    [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in q]
+
+
+def test_hip_flat_model_file_round_trip(lm, tmp_path):
+    """NgramModel(arpa).save_flat -> *.ctcdec -> build_ctcdecoder / save_to_dir / load_from_dir on the HIP build:
+    same beams, scores and LM states as the decoder built from the ARPA text; damaged and kenlm-binary files are refused."""
+    import torch
+
+    from pyctcdecode_amd import BeamSearchDecoderCTC, build_ctcdecoder
+    from pyctcdecode_amd.language_model import NgramModel, load_unigram_set_from_arpa
+
+    flat = str(tmp_path / "model.ctcdec")
+    NgramModel(lm.path).save_flat(flat)
+    uni = sorted(load_unigram_set_from_arpa(lm.path))
+    a = build_ctcdecoder(synth.LIBRI_LABELS, lm.path, uni)
+    b = build_ctcdecoder(synth.LIBRI_LABELS, flat, uni)
+    xs = [synth.d_words(2, u, 80, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=5.0) for u in range(3)]
+    for x in xs:
+        xd = torch.from_numpy(x).cuda()
+        ra, rb = a.decode_beams(xd, beam_width=40), b.decode_beams(xd, beam_width=40)
+        assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in ra] == [
+            (o.text, o.text_frames, o.logit_score, o.lm_score) for o in rb]
+        assert ra[0].last_lm_state.state == rb[0].last_lm_state.state
+    d = tmp_path / "dec"
+    d.mkdir()
+    b.save_to_dir(str(d))
+    c = BeamSearchDecoderCTC.load_from_dir(str(d))
+    assert c.decode_batch(None, xs) == a.decode_batch(None, xs)
+    raw = open(flat, "rb").read()
+    bad = tmp_path / "cut.ctcdec"
+    bad.write_bytes(raw[: len(raw) // 2])
+    with pytest.raises(OSError):
+        NgramModel(str(bad))
+    with pytest.raises(NotImplementedError):  # kenlm's own binaries stay refused (no sample to pin a reader against)
+        NgramModel(str(tmp_path / "model.binary"))
