@@ -426,7 +426,18 @@ CTC_UNROLL
   }
   // begin: beams 0..63 get their node index and issue their n-gram probes (resolved by completions_end after
   // the match); beams 64.. (more than 64 live beams: rare) are completed on the spot
+  CTC_HD u32x4 opaque128(u32x4 v) { return mk4(ctx.opaque32(v[0]), ctx.opaque32(v[1]), ctx.opaque32(v[2]), ctx.opaque32(v[3])); }
   CTC_HD void completions_begin() {
+    // The source node fetched at the start of the frame is first LOOKED AT here: laundering its registers keeps the
+    // compiler from hoisting pieces of the work below (the history fold's count, the state length) up to right behind
+    // the loads, where their s_waitcnt vmcnt(0) put the fetch's whole round trip in front of the branch modes.
+    cp_c2 = opaque128(cp_c2);
+    cp_c3 = opaque128(cp_c3);
+    cp_c4 = opaque128(cp_c4);
+    cp_c5 = opaque128(cp_c5);
+    cp_c6 = opaque128(cp_c6);
+    cp_raw = bits_f64(pack64(ctx.opaque32((uint32_t)f64_bits(cp_raw)), ctx.opaque32((uint32_t)(f64_bits(cp_raw) >> 32))));
+    cp_ring3 = pack64(ctx.opaque32((uint32_t)cp_ring3), ctx.opaque32((uint32_t)(cp_ring3 >> 32)));
     cp_todo = cp_cand;
     if (ctx.ballot(cp_todo) != 0ull) {
       comp_pending = true;
@@ -1245,6 +1256,21 @@ CTC_UNROLL
              (unsigned long long)q_hi(t0), bits_f64(q_lo(t1)), t1[2], t1[3], t5[0], t5[1], t5[3]);
     }
 #endif
+    // Block 0's labels go to LDS first: their registers were requested a frame ago, but the wait for them also covers
+    // every younger load (loads and stores share vmcnt) -- it has to come BEFORE the source-node fetch below is issued,
+    // or the frame starts with that fetch's full round trip.
+    uint32_t id0 = 0, fl0 = TK_BLANK;
+    double lp0 = 0.0;
+    if ((uint32_t)lane < ns) {
+      id0 = pf_id;
+      lp0 = pf_lp;
+      fl0 = pt_flags;
+      L.lab[lane * 3] = mk4q(pt_h_raw, pt_pow_raw);
+      L.lab[lane * 3 + 1] = mk4((uint32_t)pt_h_clean, (uint32_t)(pt_h_clean >> 32), pt_len_raw, pt_len_clean);
+      L.lab[lane * 3 + 2] = mk4(pt_flags, pt_start_flags, pt_start_word_id, pt_hot);
+    }
+    id0 = ctx.opaque32(id0);  // (pins the consumption above the fetch)
+    ctx.wsync();
     uint32_t lc[SLB];
     completions_fetch(lc);
     tick<W_PROF_FETCH>();
@@ -1269,12 +1295,9 @@ CTC_UNROLL
       double lp = 0.0;
       if (base == 0) {
         if (mine) {
-          id = pf_id;
-          lp = pf_lp;
-          fl = pt_flags;
-          L.lab[lane * 3] = mk4q(pt_h_raw, pt_pow_raw);
-          L.lab[lane * 3 + 1] = mk4((uint32_t)pt_h_clean, (uint32_t)(pt_h_clean >> 32), pt_len_raw, pt_len_clean);
-          L.lab[lane * 3 + 2] = mk4(pt_flags, pt_start_flags, pt_start_word_id, pt_hot);
+          id = id0;
+          lp = lp0;
+          fl = fl0;
         }
       } else {
         // (more than 64 survivors in one frame: rare; fetched on the spot)
