@@ -188,7 +188,8 @@ struct WaveDecoder {
   double pf_lp = 0.0;
   bool pf_live = false;
   uint64_t pt_h_raw = 0, pt_pow_raw = 0, pt_h_clean = 0;
-  uint32_t pt_len_raw = 0, pt_len_clean = 0, pt_flags = TK_BLANK, pt_start_flags = 0, pt_start_word_id = 0, pt_hot = 0;
+  uint32_t pt_len_raw = 0, pt_len_clean = 0, pt_flags = TK_BLANK, pt_start_flags = 0, pt_start_word_id = 0;
+  uint64_t pt_hot_raw = 0;  // the label's TokHot entry as loaded (min_len, complete): folded only where it is consumed
   // completions in flight (lane = beam): source node fetched at the start of the frame, n-gram probes issued
   // before the candidates are generated, everything resolved after the match
   // What the completion of beam (slot, lane) needs, fetched as raw 16-byte chunks and decoded where it is
@@ -282,7 +283,8 @@ struct WaveDecoder {
     pt_flags = g.flags;
     pt_start_flags = g.start_flags;
     pt_start_word_id = g.start_word_id;
-    pt_hot = tab.tok_hot ? ((tab.tok_hot[pf_id].min_len & 0xFFFFu) | (tab.tok_hot[pf_id].complete ? 0x80000000u : 0u)) : 0u;
+    // (raw: any arithmetic on the loaded words here would wait for them on the spot)
+    pt_hot_raw = tab.tok_hot ? *(const uint64_t*)&tab.tok_hot[pf_id] : 0ull;
   }
 
   // Branch modes of up to 64 labels, one per lane (flags TK_BLANK for a lane without a label). For BPE
@@ -1267,6 +1269,7 @@ CTC_UNROLL
       fl0 = pt_flags;
       L.lab[lane * 3] = mk4q(pt_h_raw, pt_pow_raw);
       L.lab[lane * 3 + 1] = mk4((uint32_t)pt_h_clean, (uint32_t)(pt_h_clean >> 32), pt_len_raw, pt_len_clean);
+      const uint32_t pt_hot = ((uint32_t)pt_hot_raw & 0xFFFFu) | ((uint32_t)(pt_hot_raw >> 32) ? 0x80000000u : 0u);
       L.lab[lane * 3 + 2] = mk4(pt_flags, pt_start_flags, pt_start_word_id, pt_hot);
     }
     id0 = ctx.opaque32(id0);  // (pins the consumption above the fetch)
