@@ -213,9 +213,19 @@ class _Batch:
             return False
         n, frames = int(t.shape[0]), int(t.shape[1])
         self.keep.append(t)
-        self.ptrs = [base + k * step for k in range(n)]
-        self.frames = [frames] * n
+        # (numpy, not 2 x B Python ints: at 4096 utterances the lists and their ctypes copies cost ~1 ms per call)
+        self.ptrs = (np.uint64(base) + np.arange(n, dtype=np.uint64) * np.uint64(step)) if n else []
+        self.frames = np.full(n, frames, dtype=np.int32) if n else []
         return True
+
+
+def _c_arrays(batch: _Batch):
+    """(void*[n], int32[n]) for the C ABI from a batch's pointer / frame lists (numpy arrays are passed as they are)."""
+    n = len(batch.ptrs)
+    if isinstance(batch.ptrs, np.ndarray):
+        batch.keep.append((batch.ptrs, batch.frames))
+        return (batch.ptrs.ctypes.data_as(C.POINTER(C.c_void_p)), batch.frames.ctypes.data_as(C.POINTER(C.c_int32)))
+    return (C.c_void_p * max(n, 1))(*batch.ptrs), (C.c_int32 * max(n, 1))(*batch.frames)
 
 
 class BeamSearchDecoderCTC:
@@ -362,8 +372,7 @@ class BeamSearchDecoderCTC:
             raise ValueError("the logits live on cuda:%d but this decoder was built for cuda:%d (one process per GPU: "
                              "LOCAL_RANK / CTCDEC_DEVICE pick the device)" % (batch.device_index, self._device))
         n = len(batch.ptrs)
-        ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
-        frames = (C.c_int32 * max(n, 1))(*batch.frames)
+        ptrs, frames = _c_arrays(batch)
         st_arr = None
         n_lms = len(self._members)
         if start_states is not None and n_lms > 0:
@@ -726,8 +735,7 @@ class BeamSearchDecoderCTC:
         if batch.is_device and batch.device_index is not None and batch.device_index != self._device:
             raise ValueError("the logits live on cuda:%d but this decoder was built for cuda:%d (one process per GPU: "
                              "LOCAL_RANK / CTCDEC_DEVICE pick the device)" % (batch.device_index, self._device))
-        ptrs = (C.c_void_p * max(n, 1))(*batch.ptrs)
-        frames = (C.c_int32 * max(n, 1))(*batch.frames)
+        ptrs, frames = _c_arrays(batch)
         first = (C.c_int32 * max(n, 1))(*[int(p) for p in processed_frames_list])
         res = C.c_void_p()
         self._lib.check(
