@@ -570,32 +570,26 @@ CTC_UNROLL
   }
 
   // One entry per lane (`ok` lanes, mask pm; e = the lane's pool index): rank by (key asc = score desc, arrival asc),
-  // history duplicates flagged; writes L.sel for the ranks below `want`.
+  // history duplicates flagged; writes L.sel for the ranks below `want`. The caller has laid the passing entries'
+  // (key, history key) out densely in L.rank_rec[0 .. np) (lane order) and fenced: every lane walks that list with
+  // broadcast LDS reads (one ds_read_b128 + a handful of VALU per entry, the reads pipelined ahead of their use)
+  // instead of 4 v_readlane + scalar bit scanning per entry.
   CTC_HD void rank_lanes(uint64_t key, uint64_t hk, bool ok, uint64_t pm, uint32_t e, bool with_hist, uint32_t want) {
     const uint32_t np = (uint32_t)ctx.popc64(pm);
     uint32_t rank = 0, dup = 0;
-    // two passing entries per iteration (their readlanes and compares interleave)
-    uint64_t m = pm;
+    // (the list is padded to a multiple of four with entries that beat nobody: key = ~0)
     if (with_hist) {
-      while (m) {
-        const int j0 = ctx.ctz64(m);
-        m &= m - 1ull;
-        const int j1 = m ? ctx.ctz64(m) : j0;
-        m &= m - 1ull;
-        const uint64_t x0 = ctx.bcast64(key, j0), h0 = ctx.bcast64(hk, j0);
-        const uint64_t x1 = ctx.bcast64(key, j1), h1 = ctx.bcast64(hk, j1);
-        const bool b0 = x0 < key, b1 = x1 < key && j1 != j0;
-        rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u);
-        dup |= ((b0 && h0 == hk) || (b1 && h1 == hk)) ? 1u : 0u;
+      for (uint32_t j = 0; j < np; j += 4u) {
+        const u32x4 r0 = L.rank_rec[j], r1 = L.rank_rec[j + 1u], r2 = L.rank_rec[j + 2u], r3 = L.rank_rec[j + 3u];
+        const bool b0 = q_lo(r0) < key, b1 = q_lo(r1) < key, b2 = q_lo(r2) < key, b3 = q_lo(r3) < key;
+        rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u) + (b2 ? 1u : 0u) + (b3 ? 1u : 0u);
+        // (bitwise, not short-circuit: the latter became a ladder of exec-mask branches)
+        dup |= (uint32_t)((b0 & (q_hi(r0) == hk)) | (b1 & (q_hi(r1) == hk)) | (b2 & (q_hi(r2) == hk)) | (b3 & (q_hi(r3) == hk)));
       }
     } else {
-      while (m) {
-        const int j0 = ctx.ctz64(m);
-        m &= m - 1ull;
-        const int j1 = m ? ctx.ctz64(m) : j0;
-        m &= m - 1ull;
-        const uint64_t x0 = ctx.bcast64(key, j0), x1 = ctx.bcast64(key, j1);
-        rank += (x0 < key ? 1u : 0u) + ((x1 < key && j1 != j0) ? 1u : 0u);
+      for (uint32_t j = 0; j < np; j += 4u) {
+        const u32x4 r0 = L.rank_rec[j], r1 = L.rank_rec[j + 1u], r2 = L.rank_rec[j + 2u], r3 = L.rank_rec[j + 3u];
+        rank += (q_lo(r0) < key ? 1u : 0u) + (q_lo(r1) < key ? 1u : 0u) + (q_lo(r2) < key ? 1u : 0u) + (q_lo(r3) < key ? 1u : 0u);
       }
     }
     // Without equal scores the ranks of the passing entries are a permutation of 0 .. np-1; an equal pair shares
@@ -631,9 +625,14 @@ CTC_UNROLL
       const double sc = bits_f64(q_lo(p0));
       const bool ok = mine && sc >= thr;
       const uint64_t pm = ctx.ballot(ok);
-      rank_lanes(ok ? score_sort_key(sc) : ~0ull, with_hist ? q_hi(p0) : 0ull, ok, pm, e, with_hist, want);
+      const uint32_t np = (uint32_t)ctx.popc64(pm);
+      const uint64_t key = ok ? score_sort_key(sc) : ~0ull, hk = with_hist ? q_hi(p0) : 0ull;
+      if (ok) L.rank_rec[prefix_cnt(pm)] = mk4q(key, hk);
+      if (lane < 4) L.rank_rec[np + (uint32_t)lane] = mk4q(~0ull, 0ull);
       ctx.wsync();
-      return (uint32_t)ctx.popc64(pm);
+      rank_lanes(key, hk, ok, pm, e, with_hist, want);
+      ctx.wsync();
+      return np;
     }
     // Larger pools (heavy frames): the entries that pass the threshold are first compacted (usually far fewer
     // than the pool holds, and mostly <= 64 again), then ranked out of registers the same way, R compacted
@@ -657,8 +656,9 @@ CTC_UNROLL
       }
       n_pass += (uint32_t)ctx.popc64(bm);
     }
+    if (n_pass <= 64u && lane < 4) L.rank_rec[n_pass + (uint32_t)lane] = mk4q(~0ull, 0ull);  // pads the list for rank_lanes (68 <= P)
     ctx.wsync();
-    if (n_pass <= 64u) {  // (all but the heaviest frames) one compacted entry per lane: the register loop of the small pool
+    if (n_pass <= 64u) {  // (all but the heaviest frames) one compacted entry per lane: the same walk as the small pool
       const bool ok = (uint32_t)lane < n_pass;
       u32x4 r = mk4(~0u, ~0u, 0, 0);
       uint32_t e = 0;
