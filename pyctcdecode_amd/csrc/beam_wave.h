@@ -793,60 +793,73 @@ CTC_UNROLL
   // FULL: also the first probe of the prefix / hot-word table of an appended partial word
   template <bool FULL>
   CTC_HD void gen(Cand& c, bool valid, uint32_t v, uint32_t l, uint32_t s, uint32_t i) {
+    // Straight-line: a lane without a candidate computes on label 0 / beam 0 (its fields are only looked at behind
+    // `valid`), and every branch of the reference's if-ladder (decoder.py:452-534) is a select -- as divergent
+    // branches this was 23 exec-mask regions and ~130 register moves for two candidates.
+    const uint32_t ll = valid ? l : 0u, ii = valid ? i : 0u;
+    const u32x4 sv = L.surv[ll];
+    const u32x4 la = L.lab[ll * 3], lb = L.lab[ll * 3 + 1];
+    const u32x4 k0 = L.beams[ii * BREC], k1 = L.beams[ii * BREC + 1], k2 = L.beams[ii * BREC + 2];
     c.valid = valid;
     c.is_rep = false;
-    c.want_p = c.want_h = false;
     c.v = v;
     c.bi = i;
     c.ls = s;
     c.ll = l;
-    c.lid = c.mw = c.br = c.pl0 = c.m2_0 = c.len_raw = c.tslot = 0;
     c.rep = v;
-    c.kp = c.ck = c.pp_key = c.ph_key = 0;
+    c.lid = sv[0];
+    c.mw = sv[1];
+    c.len_raw = lb[2];
+    const uint32_t meta1 = k1[2];
+    const uint32_t pl = meta1 >> 16;
+    c.pl0 = pl;
+    c.m2_0 = k1[3];
+    // branch (branch_of, as selects)
+    const uint32_t mode = sv[1] & 0xFFu;
+    const bool keep = (sv[1] & (TK_BLANK << 16)) != 0u || (meta1 & 0xFFFFu) == sv[0];
+    const bool first_b = ii == ((sv[1] >> 8) & 0xFFu);
+    uint32_t b = BR_APPEND;
+    b = mode == MODE_C ? (uint32_t)BR_SPACE : b;
+    b = (mode == MODE_FIRST_B && first_b) ? (uint32_t)BR_BOUNDARY : b;
+    b = mode == MODE_ALL_B ? (uint32_t)BR_BOUNDARY : b;
+    b = keep ? 0u : b;
+    c.br = b;
+    const bool closes = b == BR_BOUNDARY || b == BR_SPACE;
+    const bool app = b == BR_APPEND;
+    // merge key parts: the text (the completed one when the open word closes: the rest of the completion may still
+    // be in flight, c_text_h is there) and the new partial word
+    const uint64_t kt = (closes && pl > 0) ? q_lo(k2) : q_lo(k0);
+    const uint64_t p_app = str_concat(q_hi(k0), q_hi(la), q_lo(la));  // pow_raw, h_raw
+    uint64_t p = q_hi(k0);
+    p = app ? p_app : p;
+    p = b == BR_BOUNDARY ? q_lo(lb) : p;  // h_clean
+    p = b == BR_SPACE ? 0ull : p;
+    c.kp = p;
+    c.tslot = 0;
+    c.want_p = c.want_h = false;
+    c.pp_key = c.ph_key = 0;
     c.pp_wid = c.pp_fl = c.ph_min = c.ph_cmp = 0;
-    c.lg = c.lmhw = 0.0;
-    if (valid) {
-      const u32x4 sv = L.surv[l];
-      const u32x4 la = L.lab[l * 3], lb = L.lab[l * 3 + 1];
-      const u32x4 k0 = L.beams[i * BREC], k1 = L.beams[i * BREC + 1], k2 = L.beams[i * BREC + 2];
-      c.lid = sv[0];
-      c.mw = sv[1];
-      c.len_raw = lb[2];
-      const uint32_t meta1 = k1[2];
-      const uint32_t pl = meta1 >> 16;
-      c.pl0 = pl;
-      c.m2_0 = k1[3];
-      const uint32_t b = branch_of(sv[1], sv[0], i, meta1 & 0xFFFFu);
-      c.br = b;
-      uint64_t kt = q_lo(k0), p = q_hi(k0);
-      if (b == BR_BOUNDARY || b == BR_SPACE) {
-        if (pl > 0) kt = q_lo(k2);  // c_text_h (the rest of the completion may still be in flight)
-        p = b == BR_BOUNDARY ? q_lo(lb) : 0;  // h_clean
-      } else if (b == BR_APPEND) {
-        p = str_concat(p, q_hi(la), q_lo(la));  // pow_raw, h_raw
-        if (FULL && p != 0) {
-          c.tslot = (uint32_t)table_slot(p);
-          c.want_p = (k1[3] & PF_ON_TABLE) && tab.prefixes;
-          c.want_h = (k1[3] & M2_HOT_ON) && tab.hot;
-          if (c.want_p) {
-            const PrefixEntry& g = tab.prefixes[c.tslot & tab.prefix_mask];
-            c.pp_key = g.key;
-            c.pp_wid = g.word_id;
-            c.pp_fl = g.flags;
-          }
-          if (c.want_h) {
-            const HotEntry& g = tab.hot[c.tslot & tab.hot_mask];
-            c.ph_key = g.key;
-            c.ph_min = g.min_len;
-            c.ph_cmp = g.complete;
-          }
-        }
+    if (FULL) {  // first probe of the prefix / hot-word table of an appended partial word
+      const bool probe = valid && app && p != 0;
+      c.tslot = (uint32_t)table_slot(p);
+      c.want_p = probe && (k1[3] & PF_ON_TABLE) && tab.prefixes;
+      c.want_h = probe && (k1[3] & M2_HOT_ON) && tab.hot;
+      if (c.want_p) {
+        const PrefixEntry& g = tab.prefixes[c.tslot & tab.prefix_mask];
+        c.pp_key = g.key;
+        c.pp_wid = g.word_id;
+        c.pp_fl = g.flags;
       }
-      c.kp = p;
-      c.lmhw = bits_f64(q_hi(k2));
-      c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
-      c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
+      if (c.want_h) {
+        const HotEntry& g = tab.hot[c.tslot & tab.hot_mask];
+        c.ph_key = g.key;
+        c.ph_min = g.min_len;
+        c.ph_cmp = g.complete;
+      }
     }
+    c.lmhw = bits_f64(q_hi(k2));
+    c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
+    c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
   }
 
   // wave-wide hash match on 64-bit keys (valid lanes only): rep = smallest candidate index with the same key.
