@@ -962,6 +962,20 @@ CTC_UNROLL
     flush_emits();
   }
 
+  // partial_score (beam_core.h: language_model.py:141-150, 326-336; decoder.py:363-367, 397-409) as selects, for the
+  // single-model kernel: same operations in the same order.
+  CTC_HD double partial_score_sel(uint32_t pf_flags, uint32_t hot_min_len, uint32_t plen) const {
+    const double pl = (double)plen;
+    double s = 0.0;
+    if (tab.has_lm) {  // (uniform)
+      const bool on_trie = tab.has_trie && (pf_flags & PF_UNI_PREFIX);
+      s = prm.unk * (on_trie ? 0.0 : 1.0);
+      if (plen > 6) s = s * pl / 6.0;  // (the two fp64 divisions stay behind branches: ~15 instructions each)
+    }
+    if (hot_min_len > 0) s = prm.hot_weight * pl / (double)hot_min_len;
+    return s;
+  }
+
   // fold, score and push the representatives of one pass; A candidates per lane, W = 32-bit words of a member
   // mask in use
   template <int A>
@@ -1021,52 +1035,39 @@ CTC_UNROLL
     uint64_t pass_key = 0;
 CTC_UNROLL
     for (int j = 0; j < A; ++j) {
-      score[j] = 0.0;
-      my_key[j] = 0;
-      v_pl[j] = v_m2[j] = v_wid[j] = 0;
-      if (c[j].is_rep) {
-        const uint32_t i = c[j].bi;
-        const uint32_t b = c[j].br;
-        // (computed into scalars and copied out once: with the per-slot arrays written inside the branches,
-        // hipcc 7.2 -O3 lost the store of the last branch in the second unrolled iteration)
-        uint32_t q_pl, q_m2, q_wid;
-        double q_ps;
-        if (b == 0) {  // blank / repeat: unchanged
-          q_pl = c[j].pl0;
-          q_m2 = c[j].m2_0;
-          q_wid = L.b32[i * 28 + 23];
-          q_ps = L.bf64[i * 14 + 7];
-        } else if (b == BR_BOUNDARY) {
-          // a new word starts with the clean label (or, for a bare boundary mark, nothing yet)
-          const u32x4 lb = L.lab[c[j].ll * 3 + 1], lc = L.lab[c[j].ll * 3 + 2];
-          const uint32_t len_clean = lb[3];
-          const uint32_t hmin = lc[3] & 0xFFFFu, hcomp = lc[3] >> 31;
-          q_pl = len_clean;
-          q_m2 = len_clean > 0 ? ((lc[1] & (PF_PARTIAL_MASK | PF_ON_TABLE)) | (hmin ? M2_HOT_ON : 0u) | (hcomp ? M2_HOT_COMPLETE : 0u) | (hmin << 8))
-                               : EMPTY_PARTIAL_M2;
-          q_wid = len_clean > 0 ? lc[2] : 0u;
-          q_ps = len_clean > 0 ? partial_score(tab, prm, lc[1], hmin, q_pl) : 0.0;
-        } else if (b == BR_APPEND) {
-          q_pl = c[j].pl0 + c[j].len_raw;
-          q_m2 = (t[j].on ? (PF_ON_TABLE | (t[j].pf & PF_PARTIAL_MASK)) : 0u) | (t[j].hon ? M2_HOT_ON : 0u) |
-                 ((t[j].hon && t[j].hcomp) ? M2_HOT_COMPLETE : 0u) | ((t[j].hon ? t[j].hmin : 0u) << 8);
-          q_wid = t[j].on ? t[j].nw : 0;
-          q_ps = partial_score(tab, prm, t[j].on ? t[j].pf : 0u, t[j].hon ? t[j].hmin : 0u, q_pl);
-        } else {  // space: the open word is empty
-          q_pl = 0;
-          q_m2 = EMPTY_PARTIAL_M2;
-          q_wid = 0;
-          q_ps = 0.0;
-        }
-        v_pl[j] = q_pl;
-        v_m2[j] = q_m2;
-        v_wid[j] = q_wid;
-        double lmhw = c[j].lmhw;
-        if ((b == BR_BOUNDARY || b == BR_SPACE) && c[j].pl0 > 0) lmhw = L.bf64[i * 14 + 6];  // c_lm_hw
-        score[j] = total_score(tab, c[j].lg, lmhw, q_ps, q_pl);
-        my_key[j] = asc_key(score[j]);
-        if (my_key[j] > pass_key) pass_key = my_key[j];
-      }
+      // Straight-line (selects, LDS reads at safe indices): as an if-ladder over the four branches this was ~30
+      // exec-mask regions per slot. Lanes that represent nothing compute on beam 0 / label 0 and are masked at the end.
+      const bool rep = c[j].is_rep;
+      const uint32_t i = rep ? c[j].bi : 0u, ll = rep ? c[j].ll : 0u;
+      const uint32_t b = c[j].br;
+      const u32x4 lb = L.lab[ll * 3 + 1], lc = L.lab[ll * 3 + 2];
+      const uint32_t st_wid = L.b32[i * 28 + 23];
+      const double st_ps = L.bf64[i * 14 + 7], c_lmhw = L.bf64[i * 14 + 6];
+      const bool is0 = b == 0, isB = b == BR_BOUNDARY, isA = b == BR_APPEND;  // else: space
+      // boundary: a new word starts with the clean label (or, for a bare boundary mark, nothing yet)
+      const uint32_t len_clean = lb[3];
+      const uint32_t hminB = lc[3] & 0xFFFFu, hcompB = lc[3] >> 31;
+      const bool bw = isB && len_clean > 0;
+      const uint32_t m2B = len_clean > 0 ? ((lc[1] & (PF_PARTIAL_MASK | PF_ON_TABLE)) | (hminB ? M2_HOT_ON : 0u) |
+                                            (hcompB ? M2_HOT_COMPLETE : 0u) | (hminB << 8))
+                                         : EMPTY_PARTIAL_M2;
+      // append: what the prefix / hot-word tables say about the longer partial word
+      const uint32_t a_pf = t[j].on ? t[j].pf : 0u, a_hmin = t[j].hon ? t[j].hmin : 0u;
+      const uint32_t m2A = (t[j].on ? (PF_ON_TABLE | (t[j].pf & PF_PARTIAL_MASK)) : 0u) | (t[j].hon ? M2_HOT_ON : 0u) |
+                           ((t[j].hon && t[j].hcomp) ? M2_HOT_COMPLETE : 0u) | (a_hmin << 8);
+      const uint32_t q_pl = is0 ? c[j].pl0 : (isB ? len_clean : (isA ? c[j].pl0 + c[j].len_raw : 0u));
+      const uint32_t q_m2 = is0 ? c[j].m2_0 : (isB ? m2B : (isA ? m2A : EMPTY_PARTIAL_M2));
+      const uint32_t q_wid = is0 ? st_wid : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t[j].on ? t[j].nw : 0u) : 0u));
+      const double ps_new = partial_score_sel(isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
+      const double q_ps = is0 ? st_ps : ((bw || isA) ? ps_new : 0.0);
+      const double lmhw = (!is0 && !isA && c[j].pl0 > 0) ? c_lmhw : c[j].lmhw;  // boundary / space close the open word
+      const double sc = total_score(tab, c[j].lg, lmhw, q_ps, q_pl);
+      score[j] = rep ? sc : 0.0;
+      my_key[j] = rep ? asc_key(sc) : 0ull;
+      v_pl[j] = q_pl;
+      v_m2[j] = q_m2;
+      v_wid[j] = q_wid;
+      if (my_key[j] > pass_key) pass_key = my_key[j];
     }
     pass_key = ctx.wave_max_u64(pass_key);
     if (pass_key > runmax) runmax = pass_key;
