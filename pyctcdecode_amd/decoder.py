@@ -341,9 +341,10 @@ class BeamSearchDecoderCTC:
 
     def _params(self, beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_weight, n_best) -> B.Params:
         lm = self._members[0] if self._members else None  # model 0; the others go through ctcdec_lm_set_params
-        for k, m in enumerate(self._members[1:], start=1):
-            self._lib.check(self._lib.dll.ctcdec_lm_set_params(
-                self._handle, k, float(m.alpha), float(m.beta), float(m.unk_score_offset), int(bool(m.score_boundary))))
+        with self._call_lock:  # (RLock: the streaming path already holds it; nothing may change the handle mid-call)
+            for k, m in enumerate(self._members[1:], start=1):
+                self._lib.check(self._lib.dll.ctcdec_lm_set_params(
+                    self._handle, k, float(m.alpha), float(m.beta), float(m.unk_score_offset), int(bool(m.score_boundary))))
         p = B.Params()
         p.beam_width = int(beam_width)
         p.prune_history = int(bool(prune_history))
