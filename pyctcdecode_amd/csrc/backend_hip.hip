@@ -591,6 +591,26 @@ __device__ __forceinline__ double exp_nonpos(double d) {
   return ldexp(p, (int)kf);
 }
 
+// The same with the degree-9 polynomial: relative error < 7e-12 (|r|^10 / 10!), for sums that feed a float32 input's
+// log-softmax (frame_prune_f32x4); four FMAs less per call.
+__device__ __forceinline__ double exp_nonpos9(double d) {
+  d = fmax(d, -750.0);
+  const double kf = rint(d * 1.44269504088896338700e+00);
+  double r = fma(kf, -6.93147180369123816490e-01, d);
+  r = fma(kf, -1.90821492927058770002e-10, r);
+  double p = 2.75573192239858907e-06;           // 1/9!
+  p = fma(p, r, 2.48015873015873016e-05);       // 1/8!
+  p = fma(p, r, 1.98412698412698413e-04);       // 1/7!
+  p = fma(p, r, 1.38888888888888889e-03);       // 1/6!
+  p = fma(p, r, 8.33333333333333333e-03);       // 1/5!
+  p = fma(p, r, 4.16666666666666667e-02);       // 1/4!
+  p = fma(p, r, 1.66666666666666667e-01);       // 1/3!
+  p = fma(p, r, 5.00000000000000000e-01);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
+}
+
 // log(s) for 1 <= s < 2^24, fp64: one Newton step on the fp32 logarithm -- y0 = logf(s), r = s * exp(-y0) - 1
 // (|r| ~ 1e-6), log(s) = y0 + log1p(r) = y0 + r - r^2/2 (next term < 1e-18). A third of ocml's double-double log.
 __device__ __forceinline__ double log_ge1(double s) {
@@ -640,19 +660,18 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
     if (lane == 0) a.row_sum[row] = rs;
     // ---- the clean row (finite maximum, no NaN: -inf masks are fine): everything below in its cheapest form
     if (isfinite(m) && rs == rs) {
-      // The reference computes the log-softmax of float32 logits IN float32 (decoder.py:180-197: np.exp / np.sum
-      // on the float32 array), so the exponentials are taken at that precision here too -- v_exp_f32, one
-      // instruction instead of the 21 of the fp64 routine, which made this kernel VALU-bound -- and summed in fp64 (a
-      // float32 accumulator loses the small terms next to the maximum's 1.0 the same way in every frame of a steady
-      // stretch, which adds up over T). Everything downstream (lse, the clipped log-probs, all
-      // score arithmetic) stays fp64. float64 inputs go through frame_prune<double>, which is fp64 throughout.
+      // The reference computes the log-softmax of float32 logits IN float32 (decoder.py:180-197: np.exp / np.sum on
+      // the float32 array, correctly rounded per term, errors of either sign). Tried and dropped: v_exp_f32 -- a
+      // third of the instructions, but the hardware exp2 errs to one side, which shifts lse by ~5e-8 in EVERY frame and
+      // the scores by 4.8e-5 over T=1000 (tools/golden_full_gap.py; the bound is 1e-4). Kept: the fp64 routine cut to
+      // the degree its purpose needs (1e-11 per term, errors of either sign), fp64 accumulation.
       const float mfw = (float)m;  // exact: m is the maximum of float32 values
       double sl = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         if (k * 64 + lane < n4)
-          sl += ((double)__expf(r[k].x - mfw) + (double)__expf(r[k].y - mfw)) +
-                ((double)__expf(r[k].z - mfw) + (double)__expf(r[k].w - mfw));
+          sl += (exp_nonpos9((double)r[k].x - m) + exp_nonpos9((double)r[k].y - m)) +
+                (exp_nonpos9((double)r[k].z - m) + exp_nonpos9((double)r[k].w - m));
       }
       const double s = wave_sum(sl);
       lse = log_ge1(s);
