@@ -1,7 +1,8 @@
 """Parity at FULL SIZE against the unmodified reference: tests/golden/cases_full.json holds what /root/reference
 returned (oracle/make_golden_full.py) for utterances of the bench workload itself -- T=1000, V=1024, 20k-word 4-gram
 LM, hot words -- fed as float64 and as float32, and for one BASELINE config-2 utterance. Inputs are regenerated from
-their seeds.
+their seeds. tests/golden/cases_peaky.json (oracle/make_golden_peaky.py) adds real-posterior-like utterances of the
+same vocabulary / LM -- the inputs on which the kernels consume runs of single-label frames in place.
 
 * float64 inputs: order / frames exact, scores within 1e-6 (oracle: 1e-9).
 * float32 inputs: the reference runs _log_softmax in the INPUT dtype (decoder.py:180-197); the device upcasts
@@ -22,7 +23,9 @@ from tests.sim_util import sim_library  # noqa: F401
 
 with open(os.path.join(GOLD, "cases_full.json")) as f:
     FULL = json.load(f)
-CASES = FULL["cases"]
+with open(os.path.join(GOLD, "cases_peaky.json")) as f:  # oracle/make_golden_peaky.py: real-posterior-like inputs
+    PEAKY = json.load(f)["cases"]
+CASES = FULL["cases"] + PEAKY
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,7 +39,11 @@ def _input(case, assets):
     lm, labels, hot = assets
     if case["kind"] == "config2":
         return synth.LIBRI_LABELS, None, synth.d_flat(2, case["utt"], case["frames"], 29).astype(case["dtype"]), dict(case["decode"])
-    x = synth.d_words(bench.CONFIG_ID, case["utt"], bench.T, labels, True, lm.words, lm.sentences, len(labels), boost=6.0)
+    if case["kind"] == "peaky":
+        x = synth.d_peaky(bench.CONFIG_ID + 1, case["utt"], bench.T, labels, True, lm.words, lm.sentences, len(labels),
+                          boost=case["boost"], unsure=case["unsure"])
+    else:
+        x = synth.d_words(bench.CONFIG_ID, case["utt"], bench.T, labels, True, lm.words, lm.sentences, len(labels), boost=6.0)
     kw = dict(case["decode"])
     kw["hotwords"] = hot if kw["hotwords"] == "bench" else None
     return labels, lm.path, x.astype(case["dtype"]), kw
@@ -54,7 +61,8 @@ def _check(case, got, tol):
             assert [[w, int(a), int(b)] for w, (a, b) in g[1]] == e["frames"], case["name"]
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("bench_u0_float64", "bench_u1_float32", "bench_u3_float32")],
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("bench_u0_float64", "bench_u1_float32", "bench_u3_float32",
+                                                                     "peaky_u1_float32", "peaky_u2_float64")],
                          ids=lambda c: c["name"])
 def test_oracle_equals_the_reference_at_full_size(case, assets):
     """The oracle keeps the input dtype like the reference: float32 cases must agree to 1e-9 as well."""
@@ -72,7 +80,8 @@ def test_oracle_equals_the_reference_at_full_size(case, assets):
                  for e, o in zip(case["expected"], out)], tol=1e-9, what=case["name"])
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("bench_u0_float64", "bench_u1_float32")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in CASES if c["name"] in ("bench_u0_float64", "bench_u1_float32") or c["kind"] == "peaky"],
+                         ids=lambda c: c["name"])
 def test_sim_equals_the_reference_at_full_size(case, assets, sim_library, both_beam_kernels):  # noqa: F811
     from pyctcdecode_amd import build_ctcdecoder
 
