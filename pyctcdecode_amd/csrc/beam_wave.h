@@ -17,6 +17,14 @@
 //   * threshold, top-B and the history prune are one counting sweep over 16-byte {score key, history
 //     key} records that every lane reads at the same address (an LDS broadcast);
 //   * the next table is built by gathering (pool entry, donor record, label record) per kept rank.
+//   * runs of frames whose only survivor is the label every beam already ends in (most frames of a real
+//     posterior) are consumed in place, 64 at a time, each checked to leave the order intact (label_run).
+// Written for a LONE wave per SIMD: exec-mask branches and misplaced s_waitcnt are what cost here, so the
+// per-candidate work is straight-line selects over safe LDS indices, and registers that receive global
+// loads are laundered (ctx.opaque32) at their first intended use.
+// Diagnostics, all off by default: CTC_WAVE_TRACE (device printf of pool / beam records), CTC_RUN_TRACE
+// (host: which frames label_run consumed), CTC_SIM_DEBUG (index checks in the simulator), tick<>() phase
+// timers (ctcdec_profile_phases).
 // Everything a lane shares with another lane goes through LDS or a cross-lane instruction; `wsync()`
 // marks the points where LDS traffic of different lanes meets (on the device a compiler fence -- one
 // wave issues its LDS operations in order --, in the 64-fiber test simulator a rendezvous).
