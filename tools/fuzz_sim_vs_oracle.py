@@ -170,6 +170,12 @@ def run_case(rng, execute=True):
         twins = lambda a, b: all(any(abs(v - w) <= 1e-9 * max(1.0, abs(w)) for w in b) for v in a)  # noqa: E731
         if common_ok and only_g and only_e and twins(only_g, list(em.values())) and twins(only_e, list(gm.values())):
             return "near-tie at a cut"
+        # ... or sits EXACTLY on the score threshold (quantised logits make score differences exact multiples of the
+        # quantum, e.g. best - 3.0 with beam_prune_logp = -3.0): `>=` holds on one side and fails by one ulp on the other
+        thr = max(list(gm.values()) + list(em.values())) + dkw["beam_prune_logp"]
+        on_thr = lambda a: all(abs(v - thr) <= 1e-9 * max(1.0, abs(thr)) for v in a)  # noqa: E731
+        if common_ok and (only_g or only_e) and on_thr(only_g) and on_thr(only_e):
+            return "near-tie at a cut"
         raise
     # batch entry points: ragged batch (incl. an empty utterance) == utterance by utterance
     if rng.random() < 0.25:
@@ -257,7 +263,8 @@ def main():
             print("case", i, flush=True)
         only = os.environ.get("FUZZ_ONLY")
         try:
-            r = run_case(rng, execute=(only is None or int(only) == i))
+            first = int(os.environ.get("FUZZ_FROM", "0"))  # FUZZ_FROM=k: replay the generator up to case k, execute from there
+            r = run_case(rng, execute=(i >= first) if only is None else int(only) == i)
         except Exception:
             print("FAILED case %d (seed %d); rng state before the case:\n%r" % (i, seed, state))
             raise
