@@ -227,6 +227,10 @@ int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out);
 /* Only the texts of all beams (utterance-major, the order of ctcdec_result_pack): UTF-8 blob + n+1 byte offsets. What
  * decode_batch needs (decoder.py:895-945) without packing word frames and states. Owned by the result. */
 int ctcdec_result_texts(ctcdec_result* r, const char** blob_out, const int64_t** off_out, int64_t* n_out);
+/* The same texts as ONE buffer with `sep` between consecutive texts (n - 1 separators, none at the end): a caller whose
+ * language splits strings natively (Python: str.split) gets its n string objects in one call instead of n slices.
+ * The caller picks a byte that cannot occur in a text (a label containing it rules this entry point out). */
+int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out, int64_t* bytes_out, int64_t* n_out);
 
 /* timing of the last call's device stages in milliseconds (HIP events on the decode stream):
  * [0] frame-prune kernel, [1] beam kernel, [2] total device time incl. result copy */

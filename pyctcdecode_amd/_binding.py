@@ -122,6 +122,7 @@ _PROTOS = {
     "ctcdec_result_lm_state_of": (C.c_int, [_VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(LmState)]),
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_texts": (C.c_int, [_VP, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
+    "ctcdec_result_texts_joined": (C.c_int, [_VP, C.c_char, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "ctcdec_result_beam_kernel": (C.c_int, [_VP]),
     "ctcdec_device": (C.c_int, []),

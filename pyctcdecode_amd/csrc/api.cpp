@@ -226,6 +226,7 @@ struct ctcdec_result {
   bool texts_packed = false;
   std::string t_blob;
   std::vector<int64_t> t_off;
+  std::string j_blob;  // ctcdec_result_texts_joined
   // packed view (built on demand by ctcdec_result_pack)
   bool packed = false;
   std::vector<int64_t> beam_off, text_off, word_cnt_off;
@@ -1341,6 +1342,28 @@ int ctcdec_result_texts(ctcdec_result* r, const char** blob_out, const int64_t**
   *blob_out = r->t_blob.data();
   *off_out = r->t_off.data();
   *n_out = (int64_t)r->t_off.size() - 1;
+  return CTCDEC_OK;
+}
+
+int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out, int64_t* bytes_out, int64_t* n_out) {
+  if (!r || !blob_out || !bytes_out || !n_out) return fail(CTCDEC_ERR_ARG, "no result");
+  size_t nb = 0, bytes = 0;
+  for (const auto& beams : r->utts)
+    for (const BeamResult& b : beams) {
+      ++nb;
+      bytes += b.text.size() + 1;
+    }
+  r->j_blob.clear();
+  r->j_blob.reserve(bytes);
+  size_t k = 0;
+  for (const auto& beams : r->utts)
+    for (const BeamResult& b : beams) {
+      if (k++) r->j_blob += sep;
+      r->j_blob += b.text;
+    }
+  *blob_out = r->j_blob.data();
+  *bytes_out = (int64_t)r->j_blob.size();
+  *n_out = (int64_t)nb;
   return CTCDEC_OK;
 }
 

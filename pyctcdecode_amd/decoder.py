@@ -271,6 +271,10 @@ class BeamSearchDecoderCTC:
             srcs = (C.c_void_p * len(members))(*[m._kenlm_model._handle for m in members])
             lib.check(lib.dll.ctcdec_lm_share_multi(handle, srcs, len(members)))
         self._hot_key: Optional[Tuple[str, ...]] = None
+        # a byte no decoded text can contain (texts are made of label characters and spaces): lets decode_batch take its
+        # texts as one joined buffer and split it natively
+        self._texts_sep: Optional[bytes] = next(
+            (c.encode("ascii") for c in ("\n", "\x01", "\x02") if not any(c in lab for lab in self._alphabet.labels)), None)
         # one native call at a time per decoder: hot words / per-model weights are decoder state that a call sets
         # up first (host threads may share a decoder; ctypes releases the GIL while the device works)
         self._call_lock = threading.RLock()
@@ -506,6 +510,15 @@ class BeamSearchDecoderCTC:
         params = self._params(beam_width, beam_prune_logp, token_min_logp, True, hotword_weight, 1)
         res = self._run(logits_list, params, hotwords)
         try:
+            if self._texts_sep is not None:  # one split instead of one slice per utterance (0.7 -> 0.15 ms at 4096)
+                blob_p, nbytes, n = C.c_void_p(), C.c_int64(), C.c_int64()
+                self._lib.check(self._lib.dll.ctcdec_result_texts_joined(res, self._texts_sep, C.byref(blob_p), C.byref(nbytes),
+                                                                         C.byref(n)))
+                if n.value == 0:
+                    return []
+                parts = C.string_at(blob_p, int(nbytes.value)).decode("utf-8").split(self._texts_sep.decode("ascii"))
+                if len(parts) == n.value:
+                    return parts
             blob_p, off_p, n = C.c_void_p(), C.POINTER(C.c_int64)(), C.c_int64()
             self._lib.check(self._lib.dll.ctcdec_result_texts(res, C.byref(blob_p), C.byref(off_p), C.byref(n)))
             nb = int(n.value)

@@ -347,3 +347,20 @@ def test_label_run_across_look_ahead_windows_to_the_end(sim_library):  # noqa: F
     held[:, 5] = 8.0
     for x, what in ((np.concatenate([head, tail]), "blank-tail"), (np.concatenate([head, held, tail[:3]]), "held")):
         _compare(labels, LM.path, x, dkw={"prune_history": True}, what=what)
+
+
+def test_decode_batch_texts_with_awkward_labels(sim_library):  # noqa: F811
+    """decode_batch takes its texts as one joined buffer and splits it natively; the separator must not be a
+    character a label can produce (a newline label moves it on), non-ASCII labels and empty texts must survive."""
+    from pyctcdecode_amd import build_ctcdecoder
+
+    for labels in (["\n", "a", "b", "é", " "], ["a", "b", "ü", "\x01", " "], ["\n", "\x01", "\x02", "a", " "]):
+        dec = build_ctcdecoder(labels)
+        assert dec._texts_sep not in [lab.encode("utf-8") for lab in labels]
+        rng = np.random.default_rng(5)
+        xs = [rng.standard_normal((t, len(labels) + 1)) * 3 for t in (12, 1, 7, 0, 9)]
+        xs[1][:, :] = -20.0
+        xs[1][:, len(labels)] = 20.0  # blank only: an empty text in the middle of the batch
+        texts = dec.decode_batch(None, xs)
+        assert texts == [dec.decode(x) for x in xs]
+        assert texts[1] == "" and texts[3] == ""
