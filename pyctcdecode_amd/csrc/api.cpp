@@ -1466,10 +1466,13 @@ void ctcdec_result_free(ctcdec_result* r) {
   // tearing down the per-beam strings and vectors of a large batch takes about as long as copying the results back
   // from the device did: off the caller's thread
   if (r->utts.size() >= 256) {
-    std::thread([r] { delete r; }).detach();
-  } else {
-    delete r;
+    try {
+      std::thread([r] { delete r; }).detach();
+      return;
+    } catch (...) {  // no thread to be had: free it here (nothing may escape an extern "C" function)
+    }
   }
+  delete r;
 }
 
 }  // extern "C"
