@@ -195,14 +195,14 @@ struct ctcdec_decoder {
   HostBuf h_xstate;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
-      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff;
+      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold;
   HostBuf h_tok, h_out, h_small;
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
-                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff};
+                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
       d_xuni[k].drop();
@@ -746,6 +746,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   // streaming: carried-over beams of every stream
   const ImportBeam* d_imports = nullptr;
   const LmState* d_import_x = nullptr;
+  int32_t max_import = 0;
   if (stream) {
     const int64_t n_imp_total = stream->beam_off[n_utts];
     std::vector<ImportBeam> imps((size_t)std::max<int64_t>(n_imp_total, 1));
@@ -756,6 +757,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       int64_t cnt = ioff[(size_t)u + 1] - ioff[(size_t)u];
       if (cnt < 1 || cnt > shape_bw_limit(B))
         return fail(CTCDEC_ERR_ARG, "a stream must carry between 1 and beam-capacity beams");
+      max_import = std::max<int32_t>(max_import, (int32_t)cnt);
       for (int64_t k = ioff[(size_t)u]; k < ioff[(size_t)u + 1]; ++k) {
         std::string e = build_import(dec, *stream, k, B, &imps[(size_t)k],
                                      K > 1 ? &imps_x[(size_t)k * (size_t)(K - 1)] : nullptr);
@@ -775,7 +777,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       upload(dec->w_eoff, eoff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
       dec->w_nout.ensure((size_t)n_utts * 4, &err) || dec->w_status.ensure((size_t)n_utts * 4, &err) ||
       dec->w_tok.ensure((size_t)std::max<unsigned long long>(tok_cap, 1) * sizeof(EmitNode), &err) ||
-      dec->w_head.ensure(16, &err))
+      dec->w_head.ensure(16, &err) || dec->w_cold.ensure((size_t)n_utts * 2 * COLD_STRIDE * sizeof(ColdRec), &err))
     return fail(CTCDEC_ERR_DEVICE, err);
   const LmState* d_start = nullptr;
   if (stream) {
@@ -852,6 +854,8 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.import_xstates = d_import_x;
   ba.import_off = stream ? (const int64_t*)dec->w_impoff.p : nullptr;
   ba.first_frames = stream ? (const int32_t*)dec->w_ff.p : nullptr;
+  ba.cold = (ColdRec*)dec->w_cold.p;
+  ba.max_import = max_import;
   if (dec->profile) {
     if (dec->w_prof.ensure(N_PROF * 8, &err) || be::zero(dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     ba.prof = (unsigned long long*)dec->w_prof.p;
@@ -940,6 +944,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
         bc.tok_pool_head = (unsigned long long*)dec->w_head.p + 2 * c;
         bc.tok_pool_cap = tok_base[(size_t)c + 1] - tok_base[(size_t)c];
         bc.prof = nullptr;
+        bc.cold = ba.cold + (size_t)u0 * 2 * COLD_STRIDE;
         be::use_stream(0);
         enq_ok = !be::ev_record(4 * c + 1, &err) && !be::launch_prune(pa, &err) && !be::ev_record(4 * c + 2, &err);
         be::use_stream(1);

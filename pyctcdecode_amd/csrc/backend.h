@@ -8,7 +8,7 @@
 
 #include <string>
 
-#include "common.h"
+#include "beam_core.h"
 
 namespace ctc {
 namespace be {
@@ -88,6 +88,8 @@ struct BeamArgs {
   const LmState* import_xstates;  // several LMs: [total beams * (n_lms - 1)] their states of LM 1.., else nullptr
   const int64_t* import_off;   // [n_utts + 1] (device)
   const int32_t* first_frames; // [n_utts] processed_frames per utterance (device), or nullptr
+  ColdRec* cold;               // [n_utts * 2 * COLD_STRIDE] scratch of the wave kernel
+  int32_t max_import;          // streaming: the largest number of beams any stream carries in
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 

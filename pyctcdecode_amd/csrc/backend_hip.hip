@@ -611,6 +611,32 @@ __device__ __forceinline__ double exp_nonpos9(double d) {
   return ldexp(p, (int)kf);
 }
 
+// float32 exp(d), d <= 0, two at a time (v_pk_* math): degree-8 Taylor polynomial after a two-constant argument reduction,
+// every step one rounding (fma). Measured on the host with the same operations (tools/exp_f32_study.c, 20 M arguments in
+// [-14, 0]): mean relative error 1.5e-11 (libm's expf: 3.5e-11), mean |error| 2.2e-8, maximum 7.4e-8 -- i.e. what numpy's
+// float32 exp gives the reference (decoder.py:180-197), and without the one-sided error of v_exp_f32. Arguments below -80
+// (incl. -inf masks) are clamped: exp(-80) = 1.8e-35 does not register in a sum >= 1.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_nonpos_f32x2(f32x2 d) {
+  d = __builtin_elementwise_max(d, (f32x2)(-80.0f));
+  const f32x2 n = __builtin_elementwise_roundeven(d * (f32x2)(1.44269504088896340736f));
+  f32x2 r = __builtin_elementwise_fma(n, (f32x2)(-0.693145751953125f), d);
+  r = __builtin_elementwise_fma(n, (f32x2)(-1.42860682030941723212e-6f), r);
+  f32x2 p = (f32x2)(2.48015873015873016e-05f);                              // 1/8!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.98412698412698413e-04f));   // 1/7!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.38888888888888889e-03f));   // 1/6!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(8.33333333333333333e-03f));   // 1/5!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(4.16666666666666667e-02f));   // 1/4!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.66666666666666667e-01f));   // 1/3!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(0.5f));
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.0f));
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.0f));
+  f32x2 out;
+  out.x = ldexpf(p.x, (int)n.x);
+  out.y = ldexpf(p.y, (int)n.y);
+  return out;
+}
+
 // log(s) for 1 <= s < 2^24, fp64: one Newton step on the fp32 logarithm -- y0 = logf(s), r = s * exp(-y0) - 1
 // (|r| ~ 1e-6), log(s) = y0 + log1p(r) = y0 + r - r^2/2 (next term < 1e-18). A third of ocml's double-double log.
 __device__ __forceinline__ double log_ge1(double s) {
@@ -622,7 +648,8 @@ __device__ __forceinline__ double log_ge1(double s) {
 // Register-resident frame-prune for fp32 rows with V % 4 == 0 and V <= 1024*... (NC chunks of 256
 // labels): each lane pulls its 4*NC logits with 16-byte loads ONCE (1 KiB per wave-instruction, fully
 // coalesced) and all three sweeps run out of registers: the logits cross HBM exactly once.
-template <int NC>
+// PK: the exponentials of the clean-row path as packed float32 polynomials (CTCDEC_PRUNE_EXP=pk; default: fp64)
+template <int NC, bool PK>
 __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs a, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -669,9 +696,17 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
       double sl = 0.0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        if (k * 64 + lane < n4)
-          sl += (exp_nonpos9((double)r[k].x - m) + exp_nonpos9((double)r[k].y - m)) +
-                (exp_nonpos9((double)r[k].z - m) + exp_nonpos9((double)r[k].w - m));
+        if (k * 64 + lane < n4) {
+          if (PK) {
+            // (x - m in float32: one rounding, as in the reference's float32 `x - x_max`)
+            const f32x2 e01 = exp_nonpos_f32x2((f32x2){r[k].x - mfw, r[k].y - mfw});
+            const f32x2 e23 = exp_nonpos_f32x2((f32x2){r[k].z - mfw, r[k].w - mfw});
+            sl += ((double)e01.x + (double)e01.y) + ((double)e23.x + (double)e23.y);
+          } else {
+            sl += (exp_nonpos9((double)r[k].x - m) + exp_nonpos9((double)r[k].y - m)) +
+                  (exp_nonpos9((double)r[k].z - m) + exp_nonpos9((double)r[k].w - m));
+          }
+        }
       }
       const double s = wave_sum(sl);
       lse = log_ge1(s);
@@ -789,10 +824,18 @@ int launch_prune(const PruneArgs& a, std::string* err) {
   } while (0)
     if (vec4) {
       const int nc = (a.n_labels / 4 + 63) / 64;
-      if (nc <= 1) CTC_LAUNCH_PRUNE(frame_prune_f32x4<1>);
-      else if (nc == 2) CTC_LAUNCH_PRUNE(frame_prune_f32x4<2>);
-      else if (nc == 3) CTC_LAUNCH_PRUNE(frame_prune_f32x4<3>);
-      else CTC_LAUNCH_PRUNE(frame_prune_f32x4<4>);
+      const char* ex = getenv("CTCDEC_PRUNE_EXP");
+      if (ex && ex[0] == 'p') {
+        if (nc <= 1) CTC_LAUNCH_PRUNE((frame_prune_f32x4<1, true>));
+        else if (nc == 2) CTC_LAUNCH_PRUNE((frame_prune_f32x4<2, true>));
+        else if (nc == 3) CTC_LAUNCH_PRUNE((frame_prune_f32x4<3, true>));
+        else CTC_LAUNCH_PRUNE((frame_prune_f32x4<4, true>));
+      } else {
+        if (nc <= 1) CTC_LAUNCH_PRUNE((frame_prune_f32x4<1, false>));
+        else if (nc == 2) CTC_LAUNCH_PRUNE((frame_prune_f32x4<2, false>));
+        else if (nc == 3) CTC_LAUNCH_PRUNE((frame_prune_f32x4<3, false>));
+        else CTC_LAUNCH_PRUNE((frame_prune_f32x4<4, false>));
+      }
     } else if (a.dtype == 0) {
       CTC_LAUNCH_PRUNE(frame_prune<float>);
     } else if (a.dtype == 1) {
@@ -903,6 +946,7 @@ __global__ __launch_bounds__(NT, 2) void beam_decode(BeamArgs a, int surv_cap) {
   io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
     io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
+  io.cold = nullptr;
   GpuCtx ctx{(int)threadIdx.x, NT};
   BeamDecoder<GpuCtx, MULTI> dec(ctx, view, shape, a.tables, a.params, io);
   dec.run();
@@ -1036,6 +1080,7 @@ __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
   io.import_xstates = nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
+  io.cold = a.cold + (size_t)u * 2 * COLD_STRIDE;
   WaveGpuCtx ctx{(int)threadIdx.x};
   WaveDecoder<WaveGpuCtx, BW> dec(ctx, view, a.tables, a.params, io);
   dec.run();
@@ -1061,11 +1106,13 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   // batch-size rule (tests, tuning; `wave` still falls back when the decode is not eligible for it).
   const char* force = getenv("CTCDEC_BEAM_KERNEL");
   const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
-  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
+  // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
+  const bool wave_ok = wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width);
+  if (a.n_utts > 0 && wave_ok && !want_group) {
     int rc;
     switch (wave_bucket(a.params.beam_width)) {
       case 64: rc = launch_wave_t<64>(a, err); break;
-      case 104: rc = launch_wave_t<104>(a, err); break;
+      case 100: rc = launch_wave_t<100>(a, err); break;
       default: rc = launch_wave_t<128>(a, err); break;
     }
     if (rc) return rc;

@@ -197,6 +197,15 @@ CTC_HD size_t lds_bytes(const LdsShape& s) {
   return lds_carve(tmp, (lds_bytes_t) nullptr, s);
 }
 
+// wave kernel (beam_wave.h): what only the table build and the finalisation need of a beam -- the frames of its open
+// word and the length of its emission chain -- lives outside LDS, two buffers of COLD_STRIDE records per utterance
+struct ColdRec {  // 16 B
+  int32_t pstart, pend;  // partial_frames of the open word
+  uint32_t depth;        // emission nodes on the beam's chain
+  uint32_t pad;
+};
+constexpr int COLD_STRIDE = 128;
+
 // per-utterance global-memory view
 struct UttIO {
   const uint32_t* surv_cnt;  // [T]
@@ -220,6 +229,7 @@ struct UttIO {
   const LmState* import_xstates;  // several LMs: [n_import * (n_lms - 1)] states of LM 1.. of those beams
   int32_t n_import;
   int32_t first_frame;        // processed_frames of this utterance (decoder.py:443)
+  ColdRec* cold;              // wave kernel: [2 * COLD_STRIDE]
 };
 constexpr int N_PROF = 24;
 

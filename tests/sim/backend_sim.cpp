@@ -170,6 +170,7 @@ static void fill_io(const BeamArgs& a, int u, UttIO& io) {
   io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
   io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
+  io.cold = a.cold ? a.cold + (size_t)u * 2 * COLD_STRIDE : nullptr;
 }
 
 // one wavefront per utterance (beam_wave.h) on 64 cooperative fibers
@@ -199,10 +200,10 @@ int last_beam_kernel() { return g_last_kernel; }
 int launch_beam(const BeamArgs& a, std::string*) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend (default here: wave)
   const bool want_group = force && force[0] == 'g';
-  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && !want_group) {
+  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width) && !want_group) {
     switch (wave_bucket(a.params.beam_width)) {
       case 64: run_wave<64>(a); break;
-      case 104: run_wave<104>(a); break;
+      case 100: run_wave<100>(a); break;
       default: run_wave<128>(a); break;
     }
     g_last_kernel = 1;
