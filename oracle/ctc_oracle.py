@@ -280,9 +280,15 @@ def _join(text: str, word: str) -> str:
     return text + " " + word
 
 
-def normalise_logits(logits: np.ndarray) -> np.ndarray:
-    """decoder.py:759-765 / :180-197."""
-    if math.isclose(logits.sum(axis=1).mean(), 1):
+def normalise_logits(logits: np.ndarray, sniff_on: Optional[np.ndarray] = None) -> np.ndarray:
+    """decoder.py:759-765 / :180-197.
+
+    ``sniff_on`` (tests only): the parity tests hand the oracle an exact float64 upcast of the float32 / float16 matrix
+    the product gets, so that the reference's own low-precision log-softmax does not blur the comparison. The
+    "probabilities or logits?" test, however, is a property of the ORIGINAL dtype (its mean row sum rounds to exactly 1
+    or it does not): it is taken on ``sniff_on`` when given."""
+    probe = logits if sniff_on is None else sniff_on
+    if math.isclose(probe.sum(axis=1).mean(), 1):
         return np.log(np.clip(logits, MIN_TOKEN_CLIP_P, 1))
     x_max = np.amax(logits, axis=1, keepdims=True)
     x_max[~np.isfinite(x_max)] = 0
@@ -508,12 +514,13 @@ class OracleDecoder:
         hotword_weight: float = 10.0,
         force_next_word: bool = False,
         is_end: bool = False,
+        sniff_on: Optional[np.ndarray] = None,
     ) -> List[OBeam]:
         """decoder.py:681-728; the caller feeds the returned beams back through ``st.beams``."""
         self._check(logits)
         hw = HotwordOracle(hotwords, hotword_weight) if hotwords is not None else HotwordOracle([], 0.0)
         self._advance(
-            normalise_logits(logits), st, beam_width, beam_prune_logp, token_min_logp,
+            normalise_logits(logits, sniff_on), st, beam_width, beam_prune_logp, token_min_logp,
             prune_history, hw, processed_frames,
         )
         out = self._finalise(st, beam_width, beam_prune_logp, hw, force_next_word, is_end)
@@ -530,13 +537,14 @@ class OracleDecoder:
         hotwords: Optional[Iterable[str]] = None,
         hotword_weight: float = 10.0,
         lm_start_state: Optional[ArpaState] = None,
+        sniff_on: Optional[np.ndarray] = None,
     ):
         """Returns [(text, last_lm_state, [(word,(start,end))...], logit_score, lm_score)]."""
         self._check(logits)
         hw = HotwordOracle(hotwords, hotword_weight)
         st = self.get_starting_state(lm_start_state)
         self._advance(
-            normalise_logits(logits), st, beam_width, beam_prune_logp, token_min_logp,
+            normalise_logits(logits, sniff_on), st, beam_width, beam_prune_logp, token_min_logp,
             prune_history, hw, 0,
         )
         final = self._finalise(st, beam_width, beam_prune_logp, hw, True, True)

@@ -864,209 +864,6 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   // queued right behind it on the same stream: the host never sits between the two kernels. The two
   // rare events the prune stage can report (probability-like input, survivor overflow) are read back
   // afterwards and simply redo the affected stage(s).
-  // ---- large batches: chunked pipeline (opt-in: CTCDEC_PIPELINE=1) -------------------------------------------
-  // The batch is cut into chunks of as many utterances as the beam kernel keeps resident at once; chunk k's
-  // frame-prune kernel (stream 0), chunk k-1's beam kernel (stream 1) and the copy-back + host replay of chunk
-  // k-2 overlap. Optimistic: if a chunk reports one of the two rare prune events (probability-like input, survivor
-  // overflow) the whole batch is redone by the sequential path below.
-  // MEASURED AND LEFT OFF BY DEFAULT (MI355X, 4096 x T=1000): 83.5 ms per step against 78.6 ms sequential. The beam
-  // kernel is a per-utterance latency chain with one wave per SIMD; frame-prune waves sharing its CUs slow every
-  // chain (beam 58.8 -> 75.9 ms in total, prune 10.9 -> 21.6 ms), which costs more than the ~6 ms of hidden
-  // prune + host tail.
-  bool pipelined_done = false;
-  {
-    const int32_t max_chunks = (be::n_events() - 1) / 4;  // four events per chunk
-    int32_t chunk = 4 * be::cus();
-    if ((n_utts + chunk - 1) / chunk > max_chunks) chunk = (n_utts + max_chunks - 1) / max_chunks;
-    const int32_t n_chunks = (n_utts + chunk - 1) / chunk;
-    if (!stream && n_chunks >= 2 && !dec->profile && getenv("CTCDEC_PIPELINE") != nullptr) {
-      size_t rows = (size_t)std::max<int64_t>(R, 1);
-      if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
-          dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
-          dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16 * (size_t)n_chunks, &err) ||
-          dec->w_head.ensure(16 * (size_t)n_chunks, &err) || dec->h_small.ensure((size_t)n_utts * 8 + 32 * (size_t)n_chunks, &err) ||
-          dec->h_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err))
-        return fail(CTCDEC_ERR_DEVICE, err);
-      dp.max_surv = max_surv;
-      int rows16 = 1;
-      for (const void* q : ptrs)
-        if (((uintptr_t)q & 15u) != 0) rows16 = 0;
-      std::vector<unsigned long long> tok_base((size_t)n_chunks + 1, 0);
-      size_t max_chunk_tok = 0;
-      for (int32_t c = 0; c < n_chunks; ++c) {
-        const int32_t u0 = c * chunk, u1 = std::min(n_utts, u0 + chunk);
-        const unsigned long long cap_c = (unsigned long long)n_best * (unsigned long long)(row0[(size_t)u1] - row0[(size_t)u0] + 2 * (int64_t)(u1 - u0));
-        tok_base[(size_t)c + 1] = tok_base[(size_t)c] + cap_c;
-        max_chunk_tok = std::max<size_t>(max_chunk_tok, (size_t)cap_c);
-      }
-      be::use_stream(0);
-      if (be::zero(dec->w_flags.p, 16 * (size_t)n_chunks, &err) || be::zero(dec->w_head.p, 16 * (size_t)n_chunks, &err) ||
-          be::ev_record(4 * 0 + 0, &err))  // (also orders the two memsets before everything else)
-        return fail(CTCDEC_ERR_DEVICE, err);
-      be::use_stream(1);
-      if (be::ev_wait(0, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-      // enqueue everything: events of chunk c are 4c+1 (prune start), 4c+2 (prune end), 4c+3 (beam start), 4c+4 (beam end)
-      bool enq_ok = true;
-      for (int32_t c = 0; c < n_chunks && enq_ok; ++c) {
-        const int32_t u0 = c * chunk, u1 = std::min(n_utts, u0 + chunk);
-        be::PruneArgs pa;
-        pa.utt_logits = (const void* const*)dec->w_ptrs.p + u0;
-        pa.utt_row0 = (const int64_t*)dec->w_row0.p + u0;
-        pa.n_utts = u1 - u0;
-        pa.n_rows = row0[(size_t)u1] - row0[(size_t)u0];
-        pa.row_base = row0[(size_t)u0];
-        pa.n_labels = V;
-        pa.dtype = dtype;
-        pa.token_min_logp = p->token_min_logp;
-        pa.max_surv = max_surv;
-        pa.row_sum = (double*)dec->w_rowsum.p;
-        pa.utt_is_prob = (uint32_t*)dec->w_isprob.p + u0;
-        pa.surv_cnt = (uint32_t*)dec->w_scnt.p;
-        pa.surv_id = (uint16_t*)dec->w_sid.p;
-        pa.surv_lp = (double*)dec->w_slp.p;
-        pa.overflow = (uint32_t*)dec->w_flags.p + 4 * c;
-        pa.pass = 0;
-        pa.rows_aligned16 = rows16;
-        be::BeamArgs bc = ba;
-        bc.n_utts = u1 - u0;
-        bc.utt_row0 = (const int64_t*)dec->w_row0.p + u0;
-        bc.surv_cnt = (const uint32_t*)dec->w_scnt.p;
-        bc.surv_id = (const uint16_t*)dec->w_sid.p;
-        bc.surv_lp = (const double*)dec->w_slp.p;
-        bc.text_off = (const uint64_t*)dec->w_toff.p + u0;
-        bc.emit_off = (const uint64_t*)dec->w_eoff.p + u0;
-        bc.start_states = d_start ? d_start + (size_t)u0 * K : nullptr;
-        bc.out_xstates = ba.out_xstates ? ba.out_xstates + (size_t)u0 * n_best * (size_t)(K - 1) : nullptr;
-        bc.out = ba.out + (size_t)u0 * n_best;
-        bc.n_out = ba.n_out + u0;
-        bc.status = ba.status + u0;
-        bc.tok_pool = ba.tok_pool + tok_base[(size_t)c];
-        bc.tok_pool_head = (unsigned long long*)dec->w_head.p + 2 * c;
-        bc.tok_pool_cap = tok_base[(size_t)c + 1] - tok_base[(size_t)c];
-        bc.prof = nullptr;
-        bc.cold = ba.cold + (size_t)u0 * 2 * COLD_STRIDE;
-        be::use_stream(0);
-        enq_ok = !be::ev_record(4 * c + 1, &err) && !be::launch_prune(pa, &err) && !be::ev_record(4 * c + 2, &err);
-        be::use_stream(1);
-        enq_ok = enq_ok && !be::ev_wait(4 * c + 2, &err) && !be::ev_record(4 * c + 3, &err) && !be::launch_beam(bc, &err) &&
-                 !be::ev_record(4 * c + 4, &err);
-      }
-      be::use_stream(0);
-      if (!enq_ok) {
-        std::string e2;
-        be::sync_all(&e2);
-        return fail(CTCDEC_ERR_DEVICE, err);
-      }
-      res->beam_kernel = be::last_beam_kernel();
-      // collect chunk by chunk while the later ones still run
-      if (dec->h_tok.ensure(max_chunk_tok * sizeof(EmitNode) + 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-      uint32_t* n_out = (uint32_t*)dec->h_small.p;
-      uint32_t* status = n_out + n_utts;
-      uint32_t* h_flags = status + n_utts;                                   // [n_chunks][4]
-      unsigned long long* h_heads = (unsigned long long*)(h_flags + 4 * n_chunks);  // [n_chunks][2]
-      const OutBeam* obs = (const OutBeam*)dec->h_out.p;
-      const LmState* xst = nullptr;
-      if (xstate_bytes) {
-        if (dec->h_xstate.ensure(xstate_bytes, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-        xst = (const LmState*)dec->h_xstate.p;
-      }
-      bool fall_back = false;
-      std::string fail_msg;
-      int fail_code = 0;
-      double prune_sum = 0.0, beam_sum = 0.0;
-      for (int32_t c = 0; c < n_chunks && !fall_back && !fail_code; ++c) {
-        const int32_t u0 = c * chunk, u1 = std::min(n_utts, u0 + chunk);
-        be::use_stream(2);
-        bool ok = !be::ev_wait(4 * c + 4, &err) &&
-                  !be::d2h_async(h_flags + 4 * c, (const uint32_t*)dec->w_flags.p + 4 * c, 8, &err) &&
-                  !be::d2h_async(h_heads + 2 * c, (const unsigned long long*)dec->w_head.p + 2 * c, 8, &err) &&
-                  !be::d2h_async(n_out + u0, (const uint32_t*)dec->w_nout.p + u0, (size_t)(u1 - u0) * 4, &err) &&
-                  !be::d2h_async(status + u0, (const uint32_t*)dec->w_status.p + u0, (size_t)(u1 - u0) * 4, &err) &&
-                  !be::d2h_async((OutBeam*)dec->h_out.p + (size_t)u0 * n_best, (const OutBeam*)dec->w_out.p + (size_t)u0 * n_best,
-                                 (size_t)(u1 - u0) * n_best * sizeof(OutBeam), &err) &&
-                  !be::sync(&err);
-        if (ok && xstate_bytes) {
-          const size_t per = (size_t)n_best * (size_t)(K - 1) * sizeof(LmState);
-          ok = !be::d2h((char*)dec->h_xstate.p + (size_t)u0 * per, (const char*)dec->w_xstate.p + (size_t)u0 * per, (size_t)(u1 - u0) * per, &err);
-        }
-        if (!ok) {
-          fail_code = CTCDEC_ERR_DEVICE;
-          fail_msg = err;
-          break;
-        }
-        if (h_flags[4 * c] || h_flags[4 * c + 1]) {
-          fall_back = true;
-          break;
-        }
-        const unsigned long long head = h_heads[2 * c];
-        for (int32_t u = u0; u < u1 && !fail_code; ++u) {
-          if (status[u] & ST_NO_BEAMS) {  // the reference: ValueError from max([]) (decoder.py:545 / :585)
-            fail_code = CTCDEC_ERR_ARG;
-            fail_msg = "max() arg is an empty sequence (utterance " + std::to_string(u) +
-                       ": no beam survived -- non-finite scores or a positive beam_prune_logp)";
-          } else if (status[u]) {
-            fail_code = CTCDEC_ERR_INTERNAL;
-            fail_msg = "beam kernel status " + std::to_string(status[u]) + " for utterance " + std::to_string(u);
-          }
-        }
-        if (fail_code) break;
-        if (head && be::d2h(dec->h_tok.p, (const EmitNode*)dec->w_tok.p + tok_base[(size_t)c], (size_t)head * sizeof(EmitNode), &err)) {
-          fail_code = CTCDEC_ERR_DEVICE;
-          fail_msg = err;
-          break;
-        }
-        const EmitNode* toks = (const EmitNode*)dec->h_tok.p;
-        for (int32_t u = u0; u < u1 && !fail_code; ++u)
-          for (uint32_t k = 0; k < n_out[u]; ++k) {
-            const OutBeam& ob = obs[(size_t)u * n_best + k];
-            if ((unsigned long long)ob.tok_off + ob.tok_cnt > head) {
-              fail_code = CTCDEC_ERR_INTERNAL;
-              fail_msg = "token pool range";
-              break;
-            }
-          }
-        if (fail_code) break;
-        auto replay_chunk = [&](int32_t a0, int32_t a1) {
-          for (int32_t u = u0 + a0; u < u0 + a1; ++u) {
-            auto& beams = res->utts[(size_t)u];
-            beams.resize(n_out[u]);
-            for (uint32_t k = 0; k < n_out[u]; ++k) {
-              const OutBeam& ob = obs[(size_t)u * n_best + k];
-              BeamResult& r = beams[k];
-              fill_result(ob, xst ? &xst[((size_t)u * n_best + k) * (size_t)(K - 1)] : nullptr, K, &r);
-              replay(dec, toks + ob.tok_off, ob.tok_cnt, nullptr, 0, &r);
-            }
-          }
-        };
-        if (!dec->replay_pool) {
-          unsigned want = 15u;  // + the calling thread
-          if (const char* env = getenv("CTCDEC_REPLAY_THREADS")) want = (unsigned)std::max(0, atoi(env) - 1);
-          const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-          dec->replay_pool.reset(new ReplayPool((int)std::min(want, hw > 1 ? hw - 1 : 0u)));
-        }
-        const std::function<void(int32_t, int32_t)> job = replay_chunk;
-        dec->replay_pool->run(u1 - u0, 4, job);
-        prune_sum += be::ev_elapsed_ms(4 * c + 1, 4 * c + 2);
-        beam_sum += be::ev_elapsed_ms(4 * c + 3, 4 * c + 4);
-      }
-      be::use_stream(0);
-      if (fall_back || fail_code) {
-        std::string e2;
-        if (be::sync_all(&e2)) return fail(CTCDEC_ERR_DEVICE, e2);
-        if (fail_code) return fail(fail_code, fail_msg);
-        for (auto& b : res->utts) b.clear();
-      } else {
-        be::set_last_timing(prune_sum, beam_sum);
-        be::last_timing(&res->ms[0], &res->ms[1]);
-        res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-        pipelined_done = true;
-      }
-    }
-  }
-  if (pipelined_done) {
-    *out = res.release();
-    return CTCDEC_OK;
-  }
   if (dec->w_flags.ensure(16, &err) || dec->w_head.ensure(16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   for (int attempt = 0; attempt < 2; ++attempt) {
     size_t rows = (size_t)std::max<int64_t>(R, 1);
@@ -1104,13 +901,16 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       return be::launch_beam(ba, &err);
     };
     if (be::launch_prune(pa, &err) || run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
-    uint32_t flags[2] = {0, 0};
-    if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    if (flags[1]) {  // some utterance looks like probabilities (decoder.py:760): redo those rows, then the beams
+    uint32_t flags[4] = {0, 0, 0, 0};
+    if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    if (flags[2]) {  // rows that sum to about 1: the reference's test in its own dtype and summation order (decoder.py:760)
+      if (be::launch_sniff_exact(pa, &err) || be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    }
+    if (flags[1]) {  // some utterance holds probabilities: redo those rows as log(clip(p)), then the beams
       pa.pass = 1;
       if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
       if (be::launch_prune(pa, &err) || run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
-      if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
     const uint32_t ovf = flags[0];
     if (!ovf) break;
@@ -1247,8 +1047,9 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   pa.pass = 0;
   pa.rows_aligned16 = (((uintptr_t)ptrs[0]) & 15u) == 0 ? 1 : 0;
   if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-  uint32_t flags[2] = {0, 0};
-  if (be::d2h(flags, dec->w_flags.p, 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  uint32_t flags[4] = {0, 0, 0, 0};
+  if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  if (flags[2] && (be::launch_sniff_exact(pa, &err) || be::d2h(flags, dec->w_flags.p, 16, &err))) return fail(CTCDEC_ERR_DEVICE, err);
   if (flags[1]) {
     pa.pass = 1;
     if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);

@@ -19,6 +19,7 @@
 #include "beam_core.h"
 #include "beam_wave.h"
 #include "set_order.h"
+#include "np_sum.h"
 
 namespace ctc {
 namespace be {
@@ -264,6 +265,10 @@ __device__ __forceinline__ int find_utt(const int64_t* row0, int n_utts, int64_t
 
 constexpr int PRUNE_WAVES = 4;  // rows per 256-thread block
 
+// decoder.py:760 in two steps. The reference tests  math.isclose(logits.sum(axis=1).mean(), 1)  in the INPUT dtype, and for
+// float32 / float16 that is in effect "does numpy's mean round to exactly 1". The frame-prune pass leaves exact (fp64) row
+// sums; an utterance whose fp64 mean is nowhere near 1 is not a probability matrix in any summation order, everything
+// else is marked ambiguous (2) and settled by utt_sniff_exact in numpy's own order and precision (np_sum.h).
 __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
   const int u = blockIdx.x;
   const int lane = threadIdx.x;
@@ -273,9 +278,23 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
   s = wave_sum(s);
   if (lane == 0) {
     double mean = r1 > r0 ? s / (double)(r1 - r0) : NAN;
-    // math.isclose(mean, 1): |mean - 1| <= 1e-9 * max(|mean|, 1)   (decoder.py:760)
-    // (an infinite mean -- rows masked with -inf -- is never close: math.isclose(+-inf, 1) is False)
-    bool is_prob = isfinite(mean) && fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);
+    // (an infinite mean -- rows masked with -inf -- is never close: math.isclose(+-inf, 1) is False.) The window:
+    // float32 pairwise sums of rows of ordinary logits are off by < 1e-2; float64 ones by < 1e-12.
+    const bool amb = isfinite(mean) && fabs(mean - 1.0) <= (a.dtype == 1 ? 1e-6 : 0.5);
+    a.utt_is_prob[u] = amb ? 2u : 0u;
+    if (amb) a.overflow[2] = 1u;  // flags[2]: some utterance needs the exact test
+  }
+}
+// one workgroup per ambiguous utterance, one thread per row (rare path: probability inputs, or logits whose rows sum to ~1)
+__global__ __launch_bounds__(256) void utt_sniff_exact(PruneArgs a) {
+  const int u = blockIdx.x;
+  if (a.utt_is_prob[u] != 2u) return;
+  const int64_t r0 = a.utt_row0[u], T = a.utt_row0[u + 1] - r0;
+  const void* x = a.utt_logits[u];
+  for (int64_t t = threadIdx.x; t < T; t += blockDim.x) a.row_sum[r0 + t] = np_row_sum(x, a.dtype, t, a.n_labels);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool is_prob = T > 0 && np_mean_is_one(np_mean_of_sums(a.row_sum + r0, a.dtype, T));
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
     if (is_prob) a.overflow[1] = 1u;  // flags[1]: some utterance needs the probability pass
   }
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
   const int V = a.n_labels;
   const int u = find_utt(a.utt_row0, a.n_utts, row);
   const bool is_prob = a.pass == 1;
-  if (is_prob && !a.utt_is_prob[u]) return;
+  if (is_prob && a.utt_is_prob[u] != 1u) return;
   const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V;
   double mx = 0.0, lse = 0.0;
   if (!is_prob) {
@@ -648,7 +667,7 @@ __device__ __forceinline__ double log_ge1(double s) {
 // Register-resident frame-prune for fp32 rows with V % 4 == 0 and V <= 1024*... (NC chunks of 256
 // labels): each lane pulls its 4*NC logits with 16-byte loads ONCE (1 KiB per wave-instruction, fully
 // coalesced) and all three sweeps run out of registers: the logits cross HBM exactly once.
-// PK: the exponentials of the clean-row path as packed float32 polynomials (CTCDEC_PRUNE_EXP=pk; default: fp64)
+// PK: the exponentials of the clean-row path as packed float32 polynomials (the default; CTCDEC_PRUNE_EXP=f64: fp64)
 template <int NC, bool PK>
 __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs a, uint32_t cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -660,7 +679,7 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
   const int V = a.n_labels;
   const int u = find_utt(a.utt_row0, a.n_utts, row);
   const bool is_prob = a.pass == 1;
-  if (is_prob && !a.utt_is_prob[u]) return;
+  if (is_prob && a.utt_is_prob[u] != 1u) return;
   const float4* x4 = (const float4*)((const float*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V);
   const int n4 = V >> 2;
   float4 r[NC];
@@ -824,8 +843,8 @@ int launch_prune(const PruneArgs& a, std::string* err) {
   } while (0)
     if (vec4) {
       const int nc = (a.n_labels / 4 + 63) / 64;
-      const char* ex = getenv("CTCDEC_PRUNE_EXP");
-      if (ex && ex[0] == 'p') {
+      const char* ex = getenv("CTCDEC_PRUNE_EXP");  // "f64": the fp64 exponential of round 2 (diagnostics)
+      if (!(ex && ex[0] == 'f')) {
         if (nc <= 1) CTC_LAUNCH_PRUNE((frame_prune_f32x4<1, true>));
         else if (nc == 2) CTC_LAUNCH_PRUNE((frame_prune_f32x4<2, true>));
         else if (nc == 3) CTC_LAUNCH_PRUNE((frame_prune_f32x4<3, true>));
@@ -853,6 +872,14 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(g_ev[1], g_stream));
+  return 0;
+}
+
+int launch_sniff_exact(const PruneArgs& a, std::string* err) {
+  if (a.n_utts > 0) {
+    hipLaunchKernelGGL(utt_sniff_exact, dim3((unsigned)a.n_utts), dim3(256), 0, g_stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
 

@@ -451,10 +451,52 @@ CTC_UNROLL
     return (uint32_t)ctx.popc64(ctx.ballot(ok));
   }
 
+  // Drop the pool entries below the threshold (stable: the rest keep their order). The running maximum only rises
+  // during a frame, so entries pushed early are often dead by now; the ranking walk and the compaction are O(entries)
+  // per lane and this is O(1).
+  CTC_HD void filter_pool(double thr) {
+    const uint32_t n = pool_n;
+    const uint64_t thr_key = score_sort_key(thr);
+    u32x4 g0[PE], g1[PE], g2[PE];
+    uint32_t dst[PE];
+    bool ok[PE];
+    uint32_t kept = 0;
+CTC_UNROLL
+    for (int k = 0; k < PE; ++k) {
+      const uint32_t e = (uint32_t)(k * 64 + lane);
+      ok[k] = false;
+      dst[k] = 0;
+      g0[k] = g1[k] = g2[k] = mk4(0, 0, 0, 0);
+      if ((uint32_t)(k * 64) >= n) continue;
+      if (e < n) {
+        g0[k] = L.pool[e * 3];
+        g1[k] = L.pool[e * 3 + 1];
+        g2[k] = L.pool[e * 3 + 2];
+        ok[k] = q_lo(g0[k]) <= thr_key;
+      }
+      const uint64_t m = ctx.ballot(ok[k]);
+      dst[k] = kept + prefix_cnt(m);
+      kept += (uint32_t)ctx.popc64(m);
+    }
+    if (kept == n) return;  // (uniform)
+    ctx.wsync();
+CTC_UNROLL
+    for (int k = 0; k < PE; ++k) {
+      if (ok[k]) {
+        L.pool[dst[k] * 3] = g0[k];
+        L.pool[dst[k] * 3 + 1] = g1[k];
+        L.pool[dst[k] * 3 + 2] = g2[k];
+      }
+    }
+    pool_n = kept;
+    ctx.wsync();
+  }
+
   // Ranks the pool entries with score >= thr by (score desc, arrival asc); L.sel[r] = pool index of rank r
   // (bit 31: kept by the history prune) for r < min(count, beam_width). Returns the count.
   // (heapq.nlargest + _prune_history, decoder.py:165-167, 244-257)
   CTC_HD uint32_t rank_pool(double thr, bool with_hist) {
+    if (pool_n > 64u) filter_pool(thr);  // (heavy frames: usually back to one entry per lane)
     const uint32_t n = pool_n;
     const uint32_t want = (uint32_t)prm.beam_width;
     const uint64_t thr_key = score_sort_key(thr);
@@ -816,6 +858,7 @@ CTC_UNROLL
                          imax | (c.lid << 8) | (blank ? (1u << 29) : 0u) | (dbr << 30), q_wid, q_m2);
     bool push = rep && score >= thr && my_key > kth_key;
     uint32_t cnt = (uint32_t)ctx.popc64(ctx.ballot(push));
+    if (pool_n + cnt > (uint32_t)P) filter_pool(thr);  // room, the cheap way: entries the risen threshold has left behind
     if (pool_n + cnt > (uint32_t)P) {
       // The pool holds the best beam_width so far plus room for 32 more: make room (exact: pruning is monotone).
       compact_pool();

@@ -174,13 +174,22 @@ class _Batch:
             torch.cuda.current_stream(dev).synchronize()
         else:
             arrs = [x.detach().cpu().numpy() if _is_device_tensor(x) else np.asarray(x) for x in logits_list]
-            want32 = len(arrs) > 0 and all(a.dtype == np.float32 or a.dtype == np.float16 for a in arrs)
+            # float32 / float16 matrices go over in their own dtype: the reference decides "probabilities or logits?" on
+            # the input dtype (decoder.py:760), and so does the library. Everything else (float64, integers, mixed
+            # batches) is widened to float64 first.
+            kinds = {a.dtype for a in arrs}
+            target, self.dtype = np.float64, 1
+            if kinds == {np.dtype(np.float32)}:
+                target, self.dtype = np.float32, 0
+            elif kinds == {np.dtype(np.float16)}:
+                target, self.dtype = np.float16, 2
+            elif kinds and kinds <= {np.dtype(np.float32), np.dtype(np.float16)}:
+                target, self.dtype = np.float32, 0
             for a in arrs:
-                a = np.ascontiguousarray(a, dtype=np.float32 if want32 else np.float64)
+                a = np.ascontiguousarray(a, dtype=target)
                 keep.append(a)
                 ptrs.append(a.ctypes.data if a.size else 0)
                 frames.append(int(a.shape[0]))
-            self.dtype = 0 if want32 else 1
 
 
     def _from_3d(self, batch: Any, n_labels: int) -> bool:
@@ -205,10 +214,10 @@ class _Batch:
             self.dtype = native[batch.dtype]
             self.is_device = True
         elif isinstance(batch, np.ndarray):
-            want32 = batch.dtype in (np.float32, np.float16)
-            t = np.ascontiguousarray(batch, dtype=np.float32 if want32 else np.float64)
+            target, self.dtype = {np.dtype(np.float32): (np.float32, 0), np.dtype(np.float16): (np.float16, 2)}.get(
+                batch.dtype, (np.float64, 1))
+            t = np.ascontiguousarray(batch, dtype=target)
             base, step = t.ctypes.data, t.strides[0]
-            self.dtype = 0 if want32 else 1
         else:
             return False
         n, frames = int(t.shape[0]), int(t.shape[1])

@@ -20,3 +20,27 @@ def both_beam_kernels(request, monkeypatch):
     library picks by batch size, and small test batches would only ever see the workgroup kernel."""
     monkeypatch.setenv("CTCDEC_BEAM_KERNEL", request.param)
     return request.param
+
+
+@pytest.fixture(params=["pk", "f64"])
+def both_prune_exps(request, monkeypatch):
+    """Float32 rows with V % 4 == 0 go through the register-resident frame-prune kernel, whose exponentials are packed
+    float32 polynomials by default (the precision the reference itself works at for float32 input) and the round-2 fp64
+    routine under CTCDEC_PRUNE_EXP=f64. The differential tests run under both: `f64` is exact against the oracle
+    (1e-9), the default within the float32 bound (tests/test_gpu_parity._tol)."""
+    if request.param == "f64":
+        monkeypatch.setenv("CTCDEC_PRUNE_EXP", "f64")
+    else:
+        monkeypatch.delenv("CTCDEC_PRUNE_EXP", raising=False)
+    return request.param
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How tight the parity comparisons of this session actually were (tests/golden_util.check_beams)."""
+    from tests.golden_util import STATS
+
+    if STATS["beam_lists"]:
+        terminalreporter.write_line(
+            "parity: %d beam lists / %d beams compared; largest |score - reference| = %.3g (%s); near-tie window used for "
+            "%d runs (%d beams)" % (STATS["beam_lists"], STATS["beams"], STATS["max_gap"], STATS["max_gap_what"],
+                                    STATS["tie_runs"], STATS["tie_run_beams"]))

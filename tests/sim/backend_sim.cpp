@@ -15,6 +15,7 @@
 #include "../../pyctcdecode_amd/csrc/beam_wave.h"
 #include "wave_fibers.h"
 #include "../../pyctcdecode_amd/csrc/set_order.h"
+#include "../../pyctcdecode_amd/csrc/np_sum.h"
 
 namespace ctc {
 namespace be {
@@ -95,15 +96,10 @@ int launch_prune(const PruneArgs& a, std::string*) {
   for (int u = 0; u < a.n_utts; ++u) {
     const void* x = a.utt_logits[u];
     int64_t r0 = a.utt_row0[u], T = a.utt_row0[u + 1] - r0;
-    double tot = 0.0;
-    for (int64_t t = 0; t < T; ++t) {
-      double s = 0.0;
-      for (int v = 0; v < V; ++v) s += load(x, a.dtype, (size_t)t * V + v);
-      a.row_sum[r0 + t] = s;
-      tot += s;
-    }
-    double mean = T > 0 ? tot / (double)T : NAN;
-    bool is_prob = std::isfinite(mean) && fabs(mean - 1.0) <= 1e-9 * fmax(fabs(mean), 1.0);  // math.isclose(mean, 1)
+    // decoder.py:760 on the input dtype, in numpy's summation order (np_sum.h)
+    for (int64_t t = 0; t < T; ++t) a.row_sum[r0 + t] = np_row_sum(x, a.dtype, t, V);
+    const double mean = T > 0 ? np_mean_of_sums(a.row_sum + r0, a.dtype, T) : NAN;
+    bool is_prob = np_mean_is_one(mean);
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
     for (int64_t t = 0; t < T; ++t) {
       if (is_prob) {
@@ -145,6 +141,8 @@ int launch_prune(const PruneArgs& a, std::string*) {
   }
   return 0;
 }
+
+int launch_sniff_exact(const PruneArgs&, std::string*) { return 0; }  // (pass 0 of the sequential reference is exact)
 
 static void fill_io(const BeamArgs& a, int u, UttIO& io) {
   int64_t r0 = a.utt_row0[u];

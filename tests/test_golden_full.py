@@ -4,11 +4,13 @@ LM, hot words -- fed as float64 and as float32, and for one BASELINE config-2 ut
 their seeds. tests/golden/cases_peaky.json (oracle/make_golden_peaky.py) adds real-posterior-like utterances of the
 same vocabulary / LM -- the inputs on which the kernels consume runs of single-label frames in place.
 
-* float64 inputs: order / frames exact, scores within 1e-6 (oracle: 1e-9).
+All bounds are ABSOLUTE (scores are around -2000 here):
+* float64 inputs: order / frames exact, |score - reference| <= 1e-9 (measured 4.6e-13 on the device), near-tie window 1e-9.
 * float32 inputs: the reference runs _log_softmax in the INPUT dtype (decoder.py:180-197); the device upcasts
   exactly and works in fp64, so its scores are the more accurate ones and differ from the reference's by the
-  reference's own fp32 rounding (measured 2.3e-6 over T=1000). Bound of the north star: 1e-4,
-  order and frames exact outside runs of scores closer than the gap.
+  reference's own fp32 rounding (measured 1.8e-5 over T=1000, DESIGN.md section 6). Bound of the north star: 1e-4;
+  order exact wherever the reference's scores are further apart than 4e-5 = twice that error (every committed float32
+  case: the smallest gap between neighbouring beams is 5e-4).
 """
 import json
 import os
@@ -53,7 +55,7 @@ def _check(case, got, tol):
     """got: [(text, frames, logit, lm)] of ALL returned beams."""
     assert len(got) == case["n_beams"], "%s: %d beams, the reference returned %d" % (case["name"], len(got), case["n_beams"])
     exp = case["expected"]
-    tie = 1e-9 if case["dtype"] == "float64" else 2e-5
+    tie = 1e-9 if case["dtype"] == "float64" else 4e-5
     texts_only = [(g[0], [], g[2], g[3]) for g in got[: len(exp)]]
     check_beams(texts_only, [dict(e, frames=[]) for e in exp], tol=tol, what=case["name"], tie_tol=tie)
     for g, e in zip(got, exp):
@@ -103,6 +105,6 @@ def test_hip_equals_the_reference_at_full_size(case, assets, both_beam_kernels):
     xt = torch.from_numpy(x).cuda()  # the device tensor in its own dtype: fp32 logits are read in place
     out = dec.decode_beams(xt, **kw)
     got = [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in out]
-    _check(case, got, 1e-6 if case["dtype"] == "float64" else 1e-4)
+    _check(case, got, 1e-9 if case["dtype"] == "float64" else 1e-4)
     gap = max(abs(g[3] - e["lm"]) for g, e in zip(got, case["expected"]) if g[0] == e["text"])
     print("%s [%s]: max |lm_score - reference| = %.3g" % (case["name"], both_beam_kernels, gap))

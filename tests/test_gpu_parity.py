@@ -1,17 +1,30 @@
 """GPU (-m gpu): the HIP path through the C ABI against (a) the reference's golden vectors,
 (b) the oracle on seeded inputs at sizes it finishes in seconds, (c) size-independent properties
-at BASELINE sizes.  Tolerance: order and frames exact (near-ties: see golden_util.check_beams),
-scores within 1e-6 absolute-relative (north-star bound: 1e-4)."""
+at BASELINE sizes.  Tolerance (ABSOLUTE, see _tol): order and frames exact (near-ties: see golden_util.check_beams),
+scores within 1e-9 wherever the device computes in fp64, within the north star's 1e-4 (measured ~1e-6) where it uses the
+float32 exponential the reference itself works at."""
+import os
+
 import numpy as np
 import pytest
 
 import synth
 from tests.golden_util import LM_DIR, check_beams, lm_path, load_cases
 
-pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_beam_kernels")]
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("both_beam_kernels", "both_prune_exps")]
 
 CASES, INPUTS = load_cases()
-TOL = 1e-6
+TOL = 1e-9  # absolute (tests/golden_util.check_beams); the device's fp64 scores differ from the oracle's by < 1e-12
+
+
+def _tol(x):
+    """Bounds for a decode of logits `x` against the oracle run on their exact float64 upcast: float32 rows of a
+    multiple of four labels (<= 1024) take the packed float32 exponential unless CTCDEC_PRUNE_EXP=f64 -- 1e-4 absolute,
+    order exact outside runs closer than 4e-5 (the north star's float32 bound); everything else is fp64: 1e-9."""
+    dt = str(getattr(x, "dtype", "")).replace("torch.", "")
+    V = int(x.shape[-1])
+    f32_path = dt == "float32" and V % 4 == 0 and V <= 1024 and os.environ.get("CTCDEC_PRUNE_EXP", "pk")[0] != "f"
+    return {"tol": 1e-4, "tie_tol": 4e-5} if f32_path else {"tol": TOL, "tie_tol": 1e-9}
 
 
 def _loaded_native():
@@ -64,7 +77,7 @@ def test_hip_vs_oracle_flat_char_beam100(lm):
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], prune_history=True)
     for u, x in enumerate(xs):
         exp = _oracle_expected(orc, x.astype(np.float64), {"prune_history": True})
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL, what="flat%d" % u)
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="flat%d" % u, **_tol(x))
 
 
 def test_hip_vs_oracle_bpe1024_lm_hotwords(lm, bpe):
@@ -83,7 +96,7 @@ def test_hip_vs_oracle_bpe1024_lm_hotwords(lm, bpe):
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], hotwords=hot, prune_history=True)
     for u, x in enumerate(xs):
         exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL, what="bpe%d" % u)
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="bpe%d" % u, **_tol(x))
     texts = dec.decode_batch(None, xs, hotwords=hot)
     assert texts == [g[0].text for g in got]
 
@@ -104,7 +117,7 @@ def test_hip_ragged_batch_and_edge_cases(lm):
     for bw in (1, 200):
         got = dec.decode_beams(xs[4], beam_width=bw)
         exp = _oracle_expected(orc, xs[4].astype(np.float64), {"beam_width": bw})
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="bw%d" % bw)
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="bw%d" % bw, **_tol(xs[4]))
     with pytest.raises(NotImplementedError):
         dec.decode_beams(xs[4], beam_width=300)
     with pytest.raises(ValueError):
@@ -157,7 +170,7 @@ def test_hip_oracle_one_full_length_utterance(lm, bpe):
     x = synth.d_words(4, 11, 1000, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0)
     got = dec.decode_beams(x, hotwords=hot, prune_history=True)
     exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
-    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="full")
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="full", **_tol(x))
 
 
 def test_hip_config2_full_size_char_nolm_stress():
@@ -192,7 +205,7 @@ def test_hip_config2_full_size_char_nolm_stress():
     x = synth.d_flat(2, 999, 120, 29)
     exp = _oracle_expected(orc, x.astype(np.float64), {})
     got = dec.decode_beams(x)
-    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="cfg2")
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="cfg2", **_tol(x))
 
 
 def test_hip_config3_hf_vocab_lm_full_length():
@@ -213,7 +226,7 @@ def test_hip_config3_hf_vocab_lm_full_length():
     assert got == [orc.decode(x.astype(np.float64)) for x in xs]
     beams = dec.decode_beams(xs[1])
     exp = _oracle_expected(orc, xs[1].astype(np.float64), {})
-    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in beams], exp, tol=TOL, what="cfg3")
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in beams], exp, what="cfg3", **_tol(xs[1]))
 
 
 def test_hip_streaming_matches_reference_scenarios():
@@ -277,7 +290,7 @@ def test_hip_config5_streaming_64_streams(lm, bpe):
                                            beam_width=200, is_end=(k == n_chunks - 1))
         assert [b.text for b in beams[u]] == [e.text for e in exp]
         assert [[tuple(f) for f in b.text_frames] for b in beams[u]] == [[tuple(f) for f in e.tframes] for e in exp]
-        assert all(abs(b.lm_score - e.lm) < TOL * max(1.0, abs(e.lm)) for b, e in zip(beams[u], exp))
+        assert all(abs(b.lm_score - e.lm) < _tol(xs[u])["tol"] for b, e in zip(beams[u], exp))
 
 
 def test_hip_half_precision_logits_in_place(lm, bpe):
@@ -294,11 +307,13 @@ def test_hip_half_precision_logits_in_place(lm, bpe):
         a = dec.decode_beams(xh, prune_history=True)
         b = dec.decode_beams(xh.to(torch.float32), prune_history=True)
         # (same beams; the half types go through the generic kernel and float32 through the register-resident one: the
-        # two sum the row in different orders and use polynomials of different degree, so scores agree to ~1e-11, not bitwise)
+        # two sum the row in different orders and use different exponentials -- fp64 polynomials of different degree
+        # under CTCDEC_PRUNE_EXP=f64, ~1e-11; the packed float32 one by default, ~1e-6 over 300 frames)
         assert [(o.text, o.text_frames) for o in a] == [(o.text, o.text_frames) for o in b]
+        bound = _tol(xh.to(torch.float32))["tol"]
         for o, q in zip(a, b):
-            assert abs(o.logit_score - q.logit_score) <= TOL * max(1.0, abs(q.logit_score))
-            assert abs(o.lm_score - q.lm_score) <= TOL * max(1.0, abs(q.lm_score))
+            assert abs(o.logit_score - q.logit_score) <= bound
+            assert abs(o.lm_score - q.lm_score) <= bound
 
 
 def test_hip_probability_rows_overflowing_the_survivor_bound():
@@ -350,8 +365,7 @@ def test_hip_multi_lm_vs_oracle_batch(lm, bpe):
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], prune_history=True, hotwords=hot)
     for u, x in enumerate(xs):
         exp = _oracle_expected(orc, x.astype(np.float64), {"prune_history": True, "hotwords": hot})
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL,
-                    what="multi%d" % u)
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="multi%d" % u, **_tol(x))
     texts = dec.decode_batch(None, torch.from_numpy(np.stack(xs)).cuda(), hotwords=hot)
     assert texts == [g[0].text for g in got]
 
@@ -381,7 +395,7 @@ def test_hip_non_finite_logits_follow_the_reference():
     with np.errstate(all="ignore"):
         exp = _oracle_expected(orc, masked.astype(np.float64), {"beam_width": 20})
     got = dec.decode_beams(torch.from_numpy(masked).cuda(), beam_width=20)
-    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, tol=TOL, what="masked")
+    check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="masked", **_tol(masked))
     big = rng.standard_normal((30, 1024)).astype(np.float32)  # the register-resident prune kernel
     dec_big = build_ctcdecoder([chr(0x4E00 + i) for i in range(1023)])
     for poison in ("row", "nan", "pinf", "last"):
@@ -421,7 +435,7 @@ def test_hip_frame_survivors_in_cpython_set_order():
                                (76, 0.05, -8.0, np.float32), (300, 0.05, -8.0, np.float32)]:
         dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
         x = (rng.standard_normal((300, V)) * scale).astype(dt)
-        border += check_against_cpython(dec, x, tmin, TOL)
+        border += check_against_cpython(dec, x, tmin, _tol(x)["tol"])
         frames += 300
     assert border < frames // 20
 
@@ -431,7 +445,7 @@ def test_hip_random_differential_slice():
     from tools import fuzz_sim_vs_oracle as fuzz
 
     _loaded_native()
-    stats = fuzz.run_many(60, 20260926, tol=TOL)
+    stats = fuzz.run_many(60, 20260926, tol=TOL, tol_f32=None if os.environ.get("CTCDEC_PRUNE_EXP") == "f64" else 1e-4)
     assert sum(stats.values()) == 60 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 57, stats
 
 
@@ -476,31 +490,6 @@ def test_hip_permuted_and_mixed_dtype_device_batches(lm):
     assert dec.decode_batch(None, mixed) == want
 
 
-def test_hip_chunked_pipeline_equals_the_sequential_path(lm, monkeypatch):
-    """CTCDEC_PIPELINE=1, more than 2 x 1024 utterances: chunks whose frame-prune / beam / copy-back stages overlap on three streams
-    (api.cpp). Same texts and beams as the sequential path; a probability-like utterance makes the optimistic
-    pipeline fall back."""
-    import torch
-
-    from pyctcdecode_amd import build_ctcdecoder
-
-    dec = build_ctcdecoder(synth.LIBRI_LABELS, lm.path)
-    base = [synth.d_words(2, u, 14 + (7 * u) % 19, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=6.0) for u in range(64)]
-    xs = [torch.from_numpy(base[u % 64]).cuda() for u in range(2500)]
-    monkeypatch.setenv("CTCDEC_PIPELINE", "1")  # opt-in (measured slower than the sequential path, see api.cpp)
-    piped = dec.decode_batch(None, xs)
-    monkeypatch.delenv("CTCDEC_PIPELINE")
-    plain = dec.decode_batch(None, xs)
-    monkeypatch.setenv("CTCDEC_PIPELINE", "1")
-    assert piped == plain and piped[:64] == piped[64:128]
-    e = np.exp(base[5].astype(np.float64))
-    ys = list(xs)
-    ys[2400] = torch.from_numpy((e / e.sum(axis=1, keepdims=True)).astype(np.float32)).cuda()
-    got = dec.decode_batch(None, ys)
-    assert got[:2400] == piped[:2400] and got[2401:] == piped[2401:]
-    assert got[2400] == dec.decode(ys[2400])
-
-
 def test_hip_peaky_posteriors_single_label_runs(lm, bpe, monkeypatch):
     """Real-posterior-like logits (synth.d_peaky: most frames have one survivor, the label every beam ends in): both
     kernels consume such frames in runs (label_run). Same beams as the oracle; identical output with the runs
@@ -525,7 +514,7 @@ def test_hip_peaky_posteriors_single_label_runs(lm, bpe, monkeypatch):
         got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], **kw)
         for u, x in enumerate(xs):
             exp = _oracle_expected(orc, x.astype(np.float64), kw)
-            check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, tol=TOL, what="peaky%d" % u)
+            check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="peaky%d" % u, **_tol(x))
         monkeypatch.setenv("CTCDEC_NO_LABEL_RUNS", "1")
         plain = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], **kw)
         monkeypatch.delenv("CTCDEC_NO_LABEL_RUNS")

@@ -284,36 +284,6 @@ def test_kernel_selection_is_reported(sim_library, monkeypatch):  # noqa: F811
     assert dec.last_beam_kernel == 2
 
 
-def test_large_batches_go_through_the_chunked_pipeline(sim_library, monkeypatch):  # noqa: F811
-    """With CTCDEC_PIPELINE=1 batches of more than 4 x (compute units) utterances are cut into chunks whose stages overlap (api.cpp); the sim
-    backend reports 4 compute units, so 40 utterances make three chunks. Same results as the sequential path, also
-    when a chunk holds probability rows (the optimistic pipeline then falls back to the sequential path)."""
-    from pyctcdecode_amd import build_ctcdecoder
-
-    dec = build_ctcdecoder(synth.LIBRI_LABELS, LM.path)
-    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
-    orc = build_oracle(alpha.labels, alpha.is_bpe, LM.path, None)
-    xs = [synth.d_words(2, u, 12 + (5 * u) % 23, synth.LIBRI_LABELS, False, LM.words, LM.sentences, 28, boost=6.0) for u in range(40)]
-    monkeypatch.setenv("CTCDEC_PIPELINE", "1")  # opt-in (measured slower than the sequential path on MI355X)
-    piped = dec.decode_batch(None, xs)
-    beams = dec.decode_beams_batch(None, xs, beam_width=30)
-    monkeypatch.delenv("CTCDEC_PIPELINE")
-    assert dec.decode_batch(None, xs) == piped
-    plain = dec.decode_beams_batch(None, xs, beam_width=30)
-    assert [[(b.text, b.text_frames, b.logit_score, b.lm_score) for b in bb] for bb in beams] == \
-           [[(b.text, b.text_frames, b.logit_score, b.lm_score) for b in bb] for bb in plain]
-    monkeypatch.setenv("CTCDEC_PIPELINE", "1")
-    for u in (0, 17, 39):
-        assert piped[u] == orc.decode(xs[u].astype(np.float64))
-    # probabilities in one utterance of the last chunk: the pipeline has to fall back
-    e = np.exp(xs[37].astype(np.float64))
-    ys = list(xs)
-    ys[37] = (e / e.sum(axis=1, keepdims=True))
-    ys = [y.astype(np.float64) for y in ys]
-    got = dec.decode_batch(None, ys)
-    assert got[37] == orc.decode(ys[37]) and got[5] == piped[5]
-
-
 @pytest.mark.parametrize("seed", range(6))
 def test_peaky_posteriors_take_the_single_label_runs(seed, sim_library, monkeypatch):  # noqa: F811
     """Real-posterior-like input (most frames: one survivor, the label every beam already ends in): the wave

@@ -20,7 +20,9 @@ from tests.golden_util import LM_DIR, TOY_ARPA, check_beams  # noqa: E402
 from tests.sim.build_sim import build  # noqa: E402
 
 HIP = os.environ.get("FUZZ_BACKEND") == "hip"  # the product library on a GPU box instead of the sequential sim
-TOL = 1e-6 if HIP else 1e-9
+TOL = 1e-9  # absolute (tests/golden_util.check_beams), sim and HIP alike
+TOL_F32 = 1e-4 if (HIP and os.environ.get("CTCDEC_PRUNE_EXP") != "f64") else None  # float32 rows, V % 4 == 0, HIP build: the packed
+# float32 exponential of frame_prune (the reference's own precision for float32 input); None: fp64 like everything else
 
 
 def use_backend():
@@ -143,7 +145,7 @@ def run_case(rng, execute=True):
     x64 = x.astype(np.float64)
     with np.errstate(all="ignore"):
         try:
-            exp = orc.decode_beams(x64, **dkw)
+            exp = orc.decode_beams(x64, sniff_on=x, **dkw)
             err = None
         except ValueError as e:
             exp, err = None, e
@@ -154,9 +156,11 @@ def run_case(rng, execute=True):
         return "both raise"
     assert err is None, "oracle raised %r, product did not" % (err,)
     tol = TOL
+    f32_path = TOL_F32 is not None and x.dtype == np.float32 and x.shape[1] % 4 == 0 and x.shape[1] <= 1024
+    tkw = {"tol": TOL_F32, "tie_tol": 4e-5} if f32_path else {"tol": TOL, "tie_tol": 1e-9}
     expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
     try:
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], expd, tol=tol, what="whole")
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], expd, what="whole", **tkw)
     except AssertionError:
         # A near-tie (scores equal to ~1 ulp: quantised fp16 / integer logits) that straddles a cut -- beam width,
         # score threshold, history prune -- is decided by the last bit of exp/log and legitimately differs between
@@ -166,14 +170,15 @@ def run_case(rng, execute=True):
         em = {e["text"]: e["lm"] for e in expd}
         only_g = [v for t, v in gm.items() if t not in em]
         only_e = [v for t, v in em.items() if t not in gm]
-        common_ok = all(abs(gm[t] - em[t]) <= 1e-9 * max(1.0, abs(em[t])) for t in gm if t in em)
-        twins = lambda a, b: all(any(abs(v - w) <= 1e-9 * max(1.0, abs(w)) for w in b) for v in a)  # noqa: E731
+        win = tkw["tie_tol"]
+        common_ok = all(abs(gm[t] - em[t]) <= max(win, tkw["tol"]) for t in gm if t in em)
+        twins = lambda a, b: all(any(abs(v - w) <= win for w in b) for v in a)  # noqa: E731
         if common_ok and only_g and only_e and twins(only_g, list(em.values())) and twins(only_e, list(gm.values())):
             return "near-tie at a cut"
         # ... or sits EXACTLY on the score threshold (quantised logits make score differences exact multiples of the
         # quantum, e.g. best - 3.0 with beam_prune_logp = -3.0): `>=` holds on one side and fails by one ulp on the other
         thr = max(list(gm.values()) + list(em.values())) + dkw["beam_prune_logp"]
-        on_thr = lambda a: all(abs(v - thr) <= 1e-9 * max(1.0, abs(thr)) for v in a)  # noqa: E731
+        on_thr = lambda a: all(abs(v - thr) <= win for v in a)  # noqa: E731
         if common_ok and (only_g or only_e) and on_thr(only_g) and on_thr(only_e):
             return "near-tie at a cut"
         raise
@@ -195,14 +200,14 @@ def run_case(rng, execute=True):
         h = x.shape[0] // 2
         first = dec.decode_beams(x[:h], **dkw)
         with np.errstate(all="ignore"):
-            ofirst = orc.decode_beams(x64[:h], **dkw)
+            ofirst = orc.decode_beams(x64[:h], sniff_on=x[:h], **dkw)
         if first and ofirst and first[0].text == ofirst[0][0]:
             second = dec.decode_beams(x[h:], lm_start_state=first[0].last_lm_state, **dkw)
             with np.errstate(all="ignore"):
-                osecond = orc.decode_beams(x64[h:], lm_start_state=ofirst[0][1], **dkw)
+                osecond = orc.decode_beams(x64[h:], lm_start_state=ofirst[0][1], sniff_on=x[h:], **dkw)
             expd2 = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in osecond]
             try:
-                check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in second], expd2, tol=TOL, what="stateful")
+                check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in second], expd2, what="stateful", **tkw)
             except AssertionError:
                 if x.dtype == np.float16:  # quantised logits: near-ties at cuts (see above)
                     return "near-tie at a cut"
@@ -221,13 +226,13 @@ def run_case(rng, execute=True):
             # chunked vs chunked: the BPE force_next_break flag is local to a call (decoder.py:442), so a chunk
             # boundary may legitimately change the result -- the oracle is cut at the same places
             with np.errstate(all="ignore"):
-                ob = orc.partial_decode_beams(x64[a:b], st, a, is_end=(b == T), **okw)
+                ob = orc.partial_decode_beams(x64[a:b], st, a, is_end=(b == T), sniff_on=x[a:b], **okw)
             gotc = [(bm.text + "|" + bm.partial_word, [(str(k), f) for k, f in enumerate(bm.text_frames)] + [("p", bm.partial_frames)],
                      bm.logit_score, bm.lm_score) for bm in beams]
             expc = [{"text": o.text + "|" + o.partial, "frames": [[str(k), int(f[0]), int(f[1])] for k, f in enumerate(o.tframes)]
                      + [["p", int(o.pframes[0]), int(o.pframes[1])]], "logit": o.logit, "lm": o.lm} for o in ob]
             try:
-                check_beams(gotc, expc, tol=TOL, what="chunk %d:%d" % (a, b))
+                check_beams(gotc, expc, what="chunk %d:%d" % (a, b), **tkw)
             except AssertionError:
                 if x.dtype == np.float16:  # quantised logits: near-ties at the beam-width cut (see above)
                     return "near-tie at a cut"
@@ -236,11 +241,13 @@ def run_case(rng, execute=True):
     return "ok"
 
 
-def run_many(n, seed, tol=None):
-    """n random cases from `seed` against whatever library pyctcdecode_amd currently uses; returns the outcome counts."""
-    global TOL
+def run_many(n, seed, tol=None, tol_f32=None):
+    """n random cases from `seed` against whatever library pyctcdecode_amd currently uses; returns the outcome counts.
+    tol_f32: bound for float32 inputs of a multiple of four labels on the HIP build (its packed float32 exponential)."""
+    global TOL, TOL_F32
     if tol is not None:
         TOL = tol
+    TOL_F32 = tol_f32
     rng = np.random.default_rng(seed)
     stats = {}
     for _ in range(n):
