@@ -181,6 +181,35 @@ int ctcdec_decode_stream_batch(ctcdec_decoder* dec, const void* const* utt_logit
                                const char* text_blob, int32_t force_next_word, int32_t is_end,
                                ctcdec_result** out);
 
+/* ---- device-resident streams ---------------------------------------------------------------------
+ * The same recursion as ctcdec_decode_stream_batch (get_starting_state / partial_decode_beams,
+ * decoder.py:669-728), but what the reference's caller carries between chunks -- the live beams, their LM states and
+ * memo values, the words and frames decoded so far -- stays on the device: a chunk costs two kernel launches and a
+ * 16-byte read-back per stream, and beams are only materialised when somebody asks for them.
+ *   open   n independent streams, each at the reference's starting state (start_states: n * max(1, n_lms) LM
+ *          states or NULL for the models' own defaults)
+ *   push   one chunk per stream (chunk_frames[u] may be 0). first_frame: processed_frames per stream, NULL = the frames
+ *          pushed so far. want_result != 0 (always the case for is_end): *out receives the ranked beams exactly as
+ *          ctcdec_decode_stream_batch would return them -- texts / word frames from the START of the stream, src_beam = -1
+ *          (or, below a ctcdec_stream_import, relative to the imported beam src_beam). After is_end the streams are back
+ *          at the starting state.
+ *   read   the current beams without advancing (a push of zero frames)
+ *   import replace the carried beams of every stream by beams the caller built or edited (the slow path: the host
+ *          resolves their strings like ctcdec_decode_stream_batch does). The arrays must stay untouched until close or the
+ *          next import (they are copied).
+ * One handle belongs to one decoder; its calls are serialised with that decoder's other calls. */
+typedef struct ctcdec_stream ctcdec_stream;
+int ctcdec_stream_open(ctcdec_decoder* dec, int32_t n_streams, const ctcdec_lm_state* start_states, ctcdec_stream** out);
+int ctcdec_stream_push(ctcdec_stream* st, const void* const* chunk_logits, const int32_t* chunk_frames, int32_t dtype,
+                       int32_t is_device, const ctcdec_params* params, const int32_t* first_frame,
+                       int32_t force_next_word, int32_t is_end, int32_t want_result, ctcdec_result** out);
+int ctcdec_stream_read(ctcdec_stream* st, const ctcdec_params* params, ctcdec_result** out);
+int ctcdec_stream_import(ctcdec_stream* st, const ctcdec_beam_in* beams, const int64_t* beam_off /* [n_streams+1] */,
+                         const char* text_blob, int64_t text_bytes);
+/* frames pushed so far per stream ([n_streams]) */
+int ctcdec_stream_frames(const ctcdec_stream* st, int64_t* frames_out);
+void ctcdec_stream_close(ctcdec_stream* st);
+
 /* ---- results (OutputBeam fields, decoder.py:102-110, assembled as decoder.py:653-667) --------- */
 int32_t ctcdec_result_num_utts(const ctcdec_result* r);
 int32_t ctcdec_result_num_beams(const ctcdec_result* r, int32_t utt);

@@ -109,6 +109,13 @@ _PROTOS = {
     "ctcdec_decode_stream_batch": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
                                              C.POINTER(Params), C.POINTER(C.c_int32), C.POINTER(BeamIn),
                                              C.POINTER(C.c_int64), C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "ctcdec_stream_open": (C.c_int, [_VP, C.c_int32, C.POINTER(LmState), C.POINTER(_VP)]),
+    "ctcdec_stream_push": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(Params),
+                                     C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "ctcdec_stream_read": (C.c_int, [_VP, C.POINTER(Params), C.POINTER(_VP)]),
+    "ctcdec_stream_import": (C.c_int, [_VP, C.POINTER(BeamIn), C.POINTER(C.c_int64), C.c_char_p, C.c_int64]),
+    "ctcdec_stream_frames": (C.c_int, [_VP, C.POINTER(C.c_int64)]),
+    "ctcdec_stream_close": (None, [_VP]),
     "ctcdec_result_num_utts": (C.c_int32, [_VP]),
     "ctcdec_result_num_beams": (C.c_int32, [_VP, C.c_int32]),
     "ctcdec_result_text": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(_VP), C.POINTER(C.c_int64)]),

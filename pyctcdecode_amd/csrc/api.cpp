@@ -240,6 +240,34 @@ struct ctcdec_result {
   std::vector<double> raw_lm;
 };
 
+// A batch of device-resident streams (ctcdec_stream_*): what survives between chunks lives in device memory owned by
+// the handle -- per stream a row of carried beams (the ImportBeam records the kernels' finalisation writes and the next
+// chunk's import_beams() reads), the emission arena (grow-only: the chains reach back to the start of the stream) and
+// the counters -- plus host mirrors of the counters, refreshed after every push.
+struct ctcdec_stream {
+  ctcdec_decoder* dec = nullptr;
+  int32_t n = 0;
+  int K = 1;
+  static constexpr int CAP = CTCDEC_MAX_BEAM_WIDTH;  // carried beams per stream
+  DevBuf carry, carry_x, sstate, emit, eoff;
+  uint64_t emit_cap = 0;  // emission nodes per stream
+  std::vector<StreamState> mirror;
+  std::vector<int64_t> frames;  // frames pushed so far
+  std::vector<ctcdec_lm_state> start_states;  // n * K, or empty: the models' defaults
+  // the caller's beams of the last ctcdec_stream_import: roots (BR_IMPORT) of the chains decoded since
+  bool has_import = false;
+  std::vector<ctcdec_beam_in> imp_beams;
+  std::vector<int64_t> imp_off;
+  std::string imp_blob;
+  ~ctcdec_stream() {
+    carry.drop();
+    carry_x.drop();
+    sstate.drop();
+    emit.drop();
+    eoff.drop();
+  }
+};
+
 static int sync_tables(ctcdec_decoder* d, std::string* err) {
   if (d->tables_dirty) {
     if (d->multi) fill_token_starts_from(d->multi->prefix_table, d->multi->prefix_mask, &d->alpha);
@@ -522,7 +550,9 @@ static void replay(const ctcdec_decoder* d, const EmitNode* toks, uint32_t n, co
     } else if (br == BR_APPEND) {
       text += d->alpha.labels[tok];
     } else if (br == BR_FINAL) {
-      close_word(toks[k].wstart, toks[k].wend, false);
+      // (the last entry of a folded beam, or -- resident streams after force_next_word -- an entry in the middle of
+      // the chain: the trailing separator of the former is dropped below)
+      close_word(toks[k].wstart, toks[k].wend, true);
     } else if (br == BR_IMPORT && st) {
       const ctcdec_beam_in& in = st->beams[imp0 + tok];
       r->src = (int32_t)tok;
@@ -566,7 +596,7 @@ static void fill_result(const OutBeam& ob, const LmState* xs, int K, BeamResult*
 
 static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
                        int32_t dtype, int32_t is_device, const ctcdec_params* p, const ctcdec_lm_state* start_states,
-                       const StreamIn* stream, ctcdec_result** out);
+                       const StreamIn* stream, ctcdec_result** out, ctcdec_stream* rs = nullptr, bool want_result = true);
 
 int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames,
                         int32_t n_utts, int32_t dtype, int32_t is_device, const ctcdec_params* p,
@@ -676,9 +706,11 @@ static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, i
   return "";
 }
 
+// rs: the streams are device-resident (`stream` then only carries first_frame / fold / eos and, below an import, the
+// caller's beams for the replay); want_result: materialise beams at all
 static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
                        int32_t dtype, int32_t is_device, const ctcdec_params* p, const ctcdec_lm_state* start_states,
-                       const StreamIn* stream, ctcdec_result** out) {
+                       const StreamIn* stream, ctcdec_result** out, ctcdec_stream* rs, bool want_result) {
   if (!dec || !p || !out || n_utts < 0 || (n_utts > 0 && (!utt_logits || !utt_frames)))
     return fail(CTCDEC_ERR_ARG, "bad arguments");
   if (dtype < CTCDEC_F32 || dtype > CTCDEC_BF16) return fail(CTCDEC_ERR_ARG, "dtype must be f32, f64, f16 or bf16");
@@ -736,18 +768,49 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   std::vector<uint64_t> toff((size_t)n_utts + 1, 0), eoff((size_t)n_utts + 1, 0);
   for (int32_t u = 0; u < n_utts; ++u) {
     uint64_t T = (uint64_t)utt_frames[u];
-    uint64_t n_imp = stream ? (uint64_t)(stream->beam_off[u + 1] - stream->beam_off[u]) : 0;
+    uint64_t n_imp = rs ? (uint64_t)rs->mirror[(size_t)u].n_carry
+                        : stream ? (uint64_t)(stream->beam_off[u + 1] - stream->beam_off[u]) : 0;
     toff[(size_t)u + 1] = toff[(size_t)u] + ((T + 1) * (uint64_t)B + 2 + n_imp) * (uint64_t)K;
     eoff[(size_t)u + 1] = eoff[(size_t)u] + T * (uint64_t)B + 2 + n_imp;
   }
   int n_best = p->n_best > 0 ? std::min(p->n_best, B) : B;
   // emission lists: at most one entry per frame plus the import root and the closing entry
   unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + 2 * (int64_t)n_utts);
+  if (rs) {  // a resident stream's lists reach back to its start (one entry per emission node at most)
+    unsigned long long hist = 0;
+    for (int32_t u = 0; u < n_utts; ++u) hist += rs->mirror[(size_t)u].emit_next;
+    tok_cap = want_result ? (unsigned long long)n_best * (hist + (unsigned long long)(R + 2 * (int64_t)n_utts)) : 1ull;
+  }
   // streaming: carried-over beams of every stream
   const ImportBeam* d_imports = nullptr;
   const LmState* d_import_x = nullptr;
   int32_t max_import = 0;
-  if (stream) {
+  if (rs) {
+    for (int32_t u = 0; u < n_utts; ++u) max_import = std::max<int32_t>(max_import, (int32_t)rs->mirror[(size_t)u].n_carry);
+    std::vector<int32_t> ff(stream->first_frame, stream->first_frame + n_utts);
+    if (upload(dec->w_ff, ff, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    // the emission arena of a resident stream is its own and reaches back to the start of the stream: room for this chunk
+    uint64_t need = 0;
+    for (int32_t u = 0; u < n_utts; ++u)
+      need = std::max<uint64_t>(need, (uint64_t)rs->mirror[(size_t)u].emit_next + (uint64_t)utt_frames[u] * (uint64_t)B +
+                                          (uint64_t)ctcdec_stream::CAP + 2);
+    if (need > rs->emit_cap) {
+      const uint64_t cap = std::max<uint64_t>(need + need / 2, 4096);
+      DevBuf grown;
+      if (grown.ensure((size_t)n_utts * cap * sizeof(EmitNode), &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      for (int32_t u = 0; u < n_utts && rs->emit.p; ++u) {
+        const size_t used = (size_t)rs->mirror[(size_t)u].emit_next * sizeof(EmitNode);
+        if (used && be::d2d((char*)grown.p + (size_t)u * cap * sizeof(EmitNode), (const char*)rs->emit.p + (size_t)u * rs->emit_cap * sizeof(EmitNode), used, &err))
+          return fail(CTCDEC_ERR_DEVICE, err);
+      }
+      rs->emit.drop();
+      rs->emit = grown;
+      rs->emit_cap = cap;
+      std::vector<uint64_t> eo((size_t)n_utts + 1);
+      for (int32_t u = 0; u <= n_utts; ++u) eo[(size_t)u] = (uint64_t)u * cap;
+      if (upload(rs->eoff, eo, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    }
+  } else if (stream) {
     const int64_t n_imp_total = stream->beam_off[n_utts];
     std::vector<ImportBeam> imps((size_t)std::max<int64_t>(n_imp_total, 1));
     std::vector<LmState> imps_x(K > 1 ? (size_t)std::max<int64_t>(n_imp_total, 1) * (size_t)(K - 1) : 0);
@@ -773,16 +836,16 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     }
   }
   if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
-      dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_toff, toff, &err) ||
-      upload(dec->w_eoff, eoff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
+      (!rs && (dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_eoff, eoff, &err))) ||
+      upload(dec->w_toff, toff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
       dec->w_nout.ensure((size_t)n_utts * 4, &err) || dec->w_status.ensure((size_t)n_utts * 4, &err) ||
       dec->w_tok.ensure((size_t)std::max<unsigned long long>(tok_cap, 1) * sizeof(EmitNode), &err) ||
       dec->w_head.ensure(16, &err) || dec->w_cold.ensure((size_t)n_utts * 2 * COLD_STRIDE * sizeof(ColdRec), &err))
     return fail(CTCDEC_ERR_DEVICE, err);
   const LmState* d_start = nullptr;
-  if (stream) {
+  if (stream && !rs) {
     d_start = nullptr;  // every imported beam carries its own LM state
-  } else if (dec->has_lm) {
+  } else if (dec->has_lm) {  // (resident streams: used by the streams that are at their starting state)
     // per utterance one state per model; a negative length (or no array) asks for the model's own default
     std::vector<LmState> st((size_t)n_utts * K);
     for (int32_t u = 0; u < n_utts; ++u) {
@@ -852,10 +915,29 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.prof = nullptr;
   ba.imports = d_imports;
   ba.import_xstates = d_import_x;
-  ba.import_off = stream ? (const int64_t*)dec->w_impoff.p : nullptr;
+  ba.import_off = (stream && !rs) ? (const int64_t*)dec->w_impoff.p : nullptr;
   ba.first_frames = stream ? (const int32_t*)dec->w_ff.p : nullptr;
   ba.cold = (ColdRec*)dec->w_cold.p;
   ba.max_import = max_import;
+  ba.carry_out = nullptr;
+  ba.carry_xstates = nullptr;
+  ba.sstate = nullptr;
+  ba.carry_stride = 0;
+  ba.want_out = 1;
+  ba.resident_in = 0;
+  if (rs) {
+    ba.emit_nodes = (EmitNode*)rs->emit.p;
+    ba.emit_off = (const uint64_t*)rs->eoff.p;
+    ba.imports = (const ImportBeam*)rs->carry.p;
+    ba.import_xstates = K > 1 ? (const LmState*)rs->carry_x.p : nullptr;
+    ba.import_off = nullptr;
+    ba.resident_in = 1;
+    ba.carry_out = (ImportBeam*)rs->carry.p;
+    ba.carry_xstates = K > 1 ? (LmState*)rs->carry_x.p : nullptr;
+    ba.sstate = (StreamState*)rs->sstate.p;
+    ba.carry_stride = ctcdec_stream::CAP;
+    ba.want_out = want_result ? 1 : 0;
+  }
   if (dec->profile) {
     if (dec->w_prof.ensure(N_PROF * 8, &err) || be::zero(dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     ba.prof = (unsigned long long*)dec->w_prof.p;
@@ -900,7 +982,9 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       if (be::zero(dec->w_head.p, 16, &err)) return -1;
       return be::launch_beam(ba, &err);
     };
-    if (be::launch_prune(pa, &err) || run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
+    // (a resident stream's beam kernel advances persistent state: it is launched once, when the prune stage has
+    // reported -- everything else launches it right behind the first prune pass and redoes it in the two rare cases)
+    if (be::launch_prune(pa, &err) || (!rs && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
     uint32_t flags[4] = {0, 0, 0, 0};
     if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     if (flags[2]) {  // rows that sum to about 1: the reference's test in its own dtype and summation order (decoder.py:760)
@@ -909,11 +993,14 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     if (flags[1]) {  // some utterance holds probabilities: redo those rows as log(clip(p)), then the beams
       pa.pass = 1;
       if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
-      if (be::launch_prune(pa, &err) || run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
+      if (be::launch_prune(pa, &err) || (!rs && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
       if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
     const uint32_t ovf = flags[0];
-    if (!ovf) break;
+    if (!ovf) {
+      if (rs && run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
+      break;
+    }
     if (max_surv == V) return fail(CTCDEC_ERR_INTERNAL, "survivor overflow at full vocabulary");
     max_surv = V;  // un-normalised probability rows can exceed the bound: redo at full width
   }
@@ -931,6 +1018,20 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       be::d2h(status, dec->w_status.p, (size_t)n_utts * 4, &err) || be::d2h(&head, dec->w_head.p, 8, &err))
     return fail(CTCDEC_ERR_DEVICE, err);
   auto t_kernel = std::chrono::steady_clock::now();
+  if (rs) {  // the streams have moved on, whatever the chunk's outcome: refresh the mirrors first
+    if (be::d2h(rs->mirror.data(), rs->sstate.p, (size_t)n_utts * sizeof(StreamState), &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    for (int32_t u = 0; u < n_utts; ++u) rs->frames[(size_t)u] += utt_frames[u];
+    if (stream->eos) {  // decoder.py:681-728 with is_end: the next chunk starts a new utterance
+      for (auto& m : rs->mirror) {
+        m.n_carry = 0;
+        m.emit_next = 1;
+        m.status = 0;
+      }
+      if (be::h2d(rs->sstate.p, rs->mirror.data(), (size_t)n_utts * sizeof(StreamState), &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      rs->has_import = false;
+      std::fill(rs->frames.begin(), rs->frames.end(), 0);
+    }
+  }
   for (int32_t u = 0; u < n_utts; ++u)
     if (status[u] & ST_NO_BEAMS)  // the reference: ValueError from max([]) (decoder.py:545 / :585)
       return fail(CTCDEC_ERR_ARG, "max() arg is an empty sequence (utterance " + std::to_string(u) +
@@ -938,6 +1039,13 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   for (int32_t u = 0; u < n_utts; ++u)
     if (status[u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[u]) +
                                                         " for utterance " + std::to_string(u));
+  if (!want_result) {  // a resident stream between reads: nothing to bring back
+    be::last_timing(&res->ms[0], &res->ms[1]);
+    res->beam_kernel = be::last_beam_kernel();
+    res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    *out = res.release();
+    return CTCDEC_OK;
+  }
   const OutBeam* obs = (const OutBeam*)dec->h_out.p;
   if (be::d2h(dec->h_out.p, dec->w_out.p, (size_t)n_utts * n_best * sizeof(OutBeam), &err))
     return fail(CTCDEC_ERR_DEVICE, err);
@@ -997,6 +1105,117 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   }
   *out = res.release();
   return CTCDEC_OK;
+}
+
+// ---- device-resident streams ------------------------------------------------------------------------------------
+int ctcdec_stream_open(ctcdec_decoder* dec, int32_t n_streams, const ctcdec_lm_state* start_states, ctcdec_stream** out) {
+  if (!dec || !out || n_streams < 1) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  std::string err;
+  std::lock_guard<std::mutex> device_lock(g_device_mu);
+  if (be::bind_thread(&err)) return fail(CTCDEC_ERR_DEVICE, err);
+  std::unique_ptr<ctcdec_stream> st(new ctcdec_stream());
+  st->dec = dec;
+  st->n = n_streams;
+  st->K = dec->has_lm ? dec->n_lms() : 1;
+  if (start_states && dec->has_lm) st->start_states.assign(start_states, start_states + (size_t)n_streams * st->K);
+  st->mirror.assign((size_t)n_streams, StreamState{0u, 1u, 0u, 0u});
+  st->frames.assign((size_t)n_streams, 0);
+  st->imp_off.assign((size_t)n_streams + 1, 0);
+  if (st->carry.ensure((size_t)n_streams * ctcdec_stream::CAP * sizeof(ImportBeam), &err) ||
+      (st->K > 1 && st->carry_x.ensure((size_t)n_streams * ctcdec_stream::CAP * (size_t)(st->K - 1) * sizeof(LmState), &err)) ||
+      st->sstate.ensure((size_t)n_streams * sizeof(StreamState), &err) ||
+      be::h2d(st->sstate.p, st->mirror.data(), (size_t)n_streams * sizeof(StreamState), &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  *out = st.release();
+  return CTCDEC_OK;
+}
+
+int ctcdec_stream_push(ctcdec_stream* st, const void* const* chunk_logits, const int32_t* chunk_frames, int32_t dtype,
+                       int32_t is_device, const ctcdec_params* params, const int32_t* first_frame, int32_t force_next_word,
+                       int32_t is_end, int32_t want_result, ctcdec_result** out) {
+  if (!st || !params || !chunk_frames) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  if ((want_result || is_end) && !out) return fail(CTCDEC_ERR_ARG, "a result is wanted but there is nowhere to put it");
+  std::vector<int32_t> ff((size_t)st->n);
+  for (int32_t u = 0; u < st->n; ++u) ff[(size_t)u] = first_frame ? first_frame[u] : (int32_t)st->frames[(size_t)u];
+  StreamIn sin;
+  sin.first_frame = ff.data();
+  sin.beams = st->has_import ? st->imp_beams.data() : nullptr;
+  sin.beam_off = st->imp_off.data();
+  sin.text_blob = st->imp_blob.data();
+  sin.fold = (force_next_word || is_end) ? 1 : 0;
+  sin.eos = is_end ? 1 : 0;
+  ctcdec_result* res = nullptr;
+  const int rc = decode_impl(st->dec, chunk_logits, chunk_frames, st->n, dtype, is_device, params,
+                             st->start_states.empty() ? nullptr : st->start_states.data(), &sin, &res, st,
+                             want_result != 0 || is_end != 0);
+  if (rc != CTCDEC_OK) return rc;
+  if (out) *out = res;
+  else ctcdec_result_free(res);
+  return CTCDEC_OK;
+}
+
+int ctcdec_stream_read(ctcdec_stream* st, const ctcdec_params* params, ctcdec_result** out) {
+  if (!st || !params || !out) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  // a chunk of zero frames: the finalisation ranks the carried beams again (same beams, same order) and this time
+  // writes output records and back-traces the emission chains
+  std::vector<const void*> ptrs((size_t)st->n, nullptr);
+  std::vector<int32_t> zero((size_t)st->n, 0);
+  return ctcdec_stream_push(st, ptrs.data(), zero.data(), CTCDEC_F32, 0, params, nullptr, 0, 0, 1, out);
+}
+
+int ctcdec_stream_import(ctcdec_stream* st, const ctcdec_beam_in* beams, const int64_t* beam_off, const char* text_blob,
+                         int64_t text_bytes) {
+  if (!st || !beams || !beam_off || !text_blob || text_bytes < 0) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  ctcdec_decoder* dec = st->dec;
+  std::string err;
+  std::lock_guard<std::mutex> device_lock(g_device_mu);
+  if (be::bind_thread(&err)) return fail(CTCDEC_ERR_DEVICE, err);
+  if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // (the hot-word view of the partial words)
+  const int K = st->K;
+  StreamIn sin;
+  sin.first_frame = nullptr;
+  sin.beams = beams;
+  sin.beam_off = beam_off;
+  sin.text_blob = text_blob;
+  sin.fold = sin.eos = 0;
+  std::vector<ImportBeam> imps((size_t)st->n * ctcdec_stream::CAP);
+  std::vector<LmState> imps_x(K > 1 ? imps.size() * (size_t)(K - 1) : 0);
+  for (int32_t u = 0; u < st->n; ++u) {
+    const int64_t cnt = beam_off[u + 1] - beam_off[u];
+    if (cnt < 1 || cnt > ctcdec_stream::CAP) return fail(CTCDEC_ERR_ARG, "a stream must carry between 1 and 256 beams");
+    for (int64_t k = 0; k < cnt; ++k) {
+      const size_t slot = (size_t)u * ctcdec_stream::CAP + (size_t)k;
+      std::string e = build_import(dec, sin, beam_off[u] + k, 0, &imps[slot], K > 1 ? &imps_x[slot * (size_t)(K - 1)] : nullptr);
+      if (!e.empty()) return fail(CTCDEC_ERR_ARG, e);
+    }
+  }
+  // the new roots go behind what the arena already holds; the old chains are unreachable from now on
+  for (int32_t u = 0; u < st->n; ++u) st->mirror[(size_t)u].n_carry = (uint32_t)(beam_off[u + 1] - beam_off[u]);
+  if (be::h2d(st->carry.p, imps.data(), imps.size() * sizeof(ImportBeam), &err) ||
+      (K > 1 && be::h2d(st->carry_x.p, imps_x.data(), imps_x.size() * sizeof(LmState), &err)) ||
+      be::h2d(st->sstate.p, st->mirror.data(), (size_t)st->n * sizeof(StreamState), &err))
+    return fail(CTCDEC_ERR_DEVICE, err);
+  const int64_t nb = beam_off[st->n];
+  st->imp_beams.assign(beams, beams + nb);
+  for (auto& b : st->imp_beams) b.more_states = nullptr;  // (copied into the carry rows above)
+  st->imp_off.assign(beam_off, beam_off + st->n + 1);
+  st->imp_blob.assign(text_blob, (size_t)text_bytes);
+  st->has_import = true;
+  return CTCDEC_OK;
+}
+
+int ctcdec_stream_frames(const ctcdec_stream* st, int64_t* frames_out) {
+  if (!st || !frames_out) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  for (int32_t u = 0; u < st->n; ++u) frames_out[u] = st->frames[(size_t)u];
+  return CTCDEC_OK;
+}
+
+void ctcdec_stream_close(ctcdec_stream* st) {
+  if (!st) return;
+  std::string err;
+  std::lock_guard<std::mutex> device_lock(g_device_mu);
+  be::bind_thread(&err);
+  delete st;
 }
 
 // Diagnostics: run only the frame-prune stage on one utterance and hand back its survivor lists.

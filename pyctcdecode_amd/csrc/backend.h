@@ -23,6 +23,7 @@ void* alloc_host(size_t bytes, std::string* err);  // page-locked staging memory
 void release_host(void* p);
 int h2d(void* dst, const void* src, size_t bytes, std::string* err);
 int d2h(void* dst, const void* src, size_t bytes, std::string* err);
+int d2d(void* dst, const void* src, size_t bytes, std::string* err);
 int zero(void* dst, size_t bytes, std::string* err);
 int sync(std::string* err);
 // streams and events for the chunked pipeline of large batches (api.cpp: decode_pipelined). Every call above and the
@@ -93,6 +94,16 @@ struct BeamArgs {
   const int32_t* first_frames; // [n_utts] processed_frames per utterance (device), or nullptr
   ColdRec* cold;               // [n_utts * 2 * COLD_STRIDE] scratch of the wave kernel
   int32_t max_import;          // streaming: the largest number of beams any stream carries in
+  // device-resident streams (ctcdec_stream_*), else nullptr / 0: where stream u's finalisation leaves its beams for the
+  // next chunk (carry_out + u * carry_stride; several LMs: carry_xstates + u * carry_stride * (n_lms - 1)), its counters
+  // (sstate + u: beams carried in, first free node of its emission arena)
+  ImportBeam* carry_out;
+  LmState* carry_xstates;
+  StreamState* sstate;
+  int32_t carry_stride;
+  int32_t want_out;            // 0: no output records / emission lists for this launch (resident streams between reads)
+  int32_t resident_in;         // 1: `imports` is the carry buffer itself (stream u: imports + u * carry_stride, sstate[u].n_carry
+                               // beams; import_xstates likewise), import_off is not used
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 

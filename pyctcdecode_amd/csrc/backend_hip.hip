@@ -122,6 +122,10 @@ int d2h(void* d, const void* s, size_t n, std::string* err) {
   HIP_TRY(hipStreamSynchronize(g_stream));
   return 0;
 }
+int d2d(void* d, const void* s, size_t n, std::string* err) {
+  HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, g_stream));
+  return 0;
+}
 int zero(void* d, size_t n, std::string* err) {
   HIP_TRY(hipMemsetAsync(d, 0, n, g_stream));
   return 0;
@@ -969,11 +973,21 @@ __global__ __launch_bounds__(NT, 2) void beam_decode(BeamArgs a, int surv_cap) {
   io.tok_pool_head = a.tok_pool_head;
   io.tok_pool_cap = a.tok_pool_cap;
   io.prof = (u == 0) ? a.prof : nullptr;
-  io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
-  io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
-    io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
+  io.imports = (a.imports && !a.resident_in) ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = (a.imports && !a.resident_in) ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+    io.import_xstates = (a.imports && a.import_xstates && !a.resident_in) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   io.cold = nullptr;
+  io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
+  io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (n_lms - 1) : nullptr;
+  io.sstate = a.sstate ? a.sstate + u : nullptr;
+  io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
+  io.want_out = a.want_out;
+  if (a.resident_in) {
+    io.imports = a.imports + (size_t)u * a.carry_stride;
+    io.n_import = (int32_t)a.sstate[u].n_carry;
+    io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * (n_lms - 1) : nullptr;
+  }
   GpuCtx ctx{(int)threadIdx.x, NT};
   BeamDecoder<GpuCtx, MULTI> dec(ctx, view, shape, a.tables, a.params, io);
   dec.run();
@@ -1103,11 +1117,21 @@ __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   io.tok_pool_head = a.tok_pool_head;
   io.tok_pool_cap = a.tok_pool_cap;
   io.prof = (u == 0) ? a.prof : nullptr;
-  io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
-  io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+  io.imports = (a.imports && !a.resident_in) ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = (a.imports && !a.resident_in) ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
   io.import_xstates = nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   io.cold = a.cold + (size_t)u * 2 * COLD_STRIDE;
+  io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
+  io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (1u - 1) : nullptr;
+  io.sstate = a.sstate ? a.sstate + u : nullptr;
+  io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
+  io.want_out = a.want_out;
+  if (a.resident_in) {
+    io.imports = a.imports + (size_t)u * a.carry_stride;
+    io.n_import = (int32_t)a.sstate[u].n_carry;
+    io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * 0 : nullptr;
+  }
   WaveGpuCtx ctx{(int)threadIdx.x};
   WaveDecoder<WaveGpuCtx, BW> dec(ctx, view, a.tables, a.params, io);
   dec.run();

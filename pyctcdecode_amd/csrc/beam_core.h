@@ -230,6 +230,14 @@ struct UttIO {
   int32_t n_import;
   int32_t first_frame;        // processed_frames of this utterance (decoder.py:443)
   ColdRec* cold;              // wave kernel: [2 * COLD_STRIDE]
+  // device-resident streams (nullptr / 0 otherwise): where the finalisation leaves the beams for the next chunk (and
+  // their LM states of model 1.. for several LMs), the stream's counters, the first free emission node at entry
+  // (0: a fresh arena), and whether output records + emission lists are wanted at all for this chunk
+  ImportBeam* carry_out;
+  LmState* carry_xstates;
+  StreamState* sstate;
+  uint32_t emit_start;
+  int32_t want_out;
 };
 constexpr int N_PROF = 24;
 
@@ -1504,7 +1512,7 @@ CTC_UNROLL
     if (ctx.tid == 0) {
       for (int k = 0; k < 16; ++k) L.scal[k] = 0;
       L.scal[1] = node_span();  // text node 0 = empty text
-      L.scal[2] = 1;  // emission node 0 = root
+      L.scal[2] = io.emit_start > 0 ? io.emit_start : 1u;  // emission node 0 = root (a resident stream goes on in its arena)
       TextNode root;
       root.text_h = 0;
       root.raw_lm = 0.0;
@@ -1562,10 +1570,13 @@ CTC_UNROLL
     if (io.imports && io.n_import > 0) import_beams();
   }
 
-  // streaming: rebuild the beam table from the caller's beams (their order is the rank order)
+  // streaming: rebuild the beam table from the caller's beams (their order is the rank order). Beams built by the host
+  // are rooted in fresh BR_IMPORT emission nodes; beams carried over on the device (resident streams) keep their chains.
   CTC_HD void import_beams() {
     const BeamSoA b = beams_at(0);
     const int n = io.n_import;
+    const uint32_t emit_base = L.scal[2];
+    const bool host_built = io.imports[0].resident == 0u;
     for (int i = ctx.tid; i < n; i += ctx.nt) {
       const ImportBeam& m = io.imports[i];
       const uint32_t span = node_span();
@@ -1596,12 +1607,21 @@ CTC_UNROLL
         for (uint32_t k = 1; k < span; ++k)
           copy_state(&more[k].state, io.import_xstates[(size_t)i * (span - 1) + (k - 1)]);
       }
-      EmitNode en;
-      en.parent = 0;
-      en.tok_branch = (uint32_t)i | (BR_IMPORT << 16);
-      en.wstart = -1;
-      en.wend = -1;
-      io.emit_nodes[1 + i] = en;
+      uint32_t enode = m.enode, depth = m.depth;
+      if (host_built) {
+        EmitNode en;
+        en.parent = 0;
+        en.tok_branch = (uint32_t)i | (BR_IMPORT << 16);
+        en.wstart = -1;
+        en.wend = -1;
+        enode = emit_base + (uint32_t)i;
+        depth = 1u;
+        if (enode >= io.emit_cap) {
+          ctx.atomic_or(&L.scal[6], ST_EMIT_OVERFLOW);
+          enode = io.emit_cap - 1;
+        }
+        io.emit_nodes[enode] = en;
+      }
       b.logit[i] = m.logit_score;
       b.lm_hw[i] = lmhw;
       b.pscore[i] = m.plen > 0 ? partial_score(tab, prm, m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
@@ -1613,17 +1633,18 @@ CTC_UNROLL
       b.c_hist_h[i] = 0;
       b.text_node[i] = node;
       b.comp_node[i] = 0;
-      b.emit_node[i] = 1 + i;
+      b.emit_node[i] = enode;
       b.word_id[i] = m.word_id;
       b.meta1[i] = (m.last_char & 0xFFFFu) | (m.plen << 16);
       b.meta2[i] = m.plen > 0 ? m.m2 : EMPTY_PARTIAL_M2;
-      b.depth[i] = 1;
+      b.depth[i] = depth;
       b.pstart[i] = m.pstart;
       b.pend[i] = m.pend;
     }
+    ctx.sync();  // (every thread has read the arena's first free node)
     if (ctx.tid == 0) {
       L.scal[1] = (1 + (uint32_t)n) * node_span();
-      L.scal[2] = 1 + (uint32_t)n;
+      if (host_built) L.scal[2] = emit_base + (uint32_t)n;
     }
     ctx.sync_mem();
     N = n;
@@ -1720,7 +1741,8 @@ CTC_UNROLL
     ctx.sync();
     finish_frame(0, true);
     uint32_t n = L.scal[9];
-    uint32_t n_out = n;
+    if (io.carry_out && !eos) carry_beams(b, n, fold);
+    uint32_t n_out = io.want_out ? n : 0u;
     if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
     // output records + back-trace of each returned beam's emission chain
     if (ctx.tid == 0) L.scal[8] = 0;
@@ -1813,10 +1835,71 @@ CTC_UNROLL
         }
       }
     }
+    ctx.sync();
     if (ctx.tid == 0) {
       *io.n_out = n_out;
       *io.status = L.scal[6];
+      if (io.sstate) {
+        io.sstate->n_carry = n;
+        io.sstate->emit_next = L.scal[2];
+        io.sstate->status = L.scal[6];
+        io.sstate->pad = 0;
+      }
     }
+  }
+
+  // Device-resident streams: the ranked beams of this chunk, written where the next chunk's import_beams() reads them
+  // (what the reference's caller carries between partial_decode_beams calls, decoder.py:681-728). A beam whose open
+  // word the finalisation closed (force_next_word) gets a BR_FINAL emission node for that word.
+  CTC_HD void carry_beams(const BeamSoA& b, uint32_t n, bool fold) {
+    for (uint32_t r = ctx.tid; r < n; r += ctx.nt) {
+      const uint32_t idx = L.sel[r];
+      const int d = (int)L.p_don[idx];
+      const uint32_t pl = plen(b, d);
+      const bool closes = fold && pl > 0;
+      uint32_t enode = b.emit_node[d], depth = b.depth[d];
+      if (closes) {
+        uint32_t e = ctx.atomic_add(&L.scal[2], 1u);
+        if (e >= io.emit_cap) {
+          ctx.atomic_or(&L.scal[6], ST_EMIT_OVERFLOW);
+          e = io.emit_cap - 1;
+        }
+        EmitNode fin;
+        fin.parent = enode;
+        fin.tok_branch = BR_FINAL << 16;
+        fin.wstart = b.pstart[d];
+        fin.wend = b.pend[d];
+        io.emit_nodes[e] = fin;
+        enode = e;
+        depth += 1;
+      }
+      const uint32_t nidx = closes ? b.comp_node[d] : b.text_node[d];
+      const TextNode& node = io.text_nodes[nidx];
+      ImportBeam& m = io.carry_out[r];
+      m.logit_score = L.p_logit[idx];
+      m.raw_lm = node.raw_lm;
+      m.text_h = node.text_h;
+      m.part_h = fold ? 0ull : b.part_h[d];
+CTC_UNROLL
+      for (int k = 0; k < MAX_CTX; ++k) m.ring[k] = node.ring[k];
+      m.ring_cnt = node.ring_cnt;
+      m.hw_cnt = node.hw_cnt;
+      m.plen = fold ? 0u : pl;
+      m.last_char = fold ? NO_CHAR : last_char(b, d);
+      m.m2 = fold ? EMPTY_PARTIAL_M2 : b.meta2[d];
+      m.word_id = fold ? 0u : b.word_id[d];
+      m.pstart = fold ? -1 : b.pstart[d];
+      m.pend = fold ? -1 : b.pend[d];
+      copy_state(&m.state, node.state);
+      m.enode = enode;
+      m.depth = depth;
+      m.resident = 1u;
+      if (MULTI && io.carry_xstates) {  // the states of model 1.. ride in the nodes behind the text's own
+        const TextNode* nodes = &node;
+        for (uint32_t k = 1; k < tab.n_lms; ++k) copy_state(&io.carry_xstates[(size_t)r * (tab.n_lms - 1) + (k - 1)], nodes[k].state);
+      }
+    }
+    ctx.sync();
   }
 
   CTC_HD void run() {

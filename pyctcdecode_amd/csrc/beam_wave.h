@@ -1407,7 +1407,7 @@ CTC_UNROLL
 
   CTC_HD void init() {
     text_next = 1;  // text node 0 = empty text
-    emit_next = 1;  // emission node 0 = root
+    emit_next = io.emit_start > 0 ? io.emit_start : 1u;  // emission node 0 = root (a resident stream goes on in its arena)
     status = 0;
     fflag = 0;
     par = 0;
@@ -1444,9 +1444,12 @@ CTC_UNROLL
   }
 
   // streaming: rebuild the beam table from the caller's beams (their order is the rank order; the host has
-  // checked that there are no more of them than the table holds)
+  // checked that there are no more of them than the table holds). Beams built by the host are rooted in fresh
+  // BR_IMPORT emission nodes; beams carried over on the device (resident streams) keep their emission chains.
   CTC_HD void import_beams() {
     const int n = io.n_import < BW ? io.n_import : BW;
+    const uint32_t emit_base = emit_next;
+    const bool host_built = io.imports[0].resident == 0u;
     for (int i = lane; i < n; i += 64) {
       const ImportBeam& m = io.imports[i];
       const uint32_t node = 1u + (uint32_t)i;  // node 0 is the empty text
@@ -1468,18 +1471,27 @@ CTC_UNROLL
         tn.state.words[k] = m.state.words[k];
         tn.state.backoff[k] = m.state.backoff[k];
       }
-      EmitNode en;
-      en.parent = 0;
-      en.tok_branch = (uint32_t)i | (BR_IMPORT << 16);
-      en.wstart = -1;
-      en.wend = -1;
-      io.emit_nodes[1 + i] = en;
+      uint32_t enode = m.enode, depth = m.depth;
+      if (host_built) {
+        EmitNode en;
+        en.parent = 0;
+        en.tok_branch = (uint32_t)i | (BR_IMPORT << 16);
+        en.wstart = -1;
+        en.wend = -1;
+        enode = emit_base + (uint32_t)i;
+        depth = 1u;
+        if (enode >= io.emit_cap) {
+          status |= ST_EMIT_OVERFLOW;
+          enode = io.emit_cap - 1;
+        }
+        io.emit_nodes[enode] = en;
+      }
       const double ps = m.plen > 0 ? partial_score(tab, prm, m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
       write_beam(i, m.text_h, m.part_h, m.logit_score, (m.last_char & 0xFFFFu) | (m.plen << 16),
-                 m.plen > 0 ? m.m2 : EMPTY_PARTIAL_M2, lmhw, ps, hh, node, 1u + (uint32_t)i, m.word_id, m.pstart, m.pend, 1u);
+                 m.plen > 0 ? m.m2 : EMPTY_PARTIAL_M2, lmhw, ps, hh, node, enode, m.word_id, m.pstart, m.pend, depth);
     }
     text_next = 1u + (uint32_t)n;
-    emit_next = 1u + (uint32_t)n;
+    if (host_built) emit_next = emit_base + (uint32_t)n;
     N = n;
   }
 
@@ -1600,7 +1612,8 @@ CTC_UNROLL
     uint32_t n = rank_pool(key_to_score(runmax) + prm.beam_prune_logp, false);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
     if (n == 0) status |= ST_NO_BEAMS;
-    uint32_t n_out = n;
+    if (io.carry_out && !eos) carry_beams(n, fold);
+    uint32_t n_out = io.want_out ? n : 0u;
     if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
     // output records + back-trace of each returned beam's emission chain
     uint32_t len[SLB], off[SLB];
@@ -1702,7 +1715,76 @@ CTC_UNROLL
     if (lane == 0) {
       *io.n_out = n_out;
       *io.status = status;
+      if (io.sstate) {
+        io.sstate->n_carry = n;
+        io.sstate->emit_next = emit_next;
+        io.sstate->status = status;
+        io.sstate->pad = 0;
+      }
     }
+  }
+
+  // Device-resident streams: the ranked beams of this chunk, written where the next chunk's import_beams() reads them
+  // (what the reference's caller carries between partial_decode_beams calls, decoder.py:681-728). A beam whose open
+  // word the finalisation closed (force_next_word) gets a BR_FINAL emission node for that word.
+  CTC_HD void carry_beams(uint32_t n, bool fold) {
+CTC_UNROLL
+    for (int j = 0; j < SLB; ++j) {
+      if ((uint32_t)(j * 64) >= n) continue;
+      const uint32_t r = (uint32_t)(j * 64 + lane);
+      const bool mine = r < n;
+      uint32_t d = 0;
+      double lg = 0.0;
+      if (mine) {
+        const uint32_t idx = L.sel[r] & 0x7FFFFFFFu;
+        d = L.pool[idx * 3 + 2][1];
+        lg = bits_f64(q_lo(L.pool[idx * 3 + 1]));
+      }
+      const uint32_t meta1 = L.b32[d * R32 + W_META1];
+      const uint32_t pl = meta1 >> 16;
+      const bool closes = mine && fold && pl > 0;
+      const uint64_t cm = ctx.ballot(closes);
+      uint32_t e = emit_next + prefix_cnt(cm);
+      emit_next += (uint32_t)ctx.popc64(cm);
+      if (!mine) continue;
+      const ColdRec cr = cold_cur()[d];
+      uint32_t enode = L.b32[d * R32 + W_ENODE], depth = cr.depth;
+      if (closes) {
+        if (e >= io.emit_cap) {
+          status |= ST_EMIT_OVERFLOW;
+          e = io.emit_cap - 1;
+        }
+        *(u32x4a*)&io.emit_nodes[e] = mk4(enode, BR_FINAL << 16, (uint32_t)cr.pstart, (uint32_t)cr.pend);
+        enode = e;
+        depth += 1;
+      }
+      const TextNode& node = io.text_nodes[closes ? L.b32[d * R32 + W_CNODE] : L.b32[d * R32 + W_TNODE]];
+      ImportBeam& m = io.carry_out[r];
+      m.logit_score = lg;
+      m.raw_lm = node.raw_lm;
+      m.text_h = node.text_h;
+      m.part_h = fold ? 0ull : L.b64[d * R64 + F_PART];
+CTC_UNROLL
+      for (int k = 0; k < MAX_CTX; ++k) m.ring[k] = node.ring[k];
+      m.ring_cnt = node.ring_cnt;
+      m.hw_cnt = node.hw_cnt;
+      m.plen = fold ? 0u : pl;
+      m.last_char = fold ? NO_CHAR : (meta1 & 0xFFFFu);
+      m.m2 = fold ? EMPTY_PARTIAL_M2 : L.b32[d * R32 + W_META2];
+      m.word_id = fold ? 0u : L.b32[d * R32 + W_WID];
+      m.pstart = fold ? -1 : cr.pstart;
+      m.pend = fold ? -1 : cr.pend;
+      m.state.len = node.state.len;
+CTC_UNROLL
+      for (int k = 0; k < MAX_CTX; ++k) {
+        m.state.words[k] = node.state.words[k];
+        m.state.backoff[k] = node.state.backoff[k];
+      }
+      m.enode = enode;
+      m.depth = depth;
+      m.resident = 1u;
+    }
+    status = ctx.wave_or_u32(status);
   }
 
   CTC_HD void run() {

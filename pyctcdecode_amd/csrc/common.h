@@ -213,6 +213,17 @@ struct ImportBeam {  // 160 B
   uint32_t ring_cnt, hw_cnt, plen, last_char, m2, word_id;
   int32_t pstart, pend;
   LmState state;
+  // device-resident streams (ctcdec_stream_*): a beam carried over by the previous chunk's kernel (resident = 1) keeps
+  // its place in the stream's emission arena; a beam built by the host (0) is rooted in a fresh BR_IMPORT node
+  uint32_t enode;
+  uint32_t depth;  // emission nodes on its chain
+  uint32_t resident;
+};
+// what a device-resident stream keeps between chunks besides its carried beams and its emission arena
+struct StreamState {  // 16 B
+  uint32_t n_carry;    // beams the last chunk handed on (rank order)
+  uint32_t emit_next;  // first free node of the emission arena
+  uint32_t status;
   uint32_t pad;
 };
 

@@ -237,6 +237,233 @@ def _c_arrays(batch: _Batch):
     return (C.c_void_p * max(n, 1))(*batch.ptrs), (C.c_int32 * max(n, 1))(*batch.frames)
 
 
+class _DeviceStreams:
+    """n streams advancing together on the device (one ctcdec_stream handle) + what the Python side has to remember to
+    turn their beams into LMBeams on demand."""
+
+    def __init__(self, decoder: "BeamSearchDecoderCTC", n: int):
+        self.decoder = decoder
+        self.lib = decoder._lib
+        self.n = n
+        self.gen = 0
+        self.hot_key: Optional[Tuple[str, ...]] = None
+        self.params: Optional[B.Params] = None
+        self.memos: List[Dict[Any, Any]] = []
+        self.parents: Optional[List[List[Beam]]] = None  # the caller's beams of the last import
+        self.lists: List[Any] = []  # weak references to the lazy lists of the current generation
+        h = C.c_void_p()
+        self.lib.check(self.lib.dll.ctcdec_stream_open(decoder._handle, n, None, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                self.lib.dll.ctcdec_stream_close(h)
+            except Exception:  # pragma: no cover
+                pass
+            self.handle = None
+
+    def alive(self, decoder) -> bool:
+        return self.handle is not None and self.decoder is decoder
+
+    # -- the slow way in: beams the caller built or edited (decoder.py:681-728 takes any List[Beam]) -------------
+    def import_beams(self, beams_list, cached_lm_scores_list) -> None:
+        dec = self.decoder
+        n_lms = len(dec._members)
+        has_lm = n_lms > 0
+        vocab2idx = dec._vocab2idx
+        pieces: List[bytes] = []
+        pos = 0
+        total = sum(len(b) for b in beams_list)
+        arr = (B.BeamIn * max(total, 1))()
+        more = (B.LmState * max(total * (n_lms - 1), 1))() if n_lms > 1 else None  # model 1..'s states per beam
+        beam_off = np.zeros(self.n + 1, dtype=np.int64)
+        k = 0
+        parents = []
+        for u in range(self.n):
+            beams = list(beams_list[u])
+            parents.append(beams)
+            for beam in beams:
+                text = beam.text if not beam.next_word else (beam.text + " " + beam.next_word if beam.text else beam.next_word)
+                text = " ".join(text.split())
+                e = arr[k]
+                e.logit_score = float(beam.logit_score)
+                if has_lm:
+                    raw, state = dec._memo_entry(cached_lm_scores_list[u], text)
+                    if n_lms > 1:
+                        if not isinstance(state, MultiLanguageModelState) or len(state.states) != n_lms:
+                            raise AssertionError(
+                                f"Wrong input state type found. Expected MultiLanguageModelState of {n_lms}, got {type(state)}")
+                        parts = state.states
+                        for j in range(1, n_lms):
+                            more[k * (n_lms - 1) + j - 1] = parts[j].state.to_c()
+                        e.more_states = C.cast(C.byref(more, k * (n_lms - 1) * C.sizeof(B.LmState)), C.POINTER(B.LmState))
+                        state = parts[0]
+                    if not isinstance(state, KenlmState):
+                        raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(state)}")
+                    e.raw_lm_score = float(raw)
+                    e.lm_state = state.state.to_c()
+                if beam.last_char is None:
+                    e.last_char = -1
+                else:
+                    if beam.last_char not in vocab2idx:
+                        raise ValueError("beam.last_char %r is not a label of this decoder" % (beam.last_char,))
+                    e.last_char = vocab2idx[beam.last_char]
+                e.partial_start = int(beam.partial_frames[0])
+                e.partial_end_frame = int(beam.partial_frames[1])
+                tb = text.encode("utf-8")
+                pb = beam.partial_word.encode("utf-8")
+                e.text_begin, e.text_end = pos, pos + len(tb)
+                pos += len(tb)
+                e.partial_begin, e.partial_end = pos, pos + len(pb)
+                pos += len(pb)
+                pieces.append(tb)
+                pieces.append(pb)
+                k += 1
+            beam_off[u + 1] = k
+        blob = b"".join(pieces) or b"\0"
+        self.lib.check(self.lib.dll.ctcdec_stream_import(self.handle, arr, B.off_ptr(beam_off), blob, pos))
+        self.parents = parents
+
+    # -- results ---------------------------------------------------------------------------------------------------
+    def retire_lists(self) -> None:
+        """The device is about to move on: lists of the current generation that nobody has looked at become unreadable."""
+        self.gen += 1
+        self.lists = []
+
+    def lazy_lists(self) -> List[List[LMBeam]]:
+        import weakref
+
+        out = [_ResidentBeams(self, u, self.gen) for u in range(self.n)]
+        self.lists = [weakref.ref(x) for x in out]
+        return out
+
+    def fill_current(self) -> None:
+        """One native read materialises the beams of every stream (the lazy lists of this generation that are still alive)."""
+        dec = self.decoder
+        with dec._call_lock:
+            res = C.c_void_p()
+            self.lib.check(self.lib.dll.ctcdec_stream_read(self.handle, C.byref(self.params), C.byref(res)))
+            try:
+                got = self.unpack(res)
+            finally:
+                self.lib.dll.ctcdec_result_free(res)
+        for u, ref in enumerate(self.lists):
+            lst = ref()
+            if lst is not None and not lst._filled:
+                list.extend(lst, got[u])
+                lst._filled = True
+
+    def unpack(self, res) -> List[List[LMBeam]]:
+        dec = self.decoder
+        lib = self.lib
+        n = self.n
+        n_lms = len(dec._members)
+        has_lm = n_lms > 0
+        pk = B.Packed()
+        lib.check(lib.dll.ctcdec_result_pack(res, C.byref(pk)))
+        nb, nw = int(pk.n_beams), int(pk.n_words)
+        if nb == 0:
+            return [[] for _ in range(n)]
+        b_off = np.ctypeslib.as_array(pk.beam_off, shape=(n + 1,))
+        t_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
+        tblob = C.string_at(pk.text_blob, int(t_off[nb])) if t_off[nb] else b""
+        p_off = np.ctypeslib.as_array(pk.partial_off, shape=(nb + 1,))
+        pblob = C.string_at(pk.partial_blob, int(p_off[nb])) if p_off[nb] else b""
+        logit = np.ctypeslib.as_array(pk.logit_score, shape=(nb,))
+        lms = np.ctypeslib.as_array(pk.lm_score, shape=(nb,))
+        raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,))
+        src = np.ctypeslib.as_array(pk.src_beam, shape=(nb,))
+        lch = np.ctypeslib.as_array(pk.last_char, shape=(nb,))
+        ps = np.ctypeslib.as_array(pk.partial_start, shape=(nb,))
+        pe = np.ctypeslib.as_array(pk.partial_end, shape=(nb,))
+        wco = np.ctypeslib.as_array(pk.word_cnt_off, shape=(nb + 1,))
+        if nw:
+            wstart = np.ctypeslib.as_array(pk.word_start, shape=(nw,))
+            wend = np.ctypeslib.as_array(pk.word_end, shape=(nw,))
+        out: List[List[LMBeam]] = []
+        for u in range(n):
+            outs = []
+            memo = self.memos[u] if u < len(self.memos) else {}
+            for j in range(int(b_off[u]), int(b_off[u + 1])):
+                text = tblob[int(t_off[j]) : int(t_off[j + 1])].decode("utf-8")
+                partial = pblob[int(p_off[j]) : int(p_off[j + 1])].decode("utf-8")
+                new_frames = [(int(wstart[w]), int(wend[w])) for w in range(int(wco[j]), int(wco[j + 1]))]
+                if src[j] >= 0 and self.parents is not None:  # decoded below one of the caller's own beams
+                    new_frames = list(self.parents[u][int(src[j])].text_frames) + new_frames
+                last = None if lch[j] < 0 else dec._idx2vocab[int(lch[j])]
+                outs.append(LMBeam(text, "", partial, last, new_frames, (int(ps[j]), int(pe[j])), float(logit[j]), float(lms[j])))
+                if has_lm and (text, False) not in memo:
+                    state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[j]))
+                    if n_lms > 1:
+                        parts = [state]
+                        for x in range(1, n_lms):
+                            cst = B.LmState()
+                            lib.check(lib.dll.ctcdec_result_lm_state_of(res, u, j - int(b_off[u]), x, C.byref(cst)))
+                            parts.append(KenlmState(NgramState.from_c(cst)))
+                        state = MultiLanguageModelState(parts)
+                    memo[(text, False)] = (float(raw[j]), float(raw[j]), state)
+            out.append(outs)
+        return out
+
+
+class _ResidentBeams(list):
+    """The LMBeams of one stream after a chunk, still on the device: an ordinary list that fills itself the first time it
+    is looked at. Handed back unchanged to partial_decode_beams(_batch) it is never filled at all."""
+
+    def __init__(self, streams: _DeviceStreams, index: int, gen: int):
+        super().__init__()
+        self._streams = streams
+        self._index = index
+        self._gen = gen
+        self._filled = False
+        self._edited = False
+
+    def _current(self) -> bool:
+        return not self._edited and self._gen == self._streams.gen
+
+    def _fill(self) -> None:
+        if self._filled:
+            return
+        if self._gen != self._streams.gen:
+            raise RuntimeError(
+                "these beams were handed back to partial_decode_beams and the stream has moved on: read them before the "
+                "next call, or keep list(beams) (CTCDEC_RESIDENT_STREAMS=0 returns plain lists every time)")
+        self._streams.fill_current()
+
+    def _touch(self) -> None:
+        self._fill()
+        self._edited = True
+
+
+def _reader(name):
+    def method(self, *a, **k):
+        self._fill()
+        return getattr(list, name)(self, *a, **k)
+
+    method.__name__ = name
+    return method
+
+
+def _writer(name):
+    def method(self, *a, **k):
+        self._touch()
+        return getattr(list, name)(self, *a, **k)
+
+    method.__name__ = name
+    return method
+
+
+for _n in ("__len__", "__iter__", "__getitem__", "__contains__", "__repr__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__",
+           "__ge__", "__add__", "__mul__", "__rmul__", "__reversed__", "index", "count", "copy"):
+    setattr(_ResidentBeams, _n, _reader(_n))
+for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort",
+           "reverse"):
+    setattr(_ResidentBeams, _n, _writer(_n))
+_ResidentBeams.__hash__ = None  # type: ignore[assignment]
+
+
 class BeamSearchDecoderCTC:
     # The reference parks the language model in a class-level dict keyed by 16 random bytes so that
     # fork-pool children find it (decoder.py:262-269); the container and its clean-up functions
@@ -674,7 +901,15 @@ class BeamSearchDecoderCTC:
         is_end: bool = False,
     ) -> List[List[LMBeam]]:
         """Many independent streams advanced by one chunk each in ONE device launch (extension of
-        partial_decode_beams, decoder.py:681-728; one workgroup per stream)."""
+        partial_decode_beams, decoder.py:681-728).
+
+        The streams are device-resident (ctcdec_stream_*): the beams, their LM states and the words decoded so far stay
+        on the GPU between chunks. What comes back is, per stream, a list of LMBeam that fills itself the first time it
+        is looked at; handed back unchanged in the next call (the reference's own usage pattern) it never has to, and a
+        chunk costs two kernel launches. Lists that are built or edited by the caller -- and everything under
+        CTCDEC_RESIDENT_STREAMS=0 -- go the reference's way: the host resolves every beam's strings for the device.
+        One caveat of the lazy lists: beams that were handed back can only be read until that next call returns its
+        own (the device state has moved on); read them first, or keep ``list(beams)``."""
         with self._call_lock:
             return self._partial_decode_beams_batch_locked(
                 logits_list, cached_lm_scores_list, cached_p_lm_scores_list, beams_list, processed_frames_list,
@@ -685,6 +920,8 @@ class BeamSearchDecoderCTC:
         beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_scorer, force_next_word, is_end,
     ) -> List[List[LMBeam]]:
         n = len(logits_list)
+        if n == 0:
+            return []
         for logits in logits_list:
             self._check_logits_dimension(logits)
         if hotword_scorer is not None and not isinstance(hotword_scorer, HotwordScorer):
@@ -696,127 +933,47 @@ class BeamSearchDecoderCTC:
             blob, off = B.pack_strings(unigrams)
             self._lib.check(self._lib.dll.ctcdec_set_hotwords(self._handle, blob, B.off_ptr(off), len(unigrams)))
             self._hot_key = key
-        n_lms = len(self._members)
-        has_lm = n_lms > 0
-        vocab2idx = self._vocab2idx
-        pieces: List[bytes] = []
-        pos = 0
-        total = sum(len(b) for b in beams_list)
-        arr = (B.BeamIn * max(total, 1))()
-        more = (B.LmState * max(total * (n_lms - 1), 1))() if n_lms > 1 else None  # model 1..'s states per beam
-        beam_off = np.zeros(n + 1, dtype=np.int64)
-        texts: List[List[str]] = []
-        k = 0
-        for u in range(n):
-            beams = beams_list[u]
-            if len(beams) == 0:
+        for beams in beams_list:
+            if not isinstance(beams, _ResidentBeams) and len(beams) == 0:
                 raise ValueError("a stream needs at least one beam (use get_starting_state())")
-            utt_texts = []
-            for beam in beams:
-                text = beam.text if not beam.next_word else (beam.text + " " + beam.next_word if beam.text else beam.next_word)
-                text = " ".join(text.split())
-                utt_texts.append(text)
-                e = arr[k]
-                e.logit_score = float(beam.logit_score)
-                if has_lm:
-                    raw, state = self._memo_entry(cached_lm_scores_list[u], text)
-                    if n_lms > 1:
-                        if not isinstance(state, MultiLanguageModelState) or len(state.states) != n_lms:
-                            raise AssertionError(
-                                f"Wrong input state type found. Expected MultiLanguageModelState of {n_lms}, got {type(state)}")
-                        parts = state.states
-                        for j in range(1, n_lms):
-                            more[k * (n_lms - 1) + j - 1] = parts[j].state.to_c()
-                        e.more_states = C.cast(C.byref(more, k * (n_lms - 1) * C.sizeof(B.LmState)), C.POINTER(B.LmState))
-                        state = parts[0]
-                    if not isinstance(state, KenlmState):
-                        raise AssertionError(f"Wrong input state type found. Expected KenlmState, got {type(state)}")
-                    e.raw_lm_score = float(raw)
-                    e.lm_state = state.state.to_c()
-                if beam.last_char is None:
-                    e.last_char = -1
-                else:
-                    if beam.last_char not in vocab2idx:
-                        raise ValueError("beam.last_char %r is not a label of this decoder" % (beam.last_char,))
-                    e.last_char = vocab2idx[beam.last_char]
-                e.partial_start = int(beam.partial_frames[0])
-                e.partial_end_frame = int(beam.partial_frames[1])
-                tb = text.encode("utf-8")
-                pb = beam.partial_word.encode("utf-8")
-                e.text_begin, e.text_end = pos, pos + len(tb)
-                pos += len(tb)
-                e.partial_begin, e.partial_end = pos, pos + len(pb)
-                pos += len(pb)
-                pieces.append(tb)
-                pieces.append(pb)
-                k += 1
-            texts.append(utt_texts)
-            beam_off[u + 1] = k
-        blob = b"".join(pieces) or b"\0"
         params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, weight, 0)
+        lazy_ok = os.environ.get("CTCDEC_RESIDENT_STREAMS", "1") != "0"
+        # which device streams do these beams belong to?
+        streams: Optional[_DeviceStreams] = None
+        first = beams_list[0]
+        if (isinstance(first, _ResidentBeams) and first._streams.alive(self) and first._streams.n == n and
+                first._streams.hot_key == key and
+                all(isinstance(b, _ResidentBeams) and b._streams is first._streams and b._index == u and b._current()
+                    for u, b in enumerate(beams_list))):
+            streams = first._streams  # handed back unchanged: nothing to import
+        elif all(len(b) == 1 and b[0] == EMPTY_START_BEAM for b in beams_list):
+            streams = _DeviceStreams(self, n)  # the reference's starting state
+        else:
+            # built or edited by the caller (or fed to another call in between): the host resolves their strings
+            streams = _DeviceStreams(self, n)
+            streams.import_beams(beams_list, cached_lm_scores_list)
+        streams.hot_key = key
         batch = _Batch(logits_list, len(self._idx2vocab))
         if batch.is_device and batch.device_index is not None and batch.device_index != self._device:
             raise ValueError("the logits live on cuda:%d but this decoder was built for cuda:%d (one process per GPU: "
                              "LOCAL_RANK / CTCDEC_DEVICE pick the device)" % (batch.device_index, self._device))
         ptrs, frames = _c_arrays(batch)
-        first = (C.c_int32 * max(n, 1))(*[int(p) for p in processed_frames_list])
+        first_frames = (C.c_int32 * n)(*[int(p) for p in processed_frames_list])
+        want = bool(is_end) or not lazy_ok
         res = C.c_void_p()
-        self._lib.check(
-            self._lib.dll.ctcdec_decode_stream_batch(
-                self._handle, ptrs, frames, n, batch.dtype, int(batch.is_device), C.byref(params), first, arr,
-                B.off_ptr(beam_off), blob, int(bool(force_next_word)), int(bool(is_end)), C.byref(res))
-        )
+        streams.retire_lists()
+        self._lib.check(self._lib.dll.ctcdec_stream_push(
+            streams.handle, ptrs, frames, batch.dtype, int(batch.is_device), C.byref(params), first_frames,
+            int(bool(force_next_word)), int(bool(is_end)), int(want), C.byref(res)))
+        streams.params = params
+        streams.memos = list(cached_lm_scores_list)
         try:
-            pk = B.Packed()
-            self._lib.check(self._lib.dll.ctcdec_result_pack(res, C.byref(pk)))
-            nb, nw = int(pk.n_beams), int(pk.n_words)
-            out: List[List[LMBeam]] = []
-            if nb == 0:
-                return [[] for _ in range(n)]
-            b_off = np.ctypeslib.as_array(pk.beam_off, shape=(n + 1,))
-            t_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
-            tblob = C.string_at(pk.text_blob, int(t_off[nb])) if t_off[nb] else b""
-            p_off = np.ctypeslib.as_array(pk.partial_off, shape=(nb + 1,))
-            pblob = C.string_at(pk.partial_blob, int(p_off[nb])) if p_off[nb] else b""
-            logit = np.ctypeslib.as_array(pk.logit_score, shape=(nb,))
-            lms = np.ctypeslib.as_array(pk.lm_score, shape=(nb,))
-            raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,))
-            src = np.ctypeslib.as_array(pk.src_beam, shape=(nb,))
-            lch = np.ctypeslib.as_array(pk.last_char, shape=(nb,))
-            ps = np.ctypeslib.as_array(pk.partial_start, shape=(nb,))
-            pe = np.ctypeslib.as_array(pk.partial_end, shape=(nb,))
-            wco = np.ctypeslib.as_array(pk.word_cnt_off, shape=(nb + 1,))
-            if nw:
-                wstart = np.ctypeslib.as_array(pk.word_start, shape=(nw,))
-                wend = np.ctypeslib.as_array(pk.word_end, shape=(nw,))
-            for u in range(n):
-                outs = []
-                memo = cached_lm_scores_list[u]
-                for j in range(int(b_off[u]), int(b_off[u + 1])):
-                    text = tblob[int(t_off[j]) : int(t_off[j + 1])].decode("utf-8")
-                    partial = pblob[int(p_off[j]) : int(p_off[j + 1])].decode("utf-8")
-                    parent = beams_list[u][int(src[j])]
-                    new_frames = [(int(wstart[w]), int(wend[w])) for w in range(int(wco[j]), int(wco[j + 1]))]
-                    last = None if lch[j] < 0 else self._idx2vocab[int(lch[j])]
-                    outs.append(
-                        LMBeam(text, "", partial, last, list(parent.text_frames) + new_frames,
-                               (int(ps[j]), int(pe[j])), float(logit[j]), float(lms[j]))
-                    )
-                    if has_lm and (text, False) not in memo:
-                        state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[j]))
-                        if n_lms > 1:
-                            parts = [state]
-                            for x in range(1, n_lms):
-                                cst = B.LmState()
-                                self._lib.check(self._lib.dll.ctcdec_result_lm_state_of(
-                                    res, u, j - int(b_off[u]), x, C.byref(cst)))
-                                parts.append(KenlmState(NgramState.from_c(cst)))
-                            state = MultiLanguageModelState(parts)
-                        memo[(text, False)] = (float(raw[j]), float(raw[j]), state)
-                out.append(outs)
-            return out
+            if want:
+                return streams.unpack(res)
         finally:
-            self._lib.dll.ctcdec_result_free(res)
+            if res:
+                self._lib.dll.ctcdec_result_free(res)
+        return streams.lazy_lists()
 
     def partial_decode_beams(
         self,

@@ -55,6 +55,7 @@ void* alloc_host(size_t bytes, std::string* err) { return alloc(bytes, err); }
 void release_host(void* p) { free(p); }
 int h2d(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int d2h(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
+int d2d(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int zero(void* d, size_t n, std::string*) { memset(d, 0, n); return 0; }
 int sync(std::string*) { return 0; }
 void use_stream(int) {}
@@ -164,11 +165,21 @@ static void fill_io(const BeamArgs& a, int u, UttIO& io) {
   io.tok_pool_head = a.tok_pool_head;
   io.tok_pool_cap = a.tok_pool_cap;
   io.prof = nullptr;
-  io.imports = a.imports ? a.imports + a.import_off[u] : nullptr;
-  io.n_import = a.imports ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
-  io.import_xstates = (a.imports && a.import_xstates) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
+  io.imports = (a.imports && !a.resident_in) ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = (a.imports && !a.resident_in) ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+  io.import_xstates = (a.imports && a.import_xstates && !a.resident_in) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   io.cold = a.cold ? a.cold + (size_t)u * 2 * COLD_STRIDE : nullptr;
+  io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
+  io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (n_lms - 1) : nullptr;
+  io.sstate = a.sstate ? a.sstate + u : nullptr;
+  io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
+  io.want_out = a.want_out;
+  if (a.resident_in) {
+    io.imports = a.imports + (size_t)u * a.carry_stride;
+    io.n_import = (int32_t)a.sstate[u].n_carry;
+    io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * (n_lms - 1) : nullptr;
+  }
 }
 
 // one wavefront per utterance (beam_wave.h) on 64 cooperative fibers

@@ -1,0 +1,220 @@
+"""Device-resident streams (ctcdec_stream_*, the lazy lists of partial_decode_beams): CPU checks through the simulator build;
+the `-m gpu` twins at the bottom run the same scenarios on the HIP build. Reference: get_starting_state /
+partial_decode_beams, decoder.py:669-728, and its tests (tests/test_decoder.py:515-698)."""
+import numpy as np
+import pytest
+
+import synth
+from oracle.ctc_oracle import build_oracle
+from pyctcdecode_amd.alphabet import Alphabet
+from pyctcdecode_amd.language_model import HotwordScorer
+from tests.golden_util import LM_DIR, check_beams
+from tests.sim_util import sim_library  # noqa: F401
+
+LM = synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2)
+BPE = synth.make_bpe_vocab(LM.words, size=255)
+
+
+def _oracle_chunks(orc, x, cuts, **kw):
+    st = orc.get_starting_state()
+    out = None
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        with np.errstate(all="ignore"):
+            out = orc.partial_decode_beams(x[a:b].astype(np.float64), st, a, is_end=(b == cuts[-1]), **kw)
+    return out
+
+
+def _lm_beams(beams):
+    return [(b.text + "|" + b.partial_word, [(str(k), f) for k, f in enumerate(b.text_frames)] + [("p", b.partial_frames)],
+             b.logit_score, b.lm_score) for b in beams]
+
+
+def _oracle_beams(ob):
+    return [{"text": o.text + "|" + o.partial, "frames": [[str(k), int(f[0]), int(f[1])] for k, f in enumerate(o.tframes)]
+             + [["p", int(o.pframes[0]), int(o.pframes[1])]], "logit": o.logit, "lm": o.lm} for o in ob]
+
+
+def _scenario_unread_chunks(build, to_input, beam_width, labels, is_bpe):
+    """The reference's usage pattern -- beams = partial_decode_beams(chunk, ..., beams, ...) -- without ever looking at the
+    intermediate lists: nothing is materialised until the end, and the end equals the oracle's chunked decode."""
+    dec = build(labels, LM.path)
+    alpha = Alphabet.build_alphabet(labels)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, LM.path, None)
+    x = synth.d_words(3, 5, 180, labels, is_bpe, LM.words, LM.sentences, len(labels), boost=6.0).astype(np.float64)
+    cuts = [0, 50, 51, 120, 180]
+    kw = {"beam_width": beam_width, "prune_history": True}
+    beams, c1, c2 = dec.get_starting_state()
+    seen = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        beams = dec.partial_decode_beams(to_input(x[a:b]), c1, c2, beams, a, is_end=(b == 180), **kw)
+        seen.append(beams)
+    from pyctcdecode_amd.decoder import _ResidentBeams
+
+    assert all(isinstance(s, _ResidentBeams) and not s._filled for s in seen[:-1])  # never looked at, never built
+    assert not isinstance(seen[-1], _ResidentBeams)
+    check_beams(_lm_beams(beams), _oracle_beams(_oracle_chunks(orc, x, cuts, **kw)), what="unread chunks")
+    with pytest.raises(RuntimeError):  # the stream has moved on
+        len(seen[0])
+    return dec
+
+
+def _scenario_reads_edits_and_hotwords(build, to_input):
+    """Lists that are read stay valid and can still be handed back; edited lists, lists of another stream and a changed
+    hot-word set go through the host import -- every route equals the oracle."""
+    labels = synth.LIBRI_LABELS
+    dec = build(labels, LM.path)
+    alpha = Alphabet.build_alphabet(labels)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, LM.path, None)
+    x = synth.d_words(2, 9, 90, labels, False, LM.words, LM.sentences, 28, boost=6.0).astype(np.float64)
+    hot = LM.hotwords(4, 1)
+    scorer = HotwordScorer.build_scorer(hot, weight=8.0)
+    cuts = [0, 30, 60, 90]
+    # (a) read every chunk, hand the same list back
+    beams, c1, c2 = dec.get_starting_state()
+    st = orc.get_starting_state()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        beams = dec.partial_decode_beams(to_input(x[a:b]), c1, c2, beams, a, is_end=(b == 90), hotword_scorer=scorer)
+        with np.errstate(all="ignore"):
+            ob = orc.partial_decode_beams(x[a:b], st, a, is_end=(b == 90), hotwords=hot, hotword_weight=8.0)
+        check_beams(_lm_beams(beams), _oracle_beams(ob), what="read %d:%d" % (a, b))
+    # (b) keep only the best 7 beams after the first chunk (an edited list: host import), then go on
+    beams, c1, c2 = dec.get_starting_state()
+    st = orc.get_starting_state()
+    beams = dec.partial_decode_beams(to_input(x[:30]), c1, c2, beams, 0)
+    with np.errstate(all="ignore"):
+        orc.partial_decode_beams(x[:30], st, 0)
+    beams = beams[:7]
+    st.beams = st.beams[:7]
+    beams = dec.partial_decode_beams(to_input(x[30:60]), c1, c2, beams, 30)
+    with np.errstate(all="ignore"):
+        ob = orc.partial_decode_beams(x[30:60], st, 30)
+    check_beams(_lm_beams(beams), _oracle_beams(ob), what="edited list")
+    # (c) ... and resident again from there, with force_next_word in the middle of the stream
+    beams = dec.partial_decode_beams(to_input(x[60:75]), c1, c2, beams, 60, force_next_word=True)
+    with np.errstate(all="ignore"):
+        ob = orc.partial_decode_beams(x[60:75], st, 60, force_next_word=True)
+    check_beams(_lm_beams(beams), _oracle_beams(ob), what="force_next_word")
+    beams = dec.partial_decode_beams(to_input(x[75:]), c1, c2, beams, 75, is_end=True)
+    with np.errstate(all="ignore"):
+        ob = orc.partial_decode_beams(x[75:], st, 75, is_end=True)
+    check_beams(_lm_beams(beams), _oracle_beams(ob), what="after force_next_word")
+
+
+def _scenario_many_streams_long(build, to_input, n_streams, n_chunks, chunk, beam_width):
+    """Several streams in one launch per chunk, enough chunks for the emission arena to grow; compared with the unchunked
+    decode of the same utterances (and stream 0 with the oracle)."""
+    dec = build(BPE, LM.path)
+    T = n_chunks * chunk
+    xs = [synth.d_words(5, u, T, BPE, True, LM.words, LM.sentences, len(BPE), boost=6.0).astype(np.float64) for u in range(n_streams)]
+    states = [dec.get_starting_state() for _ in range(n_streams)]
+    beams = [s[0] for s in states]
+    for k in range(n_chunks):
+        beams = dec.partial_decode_beams_batch([to_input(x[k * chunk:(k + 1) * chunk]) for x in xs], [s[1] for s in states],
+                                               [s[2] for s in states], beams, [k * chunk] * n_streams, beam_width=beam_width,
+                                               is_end=(k == n_chunks - 1))
+    whole = dec.decode_beams_batch(None, xs, beam_width=beam_width)
+    for u in range(n_streams):
+        assert [b.text for b in beams[u]] == [w.text for w in whole[u]]
+        assert [b.text_frames for b in beams[u]] == [[f[1] for f in w.text_frames] for w in whole[u]]
+        assert all(abs(b.lm_score - w.lm_score) < 1e-9 for b, w in zip(beams[u], whole[u]))
+    alpha = Alphabet.build_alphabet(BPE)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, LM.path, None)
+    exp = _oracle_chunks(orc, xs[0], [k * chunk for k in range(n_chunks + 1)], beam_width=beam_width)
+    check_beams(_lm_beams(beams[0]), _oracle_beams(exp), what="stream 0")
+
+
+def _build():
+    from pyctcdecode_amd import build_ctcdecoder
+
+    return build_ctcdecoder
+
+
+@pytest.mark.parametrize("beam_width,labels,is_bpe", [(40, synth.LIBRI_LABELS, False), (100, BPE, True), (200, BPE, True)])
+def test_unread_chunks_stay_on_the_device(beam_width, labels, is_bpe, sim_library, both_beam_kernels):  # noqa: F811
+    _scenario_unread_chunks(_build(), lambda a: a, beam_width, labels, is_bpe)
+
+
+def test_reads_edits_force_next_word_and_hotwords(sim_library, both_beam_kernels):  # noqa: F811
+    _scenario_reads_edits_and_hotwords(_build(), lambda a: a)
+
+
+def test_many_streams_and_a_growing_history(sim_library, both_beam_kernels):  # noqa: F811
+    _scenario_many_streams_long(_build(), lambda a: a, n_streams=5, n_chunks=12, chunk=25, beam_width=30)
+
+
+def test_plain_lists_on_request(sim_library, monkeypatch):  # noqa: F811
+    """CTCDEC_RESIDENT_STREAMS=0: every call returns ordinary, filled lists (and fills the caller's memo) like the reference."""
+    from pyctcdecode_amd.decoder import _ResidentBeams
+
+    monkeypatch.setenv("CTCDEC_RESIDENT_STREAMS", "0")
+    dec = _build()(synth.LIBRI_LABELS, LM.path)
+    x = synth.d_words(2, 1, 40, synth.LIBRI_LABELS, False, LM.words, LM.sentences, 28, boost=6.0)
+    beams, c1, c2 = dec.get_starting_state()
+    first = dec.partial_decode_beams(x[:20], c1, c2, beams, 0)
+    assert not isinstance(first, _ResidentBeams) and len(first) > 0 and (first[0].text, False) in c1
+    second = dec.partial_decode_beams(x[20:], c1, c2, first, 20, is_end=True)
+    assert first[0].text is not None and second[0].text == dec.decode_beams(x)[0].text
+
+
+def test_multi_lm_streams_are_resident_too(sim_library):  # noqa: F811
+    """Two language models (the workgroup kernel): the states of model 1.. ride along on the device."""
+    from tests import test_multi_lm as M
+
+    case = {"labels": BPE, "members": [{"lm": {"n_words": 300, "n_sent": 400, "order": 4, "seed": 2}},
+                                       {"lm": {"n_words": 200, "n_sent": 300, "order": 3, "seed": 3},
+                                        "build": {"alpha": 0.8, "beta": 1.0}}]}
+    dec, _ = M.build_product_multi(case)
+    orc = M.build_oracle_multi(case)
+    x = synth.d_words(4, 3, 90, BPE, True, LM.words, LM.sentences, len(BPE), boost=6.0).astype(np.float64)
+    cuts = [0, 31, 62, 90]
+    beams, c1, c2 = dec.get_starting_state()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        beams = dec.partial_decode_beams(x[a:b], c1, c2, beams, a, is_end=(b == 90), beam_width=50)
+    check_beams(_lm_beams(beams), _oracle_beams(_oracle_chunks(orc, x, cuts, beam_width=50)), what="multi")
+
+
+# ---- the same scenarios on the HIP build ---------------------------------------------------------------------------------
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beam_width,labels,is_bpe", [(40, synth.LIBRI_LABELS, False), (100, BPE, True), (200, BPE, True)])
+def test_hip_unread_chunks_stay_on_the_device(beam_width, labels, is_bpe, both_beam_kernels):
+    _scenario_unread_chunks(_build(), _dev, beam_width, labels, is_bpe)
+
+
+@pytest.mark.gpu
+def test_hip_reads_edits_force_next_word_and_hotwords(both_beam_kernels):
+    _scenario_reads_edits_and_hotwords(_build(), _dev)
+    _scenario_reads_edits_and_hotwords(_build(), lambda a: a)  # host chunks
+
+
+@pytest.mark.gpu
+def test_hip_many_streams_and_a_growing_history(both_beam_kernels):
+    _scenario_many_streams_long(_build(), _dev, n_streams=64, n_chunks=20, chunk=50, beam_width=200)
+
+
+@pytest.mark.gpu
+def test_hip_bench_n_gt_1_path_rehearsed_on_one_gpu():
+    """The N > 1 path of bench.py -- process group over RCCL (backend "nccl"), device binding by LOCAL_RANK, the one
+    all_gather of texts per step -- at world size 1 (CTC_BENCH_FORCE_DIST=1), weak and strong scaling."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for scaling in ("weak", "strong"):
+        env = dict(os.environ, CTC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+                   LOCAL_RANK="0")
+        env.pop("CTCDEC_BEAM_KERNEL", None)
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "192", "--frames", "200",
+                              "--steps", "2", "--warmup", "1", "--scaling", scaling], env=env, capture_output=True, text=True,
+                             timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 1 and line["scaling"] == scaling and line["value"] > 0
+        assert "RCCL all_gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
