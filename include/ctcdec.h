@@ -265,7 +265,7 @@ int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out
  * [0] frame-prune kernel, [1] beam kernel, [2] total device time incl. result copy */
 int ctcdec_result_timing(const ctcdec_result* r, double* ms3);
 /* which beam kernel produced the result: 1 = one wavefront per utterance (csrc/beam_wave.h: one language model
- * or none, beam_width <= 128, at most 160 survivors per frame), 2 = one workgroup per utterance
+ * or none, beam_width <= 128, at most 480 survivors per frame), 2 = one workgroup per utterance
  * (csrc/beam_core.h: everything else), 0 = empty batch. The environment variable CTCDEC_BEAM_KERNEL=group|wave
  * forces one of them (tests and tuning). */
 int ctcdec_result_beam_kernel(const ctcdec_result* r);

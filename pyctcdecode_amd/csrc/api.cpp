@@ -795,7 +795,9 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       need = std::max<uint64_t>(need, (uint64_t)rs->mirror[(size_t)u].emit_next + (uint64_t)utt_frames[u] * (uint64_t)B +
                                           (uint64_t)ctcdec_stream::CAP + 2);
     if (need > rs->emit_cap) {
-      const uint64_t cap = std::max<uint64_t>(need + need / 2, 4096);
+      // (sized for the worst case -- one node per frame and beam --, of which a real stream uses a few per cent: grow
+      // in big steps so that a long stream reallocates a handful of times)
+      const uint64_t cap = std::max<uint64_t>(std::max<uint64_t>(4 * need, 2 * rs->emit_cap), 4096);
       DevBuf grown;
       if (grown.ensure((size_t)n_utts * cap * sizeof(EmitNode), &err)) return fail(CTCDEC_ERR_DEVICE, err);
       for (int32_t u = 0; u < n_utts && rs->emit.p; ++u) {
@@ -1040,6 +1042,15 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     if (status[u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[u]) +
                                                         " for utterance " + std::to_string(u));
   if (!want_result) {  // a resident stream between reads: nothing to bring back
+    if (host_timing) {
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+      };
+      double pm = 0, bm = 0;
+      be::last_timing(&pm, &bm);
+      fprintf(stderr, "[ctcdec host] stream push: setup+prune+launch %.3f ms, wait beam kernel %.3f ms, total %.3f ms (prune kernel %.3f, beam kernel %.3f)\n",
+              ms(t_begin, t_launch), ms(t_launch, t_kernel), ms(t_begin, std::chrono::steady_clock::now()), pm, bm);
+    }
     be::last_timing(&res->ms[0], &res->ms[1]);
     res->beam_kernel = be::last_beam_kernel();
     res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1486,17 +1497,60 @@ int ctcdec_result_timing(const ctcdec_result* r, double* ms3) {
 }
 int ctcdec_result_beam_kernel(const ctcdec_result* r) { return r ? r->beam_kernel : 0; }
 int ctcdec_device(void) { return be::current_device(); }
-void ctcdec_result_free(ctcdec_result* r) {
-  if (!r) return;
-  // tearing down the per-beam strings and vectors of a large batch takes about as long as copying the results back
-  // from the device did: off the caller's thread
-  if (r->utts.size() >= 256) {
+// Tearing down the per-beam strings and vectors of a large batch takes about as long as copying the results back from
+// the device did: large results are handed to ONE reclaimer thread (started on first use, joined when the library is
+// unloaded or the process exits, so that no free can race static destruction).
+namespace {
+class Reclaimer {
+ public:
+  ~Reclaimer() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (worker_.joinable()) worker_.join();
+    for (ctcdec_result* r : queue_) delete r;
+  }
+  bool hand_over(ctcdec_result* r) {
     try {
-      std::thread([r] { delete r; }).detach();
-      return;
-    } catch (...) {  // no thread to be had: free it here (nothing may escape an extern "C" function)
+      std::lock_guard<std::mutex> g(m_);
+      if (stop_ || queue_.size() >= 64) return false;  // (a caller that frees faster than we reclaim: do it inline)
+      if (!worker_.joinable()) worker_ = std::thread([this] { loop(); });
+      queue_.push_back(r);
+    } catch (...) {  // no thread / no memory: the caller frees inline (nothing may escape an extern "C" function)
+      return false;
+    }
+    cv_.notify_one();
+    return true;
+  }
+
+ private:
+  void loop() {
+    for (;;) {
+      ctcdec_result* r = nullptr;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [this] { return stop_ || !queue_.empty(); });
+        if (queue_.empty()) return;  // (stop requested and nothing left)
+        r = queue_.back();
+        queue_.pop_back();
+      }
+      delete r;
     }
   }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<ctcdec_result*> queue_;
+  std::thread worker_;
+  bool stop_ = false;
+};
+Reclaimer g_reclaimer;
+}  // namespace
+
+void ctcdec_result_free(ctcdec_result* r) {
+  if (!r) return;
+  if (r->utts.size() >= 256 && g_reclaimer.hand_over(r)) return;
   delete r;
 }
 

@@ -501,6 +501,9 @@ class BeamSearchDecoderCTC:
                                   self._device, C.byref(handle))
         )
         self._handle = handle
+        # the device the library actually bound (one visible GPU per rank under SLURM / HIP_VISIBLE_DEVICES: LOCAL_RANK may
+        # exceed the device count and the library falls back to device 0)
+        self._device = int(lib.dll.ctcdec_device())
         if len(members) == 1:
             lib.check(lib.dll.ctcdec_lm_share(handle, members[0]._kenlm_model._handle))
         elif len(members) > 1:

@@ -218,3 +218,28 @@ def test_hip_bench_n_gt_1_path_rehearsed_on_one_gpu():
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 1 and line["scaling"] == scaling and line["value"] > 0
         assert "RCCL all_gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
+
+
+def test_more_carried_beams_than_the_wave_table_holds(sim_library, monkeypatch):  # noqa: F811
+    """A chunk decoded with beam_width 128 hands on up to 128 beams; the next one asks for beam_width 100, whose one-wave
+    table holds 100 records: the launch has to fall back to the workgroup kernel instead of overrunning the table
+    (round-2 advisor finding), resident and host-imported alike."""
+    monkeypatch.setenv("CTCDEC_BEAM_KERNEL", "wave")
+    labels = synth.LIBRI_LABELS
+    dec = _build()(labels)
+    alpha = Alphabet.build_alphabet(labels)
+    orc = build_oracle(alpha.labels, alpha.is_bpe)
+    x = synth.d_flat(2, 77, 24, 29).astype(np.float64)  # flat rows: the beam is full after a few frames
+    for edit in (False, True):
+        beams, c1, c2 = dec.get_starting_state()
+        st = orc.get_starting_state()
+        beams = dec.partial_decode_beams(x[:12], c1, c2, beams, 0, beam_width=128, beam_prune_logp=-30.0)
+        with np.errstate(all="ignore"):
+            orc.partial_decode_beams(x[:12], st, 0, beam_width=128, beam_prune_logp=-30.0)
+        assert len(st.beams) > 100
+        if edit:
+            beams = list(beams)  # a plain list: the host import path
+        beams = dec.partial_decode_beams(x[12:], c1, c2, beams, 12, beam_width=100, beam_prune_logp=-30.0, is_end=True)
+        with np.errstate(all="ignore"):
+            ob = orc.partial_decode_beams(x[12:], st, 12, beam_width=100, beam_prune_logp=-30.0, is_end=True)
+        check_beams(_lm_beams(beams), _oracle_beams(ob), what="carry 128 -> 100")
