@@ -520,8 +520,56 @@ CTC_UNROLL
     return np;
   }
 
-  // keep only the best beam_width pool entries (exact: pruning is monotone)
+  // Make room in the pool: keep (a little more than) its best beam_width entries -- exact, pruning is monotone (SURVEY
+  // App. G). Nothing has to be RANKED for that: a bisection on the score key finds a cut K with beam_width <= #(key <= K)
+  // <= beam_width + 8 (a dozen ballots instead of a walk of every entry against every other), the entries behind the cut
+  // are dropped in place, and from then on only a candidate that beats K can still matter: later candidates arrive
+  // later, so an equal score ranks behind the >= beam_width entries kept here. (Many exactly equal scores around the
+  // cut: the full ranking decides.)
   CTC_HD void compact_pool() {
+    filter_pool(key_to_score(runmax) + prm.beam_prune_logp);
+    const uint32_t n = pool_n, want = (uint32_t)prm.beam_width;
+    if (n <= want) {
+      tick<W_PROF_COMPACT>();
+      return;
+    }
+    uint64_t key[PE];
+    uint64_t worst = 0, best_inv = 0;
+CTC_UNROLL
+    for (int k = 0; k < PE; ++k) {
+      const uint32_t e = (uint32_t)(k * 64 + lane);
+      key[k] = ~0ull;
+      if ((uint32_t)(k * 64) < n && e < n) {
+        key[k] = q_lo(L.pool[e * 3]);
+        if (key[k] > worst) worst = key[k];
+        if (~key[k] > best_inv) best_inv = ~key[k];
+      }
+    }
+    uint64_t lo = ~ctx.wave_max_u64(best_inv), hi = ctx.wave_max_u64(worst);  // #(key <= hi) = n > want
+    uint32_t cnt = n;
+    while (lo < hi) {
+      const uint64_t mid = lo + ((hi - lo) >> 1);
+      uint32_t c = 0;
+CTC_UNROLL
+      for (int k = 0; k < PE; ++k)
+        if ((uint32_t)(k * 64) < n) c += (uint32_t)ctx.popc64(ctx.ballot(key[k] <= mid));
+      if (c >= want) {
+        hi = mid;
+        cnt = c;
+        if (c <= want + 8u) break;
+      } else {
+        lo = mid + 1;
+      }
+    }
+    if (cnt > want + 8u) {  // (a pile of equal scores at the cut)
+      compact_pool_ranked();
+      return;
+    }
+    filter_pool(key_to_score(~hi));
+    kth_key = ~hi;  // (score key = ~ascending key)
+    tick<W_PROF_COMPACT>();
+  }
+  CTC_HD void compact_pool_ranked() {
     const double mx = key_to_score(runmax);
     uint32_t n = rank_pool(mx + prm.beam_prune_logp, false);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
@@ -532,9 +580,6 @@ CTC_UNROLL
       g0[j] = g1[j] = g2[j] = mk4(0, 0, 0, 0);
       if (r < n) {
         const uint32_t e = L.sel[r] & 0x7FFFFFFFu;
-#ifdef CTC_SIM_DEBUG
-        if (e >= (uint32_t)P) { fprintf(stderr, "compact: r=%u n=%u pool_n=%u sel=%x N=%d\n", r, n, pool_n, L.sel[r], N); abort(); }
-#endif
         g0[j] = L.pool[e * 3];
         g1[j] = L.pool[e * 3 + 1];
         g2[j] = L.pool[e * 3 + 2];
@@ -551,8 +596,6 @@ CTC_UNROLL
       }
     }
     pool_n = n;
-    // from now on only a candidate that beats the current beam_width-th best can still matter: later
-    // candidates arrive later, so an equal score ranks behind the beam_width entries kept here
     if (n >= (uint32_t)prm.beam_width) {
       const uint32_t r = n - 1;
       uint64_t k = 0;
@@ -859,18 +902,19 @@ CTC_UNROLL
     bool push = rep && score >= thr && my_key > kth_key;
     uint32_t cnt = (uint32_t)ctx.popc64(ctx.ballot(push));
     if (pool_n + cnt > (uint32_t)P) filter_pool(thr);  // room, the cheap way: entries the risen threshold has left behind
-    if (pool_n + cnt > (uint32_t)P) {
-      // The pool holds the best beam_width so far plus room for 32 more: make room (exact: pruning is monotone).
+    while (pool_n + cnt > (uint32_t)P) {
+      // The pool holds the best beam_width so far plus room for two dozen more: make room (exact: pruning is monotone),
+      // if need be in several parts.
       compact_pool();
       push = push && my_key > kth_key;
       const uint64_t m = ctx.ballot(push);
       cnt = (uint32_t)ctx.popc64(m);
-      if (pool_n + cnt > (uint32_t)P) {  // more than 32 at once: in two parts
-        const bool first = push && prefix_cnt(m) < (uint32_t)P - pool_n;
-        pool_put(first, e0, e1, e2);
+      if (pool_n + cnt > (uint32_t)P) {
+        const bool part = push && prefix_cnt(m) < (uint32_t)P - pool_n;
+        pool_put(part, e0, e1, e2);
         ctx.wsync();
-        compact_pool();
-        push = push && !first && my_key > kth_key;
+        push = push && !part;
+        cnt = (uint32_t)ctx.popc64(ctx.ballot(push));
       }
     }
     pool_put(push, e0, e1, e2);
