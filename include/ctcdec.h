@@ -59,6 +59,10 @@ typedef struct ctcdec_params {
   double log_base_change;    /* LOG_BASE_CHANGE_FACTOR       constants.py:18 */
   int32_t lm_score_boundary; /* language_model.py:269        */
   int32_t first_frame;       /* processed_frames offset      decoder.py:443  */
+  int32_t texts_only;        /* 0/1 (ctcdec_decode_batch with n_best = 1): only the best beam's TEXT is wanted
+                                (decode_batch, decoder.py:895-945) -- it is assembled on the device and the result holds
+                                one beam per utterance with its text and scores, no word frames and no LM state */
+  int32_t reserved;
 } ctcdec_params;
 
 /* LM start state for one utterance (decode_beams(lm_start_state=...), decoder.py:621-625):

@@ -33,6 +33,8 @@ class Params(C.Structure):
         ("log_base_change", C.c_double),
         ("lm_score_boundary", C.c_int32),
         ("first_frame", C.c_int32),
+        ("texts_only", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

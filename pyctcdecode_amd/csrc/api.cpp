@@ -195,14 +195,17 @@ struct ctcdec_decoder {
   HostBuf h_xstate;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
-      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold;
+      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_tscr, w_tsoff, w_tpool,
+      d_toktext, d_tokbytes;
+  uint32_t max_label_bytes = 1;
   HostBuf h_tok, h_out, h_small;
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
-                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold};
+                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold,
+                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
       d_xuni[k].drop();
@@ -227,6 +230,11 @@ struct ctcdec_result {
   std::string t_blob;
   std::vector<int64_t> t_off;
   std::string j_blob;  // ctcdec_result_texts_joined
+  // params.texts_only: the texts as the device wrote them (one block per utterance somewhere in dev_texts) and the
+  // output records; BeamResults are only built when an accessor other than ctcdec_result_texts_joined asks for them
+  bool device_texts = false;
+  std::string dev_texts;
+  std::vector<OutBeam> dev_out;  // [n_utts]
   // packed view (built on demand by ctcdec_result_pack)
   bool packed = false;
   std::vector<int64_t> beam_off, text_off, word_cnt_off;
@@ -273,6 +281,26 @@ static int sync_tables(ctcdec_decoder* d, std::string* err) {
     if (d->multi) fill_token_starts_from(d->multi->prefix_table, d->multi->prefix_mask, &d->alpha);
     else if (d->has_lm) d->lm_ref().fill_token_starts(&d->alpha);
     if (upload(d->d_tok, d->alpha.tok, err)) return -1;
+    {  // the labels' UTF-8 bytes, for the kernels that assemble texts themselves
+      std::vector<TokText> tt(d->alpha.labels.size());
+      std::string bytes;
+      uint32_t longest = 1;
+      for (size_t i = 0; i < tt.size(); ++i) {
+        const std::string &raw = d->alpha.labels[i], &clean = d->alpha.clean[i];
+        tt[i].raw_off = (uint32_t)bytes.size();
+        tt[i].raw_len = (uint16_t)raw.size();
+        bytes += raw;
+        tt[i].clean_off = (uint32_t)bytes.size();
+        tt[i].clean_len = (uint16_t)clean.size();
+        bytes += clean;
+        tt[i].pad = 0;
+        longest = std::max<uint32_t>(longest, (uint32_t)std::max(raw.size(), clean.size()));
+      }
+      std::vector<uint8_t> bv(bytes.begin(), bytes.end());
+      if (bv.empty()) bv.push_back(0);
+      if (upload(d->d_toktext, tt, err) || upload(d->d_tokbytes, bv, err)) return -1;
+      d->max_label_bytes = longest;
+    }
     if (d->has_lm) {
       if (upload(d->d_uni, d->lm_ref().unigrams, err)) return -1;
       if (upload(d->d_ngr, d->lm_ref().ngram_table, err)) return -1;
@@ -303,6 +331,9 @@ static void device_tables(const ctcdec_decoder* d, DeviceTables* t) {
   if (d->has_lm) d->lm_ref().tables(t);
   t->tok = (const TokInfo*)d->d_tok.p;
   t->tok_hot = (const TokHot*)d->d_tok_hot.p;
+  t->tok_text = (const TokText*)d->d_toktext.p;
+  t->tok_bytes = (const uint8_t*)d->d_tokbytes.p;
+  t->max_label_bytes = d->max_label_bytes;
   if (d->has_lm) {
     t->unigrams = (const UnigramEntry*)d->d_uni.p;
     t->ngrams = (const NgramEntry*)d->d_ngr.p;
@@ -895,7 +926,10 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   dp.fold = stream ? stream->fold : 1;
   dp.eos = stream ? stream->eos : 1;
   dp.no_label_runs = getenv("CTCDEC_NO_LABEL_RUNS") != nullptr ? 1 : 0;
-  dp.pad_ = 0;
+  // decode_batch: the kernels assemble the best beam's text themselves (CTCDEC_HOST_REPLAY=1: the emission lists come
+  // back and the host replays them, as for every other call)
+  const bool device_texts = p->texts_only != 0 && n_best == 1 && !stream && getenv("CTCDEC_HOST_REPLAY") == nullptr;
+  dp.texts_only = device_texts ? 1 : 0;
   ba.n_utts = n_utts;
   ba.utt_row0 = (const int64_t*)dec->w_row0.p;
   ba.surv_cnt = (const uint32_t*)dec->w_scnt.p;
@@ -921,6 +955,23 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.first_frames = stream ? (const int32_t*)dec->w_ff.p : nullptr;
   ba.cold = (ColdRec*)dec->w_cold.p;
   ba.max_import = max_import;
+  ba.text_scratch = nullptr;
+  ba.text_soff = nullptr;
+  ba.text_pool = nullptr;
+  ba.text_pool_cap = 0;
+  if (device_texts) {
+    // scratch per utterance: at most one emission per frame, each a label and a separator
+    std::vector<uint64_t> soff((size_t)n_utts + 1, 0);
+    for (int32_t u = 0; u < n_utts; ++u)
+      soff[(size_t)u + 1] = soff[(size_t)u] + (((uint64_t)utt_frames[u] + 2) * (uint64_t)(dec->max_label_bytes + 1) + 15) / 16 * 16;
+    if (dec->w_tscr.ensure((size_t)soff[(size_t)n_utts] + 16, &err) || dec->w_tpool.ensure((size_t)soff[(size_t)n_utts] + 16, &err) ||
+        upload(dec->w_tsoff, soff, &err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    ba.text_scratch = (uint8_t*)dec->w_tscr.p;
+    ba.text_soff = (const uint64_t*)dec->w_tsoff.p;
+    ba.text_pool = (uint8_t*)dec->w_tpool.p;
+    ba.text_pool_cap = soff[(size_t)n_utts];
+  }
   ba.carry_out = nullptr;
   ba.carry_xstates = nullptr;
   ba.sstate = nullptr;
@@ -1041,6 +1092,29 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   for (int32_t u = 0; u < n_utts; ++u)
     if (status[u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[u]) +
                                                         " for utterance " + std::to_string(u));
+  if (device_texts) {  // one block of text per utterance, written by the kernels
+    unsigned long long heads[2] = {0, 0};
+    if (be::d2h(heads, dec->w_head.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    res->device_texts = true;
+    res->dev_out.resize((size_t)n_utts);
+    res->dev_texts.resize((size_t)heads[1]);
+    if (be::d2h(res->dev_out.data(), dec->w_out.p, (size_t)n_utts * sizeof(OutBeam), &err) ||
+        (heads[1] && be::d2h(&res->dev_texts[0], dec->w_tpool.p, (size_t)heads[1], &err)))
+      return fail(CTCDEC_ERR_DEVICE, err);
+    for (int32_t u = 0; u < n_utts; ++u) {
+      const OutBeam& ob = res->dev_out[(size_t)u];
+      if (n_out[u] != 1 || (unsigned long long)ob.tok_off + ob.tok_cnt > heads[1]) return fail(CTCDEC_ERR_INTERNAL, "text pool range");
+    }
+    be::last_timing(&res->ms[0], &res->ms[1]);
+    res->beam_kernel = be::last_beam_kernel();
+    if (dec->profile && be::d2h(dec->prof, dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (host_timing)
+      fprintf(stderr, "[ctcdec host] texts from the device: %llu bytes, native call %.3f ms (kernels %.3f + %.3f)\n", heads[1], res->ms[2],
+              res->ms[0], res->ms[1]);
+    *out = res.release();
+    return CTCDEC_OK;
+  }
   if (!want_result) {  // a resident stream between reads: nothing to bring back
     if (host_timing) {
       auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -1300,12 +1374,34 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   return CTCDEC_OK;
 }
 
+// a texts-only result (params.texts_only) as ordinary beams, for the accessors that want them
+static void materialise(const ctcdec_result* cr) {
+  ctcdec_result* r = const_cast<ctcdec_result*>(cr);
+  if (!r || !r->device_texts || r->dev_out.empty()) return;
+  for (size_t u = 0; u < r->dev_out.size(); ++u) {
+    const OutBeam& ob = r->dev_out[u];
+    r->utts[u].resize(1);
+    BeamResult& b = r->utts[u][0];
+    b.text.assign(r->dev_texts, ob.tok_off, ob.tok_cnt);
+    b.logit = ob.logit_score;
+    b.lm = ob.lm_score;
+    b.state.length = -1;
+    for (int j = 0; j < MAX_CTX; ++j) {
+      b.state.words[j] = 0;
+      b.state.backoff[j] = 0.f;
+    }
+    b.word_off.assign(1, (int32_t)b.text.size());
+  }
+  r->dev_out.clear();
+}
 int32_t ctcdec_result_num_utts(const ctcdec_result* r) { return r ? (int32_t)r->utts.size() : 0; }
 int32_t ctcdec_result_num_beams(const ctcdec_result* r, int32_t utt) {
+  materialise(r);
   if (!r || utt < 0 || (size_t)utt >= r->utts.size()) return 0;
   return (int32_t)r->utts[(size_t)utt].size();
 }
 static const BeamResult* get_beam(const ctcdec_result* r, int32_t utt, int32_t beam) {
+  materialise(r);
   if (!r || utt < 0 || (size_t)utt >= r->utts.size()) return nullptr;
   const auto& b = r->utts[(size_t)utt];
   if (beam < 0 || (size_t)beam >= b.size()) return nullptr;
@@ -1356,6 +1452,7 @@ int ctcdec_result_lm_state_of(const ctcdec_result* r, int32_t utt, int32_t beam,
 // 4096-utterance batch costs more than copying its results back from the device)
 int ctcdec_result_texts(ctcdec_result* r, const char** blob_out, const int64_t** off_out, int64_t* n_out) {
   if (!r || !blob_out || !off_out || !n_out) return fail(CTCDEC_ERR_ARG, "no result");
+  materialise(r);
   if (!r->texts_packed) {
     size_t nb = 0, bytes = 0;
     for (const auto& beams : r->utts)
@@ -1383,6 +1480,18 @@ int ctcdec_result_texts(ctcdec_result* r, const char** blob_out, const int64_t**
 
 int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out, int64_t* bytes_out, int64_t* n_out) {
   if (!r || !blob_out || !bytes_out || !n_out) return fail(CTCDEC_ERR_ARG, "no result");
+  if (r->device_texts && !r->dev_out.empty()) {  // straight from the blocks the device wrote
+    r->j_blob.clear();
+    r->j_blob.reserve(r->dev_texts.size() + r->dev_out.size());
+    for (size_t u = 0; u < r->dev_out.size(); ++u) {
+      if (u) r->j_blob += sep;
+      r->j_blob.append(r->dev_texts, r->dev_out[u].tok_off, r->dev_out[u].tok_cnt);
+    }
+    *blob_out = r->j_blob.data();
+    *bytes_out = (int64_t)r->j_blob.size();
+    *n_out = (int64_t)r->dev_out.size();
+    return CTCDEC_OK;
+  }
   size_t nb = 0, bytes = 0;
   for (const auto& beams : r->utts)
     for (const BeamResult& b : beams) {
@@ -1405,6 +1514,7 @@ int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out
 
 int ctcdec_result_pack(ctcdec_result* r, ctcdec_packed* out) {
   if (!r || !out) return fail(CTCDEC_ERR_ARG, "no result");
+  materialise(r);
   if (!r->packed) {
     size_t nb = 0, nw = 0, tb = 0;
     for (const auto& beams : r->utts)

@@ -102,6 +102,12 @@ struct BeamArgs {
   StreamState* sstate;
   int32_t carry_stride;
   int32_t want_out;            // 0: no output records / emission lists for this launch (resident streams between reads)
+  // texts assembled on the device (params.texts_only), else nullptr: utterance u writes its text backwards from the end of
+  // text_scratch[text_soff[u] .. text_soff[u + 1]) and copies it to a block of text_pool taken from tok_pool_head[1]
+  uint8_t* text_scratch;
+  const uint64_t* text_soff;   // [n_utts + 1] (device)
+  uint8_t* text_pool;
+  unsigned long long text_pool_cap;
   int32_t resident_in;         // 1: `imports` is the carry buffer itself (stream u: imports + u * carry_stride, sstate[u].n_carry
                                // beams; import_xstates likewise), import_off is not used
 };

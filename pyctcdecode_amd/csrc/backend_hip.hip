@@ -697,16 +697,19 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
   const unsigned long long lt = (1ull << lane) - 1ull;
   if (!is_prob) {
     float mf = -INFINITY;
-    double rs = 0.0;
+    // The row sum only feeds utt_sniff's coarse "could these be probabilities?" test (|mean row sum - 1| <= 0.5; the exact
+    // test in numpy's own order is utt_sniff_exact's): each lane adds its <= 16 values in float32 (error < 2e-5 for
+    // logits up to +-20, nothing for probabilities), the wave sum is fp64.
+    float rsf = 0.f;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
       if (k * 64 + lane < n4) {
         mf = fmaxf(fmaxf(mf, fmaxf(r[k].x, r[k].y)), fmaxf(r[k].z, r[k].w));
-        rs += ((double)r[k].x + (double)r[k].y) + ((double)r[k].z + (double)r[k].w);
+        rsf += (r[k].x + r[k].y) + (r[k].z + r[k].w);
       }
     }
     double m = wave_max((double)mf);
-    rs = wave_sum(rs);
+    double rs = wave_sum((double)rsf);
     if (lane == 0) a.row_sum[row] = rs;
     // ---- the clean row (finite maximum, no NaN: -inf masks are fine): everything below in its cheapest form
     if (isfinite(m) && rs == rs) {
@@ -983,6 +986,11 @@ __global__ __launch_bounds__(NT, 2) void beam_decode(BeamArgs a, int surv_cap) {
   io.sstate = a.sstate ? a.sstate + u : nullptr;
   io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
   io.want_out = a.want_out;
+  io.text_scratch = a.text_scratch ? a.text_scratch + a.text_soff[u] : nullptr;
+  io.text_scratch_cap = a.text_scratch ? (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]) : 0u;
+  io.text_pool = a.text_pool;
+  io.text_pool_head = a.tok_pool_head + 1;
+  io.text_pool_cap = a.text_pool_cap;
   if (a.resident_in) {
     io.imports = a.imports + (size_t)u * a.carry_stride;
     io.n_import = (int32_t)a.sstate[u].n_carry;
@@ -1127,6 +1135,11 @@ __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   io.sstate = a.sstate ? a.sstate + u : nullptr;
   io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
   io.want_out = a.want_out;
+  io.text_scratch = a.text_scratch ? a.text_scratch + a.text_soff[u] : nullptr;
+  io.text_scratch_cap = a.text_scratch ? (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]) : 0u;
+  io.text_pool = a.text_pool;
+  io.text_pool_head = a.tok_pool_head + 1;
+  io.text_pool_cap = a.text_pool_cap;
   if (a.resident_in) {
     io.imports = a.imports + (size_t)u * a.carry_stride;
     io.n_import = (int32_t)a.sstate[u].n_carry;

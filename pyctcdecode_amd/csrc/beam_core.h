@@ -238,7 +238,43 @@ struct UttIO {
   StreamState* sstate;
   uint32_t emit_start;
   int32_t want_out;
+  // texts assembled on the device (DecodeParams::texts_only): this utterance's scratch area (the text is written
+  // backwards from its end) and the pool the finished text is copied to
+  uint8_t* text_scratch;
+  uint32_t text_scratch_cap;
+  uint8_t* text_pool;
+  unsigned long long* text_pool_head;
+  unsigned long long text_pool_cap;
 };
+
+// ONE thread: the text of a beam (decoder.py:653-667: its words joined by single spaces) from its emission chain, leaf
+// to root, written backwards into scratch[.. cap); returns where it starts. Walking backwards a separator is due when a
+// word boundary (BR_BOUNDARY / BR_SPACE / BR_FINAL) has been passed since the last bytes and there are bytes to its right.
+CTC_HD uint32_t text_backwards(const UttIO& io, const DeviceTables& tab, uint32_t enode, uint8_t* scratch, uint32_t cap) {
+  uint32_t pos = cap;
+  bool emitted = false, pending = false;
+  for (uint32_t e = enode; e != 0;) {
+    const EmitNode en = io.emit_nodes[e];
+    const uint32_t br = en.tok_branch >> 16, tok = en.tok_branch & 0xFFFFu;
+    uint32_t off = 0, len = 0;
+    if (br == BR_APPEND) {
+      off = tab.tok_text[tok].raw_off;
+      len = tab.tok_text[tok].raw_len;
+    } else if (br == BR_BOUNDARY) {
+      off = tab.tok_text[tok].clean_off;
+      len = tab.tok_text[tok].clean_len;
+    }
+    if (len > 0) {
+      if (pending && emitted && pos > 0) scratch[--pos] = (uint8_t)' ';
+      pending = false;
+      for (uint32_t k = len; k > 0 && pos > 0; --k) scratch[--pos] = tab.tok_bytes[off + k - 1];
+      emitted = true;
+    }
+    if (br == BR_BOUNDARY || br == BR_SPACE || br == BR_FINAL) pending = true;
+    e = en.parent;
+  }
+  return pos;
+}
 constexpr int N_PROF = 24;
 
 // ---------------------------------------------------------------------------------------------
@@ -1744,6 +1780,46 @@ CTC_UNROLL
     if (io.carry_out && !eos) carry_beams(b, n, fold);
     uint32_t n_out = io.want_out ? n : 0u;
     if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
+    const bool texts = prm.texts_only != 0 && io.text_scratch != nullptr;
+    if (texts && n_out > 0) {  // decode_batch: the best beam's text, nothing else
+      n_out = 1;
+      if (ctx.tid == 0) {
+        const uint32_t idx = L.sel[0];
+        const int d = (int)L.p_don[idx];
+        const uint32_t pos = text_backwards(io, tab, b.emit_node[d], io.text_scratch, io.text_scratch_cap);
+        const uint32_t len = io.text_scratch_cap - pos;
+        unsigned long long base = ctx.global_add(io.text_pool_head, (unsigned long long)len);
+        if (base + len > io.text_pool_cap) {
+          L.scal[6] |= ST_TOK_OVERFLOW;
+          base = 0;
+        }
+        L.smax[1] = base;
+        L.scal[8] = pos;
+        OutBeam& ob = io.out[0];
+        ob.logit_score = L.p_logit[idx];
+        ob.lm_score = L.p_score[idx];
+        ob.raw_lm = 0.0;
+        ob.tok_off = (uint32_t)base;
+        ob.tok_cnt = (L.scal[6] & ST_TOK_OVERFLOW) ? 0u : len;
+        ob.state.len = -1;
+        ob.last_char = NO_CHAR;
+        ob.pstart = ob.pend = -1;
+        ob.pad[0] = (uint32_t)(base >> 32);
+        ob.pad[1] = 0;
+      }
+      ctx.sync_mem();
+      if (!(L.scal[6] & ST_TOK_OVERFLOW)) {
+        const uint32_t pos = L.scal[8], len = io.text_scratch_cap - pos;
+        const unsigned long long base = L.smax[1];
+        for (uint32_t k = ctx.tid; k < len; k += ctx.nt) io.text_pool[base + k] = io.text_scratch[pos + k];
+      }
+      ctx.sync();
+      if (ctx.tid == 0) {
+        *io.n_out = 1;
+        *io.status = L.scal[6];
+      }
+      return;
+    }
     // output records + back-trace of each returned beam's emission chain
     if (ctx.tid == 0) L.scal[8] = 0;
     ctx.sync();

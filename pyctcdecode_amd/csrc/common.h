@@ -155,6 +155,13 @@ struct TokInfo {  // 64 B
 };
 constexpr uint32_t PF_ON_TABLE = 8u;  // beam flag: the partial is a stored prefix
 
+// the UTF-8 bytes of a label, for the kernels that assemble decoded texts themselves (decode_batch)
+struct TokText {  // 16 B
+  uint32_t raw_off, clean_off;  // into DeviceTables::tok_bytes: the label as appended / without boundary marks
+  uint16_t raw_len, clean_len;
+  uint32_t pad;
+};
+
 struct TokHot {  // per call (hot words change per call): hot-word view of the CLEAN label
   uint32_t min_len;  // 0 = not a hot-word prefix
   uint32_t complete;
@@ -242,6 +249,10 @@ struct LmExtra {
 struct DeviceTables {
   const TokInfo* tok;
   const TokHot* tok_hot;
+  const TokText* tok_text;    // per label: where its bytes are
+  const uint8_t* tok_bytes;
+  uint32_t max_label_bytes;   // longest label, in bytes
+  uint32_t pad_text;
   const UnigramEntry* unigrams;
   const NgramEntry* ngrams;
   uint64_t ngram_mask;  // table size - 1 (0: no table)
@@ -277,7 +288,7 @@ struct DecodeParams {
   int32_t fold;      // finalisation closes the open word (force_next_word or is_end, decoder.py:570)
   int32_t eos;       // finalisation scores end of sentence (is_end, decoder.py:597)
   int32_t no_label_runs;  // diagnostics (CTCDEC_NO_LABEL_RUNS=1): every frame takes the full path
-  int32_t pad_;
+  int32_t texts_only;     // decode_batch: the best beam's text is assembled on the device, nothing else is returned
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -175,6 +175,11 @@ static void fill_io(const BeamArgs& a, int u, UttIO& io) {
   io.sstate = a.sstate ? a.sstate + u : nullptr;
   io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
   io.want_out = a.want_out;
+  io.text_scratch = a.text_scratch ? a.text_scratch + a.text_soff[u] : nullptr;
+  io.text_scratch_cap = a.text_scratch ? (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]) : 0u;
+  io.text_pool = a.text_pool;
+  io.text_pool_head = a.tok_pool_head + 1;
+  io.text_pool_cap = a.text_pool_cap;
   if (a.resident_in) {
     io.imports = a.imports + (size_t)u * a.carry_stride;
     io.n_import = (int32_t)a.sstate[u].n_carry;

@@ -334,3 +334,24 @@ def test_decode_batch_texts_with_awkward_labels(sim_library):  # noqa: F811
         texts = dec.decode_batch(None, xs)
         assert texts == [dec.decode(x) for x in xs]
         assert texts[1] == "" and texts[3] == ""
+
+
+@pytest.mark.parametrize("kind", ["char", "bpe"])
+def test_decode_batch_texts_come_from_the_device(kind, sim_library, both_beam_kernels, monkeypatch):  # noqa: F811
+    """decode_batch asks for texts only (ctcdec_params.texts_only): the kernels assemble each best beam's text themselves.
+    Same texts as the host replay of the emission lists (CTCDEC_HOST_REPLAY=1), as decode(), and as the other accessors
+    of the same result -- ragged batch, an empty utterance, BPE pieces with and without the boundary mark."""
+    from pyctcdecode_amd import build_ctcdecoder
+
+    labels = synth.LIBRI_LABELS if kind == "char" else BPE
+    dec = build_ctcdecoder(labels, LM.path)
+    xs = [synth.d_words(3, u, T, labels, kind == "bpe", LM.words, LM.sentences, len(labels) if kind == "bpe" else 28, boost=6.0)
+          for u, T in enumerate([40, 0, 1, 75, 13, 120])]
+    xs.append(synth.d_flat(3, 9, 30, xs[0].shape[1]))
+    hot = LM.hotwords(3, 1)
+    got = dec.decode_batch(None, xs, hotwords=hot)
+    monkeypatch.setenv("CTCDEC_HOST_REPLAY", "1")
+    assert dec.decode_batch(None, xs, hotwords=hot) == got
+    monkeypatch.delenv("CTCDEC_HOST_REPLAY")
+    assert got == [dec.decode(x, hotwords=hot) for x in xs]
+    assert got[1] == "" and all(t == " ".join(t.split()) for t in got)
