@@ -264,6 +264,10 @@ int ctcdec_result_texts(ctcdec_result* r, const char** blob_out, const int64_t**
  * language splits strings natively (Python: str.split) gets its n string objects in one call instead of n slices.
  * The caller picks a byte that cannot occur in a text (a label containing it rules this entry point out). */
 int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out, int64_t* bytes_out, int64_t* n_out);
+/* ... or without any copy: text i is pool[off[i] .. off[i] + len[i]) (in whatever order the pool happens to hold them).
+ * Pointers stay valid until ctcdec_result_free. */
+int ctcdec_result_text_blocks(ctcdec_result* r, const char** pool_out, const int64_t** off_out, const int64_t** len_out,
+                              int64_t* n_out);
 
 /* timing of the last call's device stages in milliseconds (HIP events on the decode stream):
  * [0] frame-prune kernel, [1] beam kernel, [2] total device time incl. result copy */

@@ -132,6 +132,8 @@ _PROTOS = {
     "ctcdec_result_pack": (C.c_int, [_VP, C.POINTER(Packed)]),
     "ctcdec_result_texts": (C.c_int, [_VP, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     "ctcdec_result_texts_joined": (C.c_int, [_VP, C.c_char, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ctcdec_result_text_blocks": (C.c_int, [_VP, C.POINTER(C.c_void_p), C.POINTER(C.POINTER(C.c_int64)),
+                                           C.POINTER(C.POINTER(C.c_int64)), C.POINTER(C.c_int64)]),
     "ctcdec_result_timing": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "ctcdec_result_beam_kernel": (C.c_int, [_VP]),
     "ctcdec_device": (C.c_int, []),
@@ -185,6 +187,47 @@ class Library:
 
 
 _LIB: Optional[Library] = None
+_PYTEXTS = None
+
+
+def _pytexts():
+    global _PYTEXTS
+    if _PYTEXTS is None:
+        path = os.path.join(_HERE, "_pytexts.so")
+        _PYTEXTS = False
+        if os.path.exists(path):
+            try:
+                dll = C.PyDLL(path)  # (keeps the GIL: the functions build Python objects)
+                dll.ctcdec_py_split_texts.restype = C.py_object
+                dll.ctcdec_py_split_texts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char]
+                dll.ctcdec_py_texts_from_blocks.restype = C.py_object
+                dll.ctcdec_py_texts_from_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64]
+                _PYTEXTS = dll
+            except (OSError, AttributeError):
+                _PYTEXTS = False
+    return _PYTEXTS
+
+
+def texts_of(lib: "Library", res) -> Optional[list]:
+    """All texts of a result as a list of str, one PyUnicode_DecodeUTF8 per text straight from the library's memory
+    (csrc/pytexts.c); None when that helper was not built (the caller then joins and splits)."""
+    dll = _pytexts()
+    if not dll:
+        return None
+    pool, off, ln, n = C.c_void_p(), C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.c_int64()
+    lib.check(lib.dll.ctcdec_result_text_blocks(res, C.byref(pool), C.byref(off), C.byref(ln), C.byref(n)))
+    if n.value == 0:
+        return []
+    return dll.ctcdec_py_texts_from_blocks(pool, off, ln, n.value)
+
+
+def split_texts(blob_ptr, nbytes: int, n: int, sep: bytes):
+    """n UTF-8 texts separated by `sep` in the library's memory -> list of str (csrc/pytexts.c when it was built, else in
+    Python)."""
+    dll = _pytexts()
+    if dll:
+        return dll.ctcdec_py_split_texts(blob_ptr, nbytes, n, sep)
+    return C.string_at(blob_ptr, nbytes).decode("utf-8").split(sep.decode("ascii"))
 
 
 def get_library() -> Library:

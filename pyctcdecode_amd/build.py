@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctcdec.so")
 SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip"]
-HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "backend.h", "host_tables.h"]
+HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "backend.h", "host_tables.h", "np_sum.h"]
 
 
 def hipcc() -> str:
@@ -24,12 +24,14 @@ def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(SRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
+    deps = [os.path.join(SRC, f) for f in SOURCES + HEADERS + ["pytexts.c"]] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
+        if not os.path.exists(PYTEXTS):
+            build_pytexts(verbose)
         return OUT
     obj_dir = os.path.join(HERE, "csrc", "_obj")
     os.makedirs(obj_dir, exist_ok=True)
@@ -51,7 +53,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     os.replace(OUT + ".tmp", OUT)
+    build_pytexts(verbose)
     return OUT
+
+
+PYTEXTS = os.path.join(HERE, "_pytexts.so")
+
+
+def build_pytexts(verbose: bool = True) -> str:
+    """The shell's one C helper (csrc/pytexts.c: a result's texts as a list of str without three passes over the blob).
+    Optional: without Python's headers the shell splits the blob in Python."""
+    import sysconfig
+
+    inc = sysconfig.get_paths().get("include")
+    src = os.path.join(SRC, "pytexts.c")
+    if not inc or not os.path.exists(os.path.join(inc, "Python.h")):
+        return ""
+    cc = os.environ.get("CC") or shutil.which("gcc") or "gcc"
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-I" + inc, src, "-o", PYTEXTS + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError):
+        return ""
+    os.replace(PYTEXTS + ".tmp", PYTEXTS)
+    return PYTEXTS
 
 
 if __name__ == "__main__":

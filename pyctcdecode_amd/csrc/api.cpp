@@ -235,6 +235,7 @@ struct ctcdec_result {
   bool device_texts = false;
   std::string dev_texts;
   std::vector<OutBeam> dev_out;  // [n_utts]
+  std::vector<int64_t> blk_off, blk_len;  // ctcdec_result_text_blocks
   // packed view (built on demand by ctcdec_result_pack)
   bool packed = false;
   std::vector<int64_t> beam_off, text_off, word_cnt_off;
@@ -1509,6 +1510,37 @@ int ctcdec_result_texts_joined(ctcdec_result* r, char sep, const char** blob_out
   *blob_out = r->j_blob.data();
   *bytes_out = (int64_t)r->j_blob.size();
   *n_out = (int64_t)nb;
+  return CTCDEC_OK;
+}
+
+int ctcdec_result_text_blocks(ctcdec_result* r, const char** pool_out, const int64_t** off_out, const int64_t** len_out,
+                              int64_t* n_out) {
+  if (!r || !pool_out || !off_out || !len_out || !n_out) return fail(CTCDEC_ERR_ARG, "no result");
+  if (r->device_texts && !r->dev_out.empty()) {  // the blocks the device wrote, as they are
+    if (r->blk_off.empty()) {
+      r->blk_off.reserve(r->dev_out.size());
+      r->blk_len.reserve(r->dev_out.size());
+      for (const OutBeam& ob : r->dev_out) {
+        r->blk_off.push_back((int64_t)ob.tok_off);
+        r->blk_len.push_back((int64_t)ob.tok_cnt);
+      }
+    }
+    *pool_out = r->dev_texts.data();
+  } else {  // any other result: the packed texts
+    const char* blob = nullptr;
+    const int64_t* off = nullptr;
+    int64_t n = 0;
+    int rc = ctcdec_result_texts(r, &blob, &off, &n);
+    if (rc != CTCDEC_OK) return rc;
+    if (r->blk_off.empty() && n > 0) {
+      r->blk_off.assign(off, off + n);
+      for (int64_t i = 0; i < n; ++i) r->blk_len.push_back(off[i + 1] - off[i]);
+    }
+    *pool_out = blob;
+  }
+  *off_out = r->blk_off.data();
+  *len_out = r->blk_len.data();
+  *n_out = (int64_t)r->blk_off.size();
   return CTCDEC_OK;
 }
 

@@ -986,11 +986,6 @@ __global__ __launch_bounds__(NT, 2) void beam_decode(BeamArgs a, int surv_cap) {
   io.sstate = a.sstate ? a.sstate + u : nullptr;
   io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
   io.want_out = a.want_out;
-  io.text_scratch = a.text_scratch ? a.text_scratch + a.text_soff[u] : nullptr;
-  io.text_scratch_cap = a.text_scratch ? (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]) : 0u;
-  io.text_pool = a.text_pool;
-  io.text_pool_head = a.tok_pool_head + 1;
-  io.text_pool_cap = a.text_pool_cap;
   if (a.resident_in) {
     io.imports = a.imports + (size_t)u * a.carry_stride;
     io.n_import = (int32_t)a.sstate[u].n_carry;
@@ -1135,11 +1130,6 @@ __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   io.sstate = a.sstate ? a.sstate + u : nullptr;
   io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
   io.want_out = a.want_out;
-  io.text_scratch = a.text_scratch ? a.text_scratch + a.text_soff[u] : nullptr;
-  io.text_scratch_cap = a.text_scratch ? (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]) : 0u;
-  io.text_pool = a.text_pool;
-  io.text_pool_head = a.tok_pool_head + 1;
-  io.text_pool_cap = a.text_pool_cap;
   if (a.resident_in) {
     io.imports = a.imports + (size_t)u * a.carry_stride;
     io.n_import = (int32_t)a.sstate[u].n_carry;
@@ -1156,6 +1146,42 @@ static int launch_wave_t(const BeamArgs& a, std::string* err) {
   HIP_TRY(hipFuncSetAttribute((const void*)beam_wave<BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((beam_wave<BW>), dim3((unsigned)a.n_utts), dim3(64), lds, g_stream, a);
   return 0;
+}
+
+// decode_batch (params.texts_only): the best beam's text of every utterance, assembled on the device. One wave per
+// utterance: lane 0 walks the emission chain leaf to root and writes the UTF-8 bytes backwards into the utterance's
+// scratch area, the wave then copies them to a block of the text pool. A launch of its own, behind the beam kernel: all
+// the chain walks (a few hundred dependent loads each) run side by side instead of one at the tail of every beam wave.
+__global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (a.n_out[u] == 0) return;
+  OutBeam& ob = a.out[(size_t)u * a.out_stride];
+  uint8_t* scratch = a.text_scratch + a.text_soff[u];
+  const uint32_t cap = (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]);
+  uint32_t pos = 0, len = 0;
+  unsigned long long base = 0;
+  if (lane == 0) {
+    pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap);
+    len = cap - pos;
+    base = atomicAdd(a.tok_pool_head + 1, (unsigned long long)len);
+    if (base + len > a.text_pool_cap) {
+      a.status[u] |= ST_TOK_OVERFLOW;
+      base = 0;
+      len = 0;
+    }
+    ob.tok_off = (uint32_t)base;
+    ob.tok_cnt = len;
+    ob.pad[0] = (uint32_t)(base >> 32);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the other lanes read what lane 0 wrote)
+  __builtin_amdgcn_wave_barrier();
+  pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+  len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+  base = ((unsigned long long)bhi << 32) | blo;
+  for (uint32_t k = (uint32_t)lane; k < len; k += 64u) a.text_pool[base + k] = scratch[pos + k];
 }
 
 static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
@@ -1197,6 +1223,10 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     g_last_kernel = 2;
+  }
+  if (a.n_utts > 0 && a.params.texts_only && a.text_scratch) {
+    hipLaunchKernelGGL(assemble_texts, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(g_ev[2], g_stream));
   g_timing_valid = true;

@@ -238,23 +238,17 @@ struct UttIO {
   StreamState* sstate;
   uint32_t emit_start;
   int32_t want_out;
-  // texts assembled on the device (DecodeParams::texts_only): this utterance's scratch area (the text is written
-  // backwards from its end) and the pool the finished text is copied to
-  uint8_t* text_scratch;
-  uint32_t text_scratch_cap;
-  uint8_t* text_pool;
-  unsigned long long* text_pool_head;
-  unsigned long long text_pool_cap;
 };
 
+// (the launch behind the beam kernel when DecodeParams::texts_only is set: backend_hip.hip assemble_texts)
 // ONE thread: the text of a beam (decoder.py:653-667: its words joined by single spaces) from its emission chain, leaf
 // to root, written backwards into scratch[.. cap); returns where it starts. Walking backwards a separator is due when a
 // word boundary (BR_BOUNDARY / BR_SPACE / BR_FINAL) has been passed since the last bytes and there are bytes to its right.
-CTC_HD uint32_t text_backwards(const UttIO& io, const DeviceTables& tab, uint32_t enode, uint8_t* scratch, uint32_t cap) {
+CTC_HD uint32_t text_backwards(const EmitNode* emit_nodes, const DeviceTables& tab, uint32_t enode, uint8_t* scratch, uint32_t cap) {
   uint32_t pos = cap;
   bool emitted = false, pending = false;
   for (uint32_t e = enode; e != 0;) {
-    const EmitNode en = io.emit_nodes[e];
+    const EmitNode en = emit_nodes[e];
     const uint32_t br = en.tok_branch >> 16, tok = en.tok_branch & 0xFFFFu;
     uint32_t off = 0, len = 0;
     if (br == BR_APPEND) {
@@ -1780,41 +1774,23 @@ CTC_UNROLL
     if (io.carry_out && !eos) carry_beams(b, n, fold);
     uint32_t n_out = io.want_out ? n : 0u;
     if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
-    const bool texts = prm.texts_only != 0 && io.text_scratch != nullptr;
-    if (texts && n_out > 0) {  // decode_batch: the best beam's text, nothing else
-      n_out = 1;
+    if (prm.texts_only != 0 && n_out > 0) {
+      // decode_batch: only the best beam's text is wanted, and a separate launch assembles it (assemble_texts: every
+      // utterance's chain walk at once instead of at the tail of this one's life) -- leave it where its chain ends
       if (ctx.tid == 0) {
         const uint32_t idx = L.sel[0];
         const int d = (int)L.p_don[idx];
-        const uint32_t pos = text_backwards(io, tab, b.emit_node[d], io.text_scratch, io.text_scratch_cap);
-        const uint32_t len = io.text_scratch_cap - pos;
-        unsigned long long base = ctx.global_add(io.text_pool_head, (unsigned long long)len);
-        if (base + len > io.text_pool_cap) {
-          L.scal[6] |= ST_TOK_OVERFLOW;
-          base = 0;
-        }
-        L.smax[1] = base;
-        L.scal[8] = pos;
         OutBeam& ob = io.out[0];
         ob.logit_score = L.p_logit[idx];
         ob.lm_score = L.p_score[idx];
         ob.raw_lm = 0.0;
-        ob.tok_off = (uint32_t)base;
-        ob.tok_cnt = (L.scal[6] & ST_TOK_OVERFLOW) ? 0u : len;
+        ob.tok_off = 0;
+        ob.tok_cnt = 0;
         ob.state.len = -1;
         ob.last_char = NO_CHAR;
         ob.pstart = ob.pend = -1;
-        ob.pad[0] = (uint32_t)(base >> 32);
-        ob.pad[1] = 0;
-      }
-      ctx.sync_mem();
-      if (!(L.scal[6] & ST_TOK_OVERFLOW)) {
-        const uint32_t pos = L.scal[8], len = io.text_scratch_cap - pos;
-        const unsigned long long base = L.smax[1];
-        for (uint32_t k = ctx.tid; k < len; k += ctx.nt) io.text_pool[base + k] = io.text_scratch[pos + k];
-      }
-      ctx.sync();
-      if (ctx.tid == 0) {
+        ob.pad[0] = 0;
+        ob.pad[1] = b.emit_node[d];
         *io.n_out = 1;
         *io.status = L.scal[6];
       }

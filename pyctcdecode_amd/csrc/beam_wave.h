@@ -1659,40 +1659,24 @@ CTC_UNROLL
     if (io.carry_out && !eos) carry_beams(n, fold);
     uint32_t n_out = io.want_out ? n : 0u;
     if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
-    if (prm.texts_only != 0 && io.text_scratch != nullptr && n_out > 0) {  // decode_batch: the best beam's text, nothing else
-      uint32_t pos = 0, len = 0;
-      unsigned long long base = 0;
+    if (prm.texts_only != 0 && n_out > 0) {
+      // decode_batch: only the best beam's text is wanted, and a separate launch assembles it (assemble_texts: every
+      // utterance's chain walk at once instead of at the tail of this one's life) -- leave it where its chain ends
       if (lane == 0) {
         const uint32_t idx = L.sel[0] & 0x7FFFFFFFu;
         const u32x4 e1 = L.pool[idx * 3 + 1];
         const uint32_t d = L.pool[idx * 3 + 2][1];
-        pos = text_backwards(io, tab, L.b32[d * R32 + W_ENODE], io.text_scratch, io.text_scratch_cap);
-        len = io.text_scratch_cap - pos;
-        base = ctx.global_add(io.text_pool_head, (unsigned long long)len);
-        if (base + len > io.text_pool_cap) {
-          status |= ST_TOK_OVERFLOW;
-          base = 0;
-          len = 0;
-        }
         OutBeam& ob = io.out[0];
         ob.logit_score = bits_f64(q_lo(e1));
         ob.lm_score = bits_f64(q_hi(e1));
         ob.raw_lm = 0.0;
-        ob.tok_off = (uint32_t)base;
-        ob.tok_cnt = len;
+        ob.tok_off = 0;
+        ob.tok_cnt = 0;
         ob.state.len = -1;
         ob.last_char = NO_CHAR;
         ob.pstart = ob.pend = -1;
-        ob.pad[0] = (uint32_t)(base >> 32);
-        ob.pad[1] = 0;
-      }
-      ctx.mem_sync();  // (the other lanes read what lane 0 wrote)
-      pos = ctx.bcast32(pos, 0);
-      len = ctx.bcast32(len, 0);
-      base = ctx.bcast64(base, 0);
-      status = ctx.wave_or_u32(status);
-      for (uint32_t k = (uint32_t)lane; k < len; k += 64u) io.text_pool[base + k] = io.text_scratch[pos + k];
-      if (lane == 0) {
+        ob.pad[0] = 0;
+        ob.pad[1] = L.b32[d * R32 + W_ENODE];
         *io.n_out = 1;
         *io.status = status;
       }

@@ -175,11 +175,6 @@ static void fill_io(const BeamArgs& a, int u, UttIO& io) {
   io.sstate = a.sstate ? a.sstate + u : nullptr;
   io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
   io.want_out = a.want_out;
-  io.text_scratch = a.text_scratch ? a.text_scratch + a.text_soff[u] : nullptr;
-  io.text_scratch_cap = a.text_scratch ? (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]) : 0u;
-  io.text_pool = a.text_pool;
-  io.text_pool_head = a.tok_pool_head + 1;
-  io.text_pool_cap = a.text_pool_cap;
   if (a.resident_in) {
     io.imports = a.imports + (size_t)u * a.carry_stride;
     io.n_import = (int32_t)a.sstate[u].n_carry;
@@ -211,7 +206,35 @@ static void run_wave(const BeamArgs& a) {
 static int g_last_kernel = 0;
 int last_beam_kernel() { return g_last_kernel; }
 
-int launch_beam(const BeamArgs& a, std::string*) {
+// the launch behind the beam kernel for params.texts_only (backend_hip.hip: assemble_texts)
+static void assemble_texts(const BeamArgs& a) {
+  for (int u = 0; u < a.n_utts; ++u) {
+    if (a.n_out[u] == 0) continue;
+    OutBeam& ob = a.out[(size_t)u * a.out_stride];
+    uint8_t* scratch = a.text_scratch + a.text_soff[u];
+    const uint32_t cap = (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]);
+    const uint32_t pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap);
+    uint32_t len = cap - pos;
+    unsigned long long base = a.tok_pool_head[1];
+    if (base + len > a.text_pool_cap) {
+      a.status[u] |= ST_TOK_OVERFLOW;
+      base = 0;
+      len = 0;
+    }
+    a.tok_pool_head[1] = base + len;
+    ob.tok_off = (uint32_t)base;
+    ob.tok_cnt = len;
+    memcpy(a.text_pool + base, scratch + pos, len);
+  }
+}
+
+static int launch_beam_kernels(const BeamArgs& a, std::string*);
+int launch_beam(const BeamArgs& a, std::string* err) {
+  const int rc = launch_beam_kernels(a, err);
+  if (rc == 0 && a.n_utts > 0 && a.params.texts_only && a.text_scratch) assemble_texts(a);
+  return rc;
+}
+static int launch_beam_kernels(const BeamArgs& a, std::string*) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend (default here: wave)
   const bool want_group = force && force[0] == 'g';
   if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width) && !want_group) {
