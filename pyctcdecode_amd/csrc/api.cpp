@@ -777,11 +777,20 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     for (int32_t u = 0; u < n_utts; ++u) ptrs[(size_t)u] = utt_logits[u];
   } else {
     if (dec->w_logits.ensure((size_t)std::max<int64_t>(R, 1) * V * esz, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    for (int32_t u = 0; u < n_utts; ++u) {
+    // (utterances that follow each other in host memory -- one [B, T, V] array -- go over in one copy)
+    for (int32_t u = 0; u < n_utts;) {
       char* dst = (char*)dec->w_logits.p + (size_t)row0[(size_t)u] * V * esz;
+      const char* src = (const char*)utt_logits[u];
       size_t bytes = (size_t)utt_frames[u] * V * esz;
-      if (bytes && be::h2d(dst, utt_logits[u], bytes, &err)) return fail(CTCDEC_ERR_DEVICE, err);
       ptrs[(size_t)u] = dst;
+      int32_t v = u + 1;
+      while (v < n_utts && (const char*)utt_logits[v] == src + bytes) {
+        ptrs[(size_t)v] = dst + bytes;
+        bytes += (size_t)utt_frames[v] * V * esz;
+        ++v;
+      }
+      if (bytes && be::h2d(dst, src, bytes, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      u = v;
     }
   }
   if (upload(dec->w_ptrs, ptrs, &err) || upload(dec->w_row0, row0, &err)) return fail(CTCDEC_ERR_DEVICE, err);
