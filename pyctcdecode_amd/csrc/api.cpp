@@ -198,6 +198,7 @@ struct ctcdec_decoder {
       w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_tscr, w_tsoff, w_tpool,
       d_toktext, d_tokbytes;
   uint32_t max_label_bytes = 1;
+  bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
   HostBuf h_tok, h_out, h_small;
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
@@ -805,15 +806,24 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
 
   const int B = p->beam_width;
 
-  // arenas
+  // Arenas of text nodes (one per completed-words prefix that is scored) and emission nodes (one per non-blank,
+  // non-repeat step of a kept beam). The worst case is beam_width of each per frame; what a frame really takes is a
+  // handful, so the usual reservation is 16 per frame (+ 2 beam_widths): an utterance that
+  // outgrows it reports ST_TEXT_OVERFLOW / ST_EMIT_OVERFLOW and the beam stage is redone with the worst case, which
+  // this decoder then keeps reserving. A resident stream's kernel cannot be redone: always the worst case (per chunk).
   std::vector<uint64_t> toff((size_t)n_utts + 1, 0), eoff((size_t)n_utts + 1, 0);
-  for (int32_t u = 0; u < n_utts; ++u) {
-    uint64_t T = (uint64_t)utt_frames[u];
-    uint64_t n_imp = rs ? (uint64_t)rs->mirror[(size_t)u].n_carry
-                        : stream ? (uint64_t)(stream->beam_off[u + 1] - stream->beam_off[u]) : 0;
-    toff[(size_t)u + 1] = toff[(size_t)u] + ((T + 1) * (uint64_t)B + 2 + n_imp) * (uint64_t)K;
-    eoff[(size_t)u + 1] = eoff[(size_t)u] + T * (uint64_t)B + 2 + n_imp;
-  }
+  bool arenas_full = rs != nullptr || dec->arenas_worst_case || getenv("CTCDEC_WORST_CASE_ARENAS") != nullptr;
+  auto size_arenas = [&](bool full) {
+    const uint64_t per_frame = full ? (uint64_t)B : std::min<uint64_t>((uint64_t)B, 16);
+    for (int32_t u = 0; u < n_utts; ++u) {
+      uint64_t T = (uint64_t)utt_frames[u];
+      uint64_t n_imp = rs ? (uint64_t)rs->mirror[(size_t)u].n_carry
+                          : stream ? (uint64_t)(stream->beam_off[u + 1] - stream->beam_off[u]) : 0;
+      toff[(size_t)u + 1] = toff[(size_t)u] + ((T + 1) * per_frame + 2 * (uint64_t)B + 2 + n_imp) * (uint64_t)K;
+      eoff[(size_t)u + 1] = eoff[(size_t)u] + T * per_frame + 2 * (uint64_t)B + 2 + n_imp;
+    }
+  };
+  size_arenas(arenas_full);
   int n_best = p->n_best > 0 ? std::min(p->n_best, B) : B;
   // emission lists: at most one entry per frame plus the import root and the closing entry
   unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + 2 * (int64_t)n_utts);
@@ -1080,6 +1090,28 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   if (be::d2h(n_out, dec->w_nout.p, (size_t)n_utts * 4, &err) ||
       be::d2h(status, dec->w_status.p, (size_t)n_utts * 4, &err) || be::d2h(&head, dec->w_head.p, 8, &err))
     return fail(CTCDEC_ERR_DEVICE, err);
+  if (!arenas_full) {
+    bool outgrown = false;
+    for (int32_t u = 0; u < n_utts; ++u) outgrown = outgrown || (status[u] & (ST_TEXT_OVERFLOW | ST_EMIT_OVERFLOW)) != 0;
+    if (outgrown) {  // (rare: flat posteriors that complete a word for every beam in every frame) the beam stage again,
+      // with the worst case reserved
+      dec->arenas_worst_case = true;
+      arenas_full = true;
+      size_arenas(true);
+      if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
+          dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_toff, toff, &err) ||
+          upload(dec->w_eoff, eoff, &err))
+        return fail(CTCDEC_ERR_DEVICE, err);
+      ba.text_nodes = (TextNode*)dec->w_text.p;
+      ba.emit_nodes = (EmitNode*)dec->w_emit.p;
+      ba.text_off = (const uint64_t*)dec->w_toff.p;
+      ba.emit_off = (const uint64_t*)dec->w_eoff.p;
+      if (be::zero(dec->w_head.p, 16, &err) || be::launch_beam(ba, &err) ||
+          be::d2h(n_out, dec->w_nout.p, (size_t)n_utts * 4, &err) || be::d2h(status, dec->w_status.p, (size_t)n_utts * 4, &err) ||
+          be::d2h(&head, dec->w_head.p, 8, &err))
+        return fail(CTCDEC_ERR_DEVICE, err);
+    }
+  }
   auto t_kernel = std::chrono::steady_clock::now();
   if (rs) {  // the streams have moved on, whatever the chunk's outcome: refresh the mirrors first
     if (be::d2h(rs->mirror.data(), rs->sstate.p, (size_t)n_utts * sizeof(StreamState), &err)) return fail(CTCDEC_ERR_DEVICE, err);

@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
   uint32_t pos = 0, len = 0;
   unsigned long long base = 0;
   if (lane == 0) {
-    pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap);
+    pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap, (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]));
     len = cap - pos;
     base = atomicAdd(a.tok_pool_head + 1, (unsigned long long)len);
     if (base + len > a.text_pool_cap) {

@@ -244,10 +244,14 @@ struct UttIO {
 // ONE thread: the text of a beam (decoder.py:653-667: its words joined by single spaces) from its emission chain, leaf
 // to root, written backwards into scratch[.. cap); returns where it starts. Walking backwards a separator is due when a
 // word boundary (BR_BOUNDARY / BR_SPACE / BR_FINAL) has been passed since the last bytes and there are bytes to its right.
-CTC_HD uint32_t text_backwards(const EmitNode* emit_nodes, const DeviceTables& tab, uint32_t enode, uint8_t* scratch, uint32_t cap) {
+// max_steps bounds the walk (a chain is never longer than its arena; an utterance that overflowed its arenas is being
+// redone and may have left a cycle behind).
+CTC_HD uint32_t text_backwards(const EmitNode* emit_nodes, const DeviceTables& tab, uint32_t enode, uint8_t* scratch, uint32_t cap,
+                               uint32_t max_steps) {
   uint32_t pos = cap;
   bool emitted = false, pending = false;
-  for (uint32_t e = enode; e != 0;) {
+  uint32_t steps = 0;
+  for (uint32_t e = enode; e != 0 && steps < max_steps; ++steps) {
     const EmitNode en = emit_nodes[e];
     const uint32_t br = en.tok_branch >> 16, tok = en.tok_branch & 0xFFFFu;
     uint32_t off = 0, len = 0;

@@ -213,7 +213,7 @@ static void assemble_texts(const BeamArgs& a) {
     OutBeam& ob = a.out[(size_t)u * a.out_stride];
     uint8_t* scratch = a.text_scratch + a.text_soff[u];
     const uint32_t cap = (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]);
-    const uint32_t pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap);
+    const uint32_t pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap, (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]));
     uint32_t len = cap - pos;
     unsigned long long base = a.tok_pool_head[1];
     if (base + len > a.text_pool_cap) {
