@@ -1095,6 +1095,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     for (int32_t u = 0; u < n_utts; ++u) outgrown = outgrown || (status[u] & (ST_TEXT_OVERFLOW | ST_EMIT_OVERFLOW)) != 0;
     if (outgrown) {  // (rare: flat posteriors that complete a word for every beam in every frame) the beam stage again,
       // with the worst case reserved
+      if (getenv("CTCDEC_ARENA_TRACE")) fprintf(stderr, "[ctcdec host] node arenas outgrown: beam stage redone with the worst case\n");
       dec->arenas_worst_case = true;
       arenas_full = true;
       size_arenas(true);

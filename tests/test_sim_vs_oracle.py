@@ -357,7 +357,7 @@ def test_decode_batch_texts_come_from_the_device(kind, sim_library, both_beam_ke
     assert got[1] == "" and all(t == " ".join(t.split()) for t in got)
 
 
-def test_node_arenas_outgrown_and_redone(sim_library, both_beam_kernels, monkeypatch):  # noqa: F811
+def test_node_arenas_outgrown_and_redone(sim_library, both_beam_kernels, monkeypatch, capfd):  # noqa: F811
     """The node arenas are reserved for 16 nodes per frame; flat posteriors over a char vocabulary complete a word for
     every beam in almost every frame (~100 per frame at beam 100): the kernels report the overflow and the beam stage
     is redone with the worst case reserved -- same beams as with the worst case from the start, and as the oracle."""
@@ -366,9 +366,12 @@ def test_node_arenas_outgrown_and_redone(sim_library, both_beam_kernels, monkeyp
     alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
     orc = build_oracle(alpha.labels, alpha.is_bpe, LM.path, None)
     xs = [synth.d_flat(7, u, 70, 29).astype(np.float64) for u in range(3)]
-    got = build_ctcdecoder(synth.LIBRI_LABELS, LM.path).decode_beams_batch(None, xs, beam_width=100)  # (a fresh decoder: small arenas)
+    kw = {"beam_width": 100, "beam_prune_logp": -60.0}  # (a wide threshold keeps the beam full)
+    monkeypatch.setenv("CTCDEC_ARENA_TRACE", "1")
+    got = build_ctcdecoder(synth.LIBRI_LABELS, LM.path).decode_beams_batch(None, xs, **kw)  # (a fresh decoder: small arenas)
     monkeypatch.setenv("CTCDEC_WORST_CASE_ARENAS", "1")
-    full = build_ctcdecoder(synth.LIBRI_LABELS, LM.path).decode_beams_batch(None, xs, beam_width=100)
+    full = build_ctcdecoder(synth.LIBRI_LABELS, LM.path).decode_beams_batch(None, xs, **kw)
     for g, f, x in zip(got, full, xs):
         assert [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g] == [(o.text, o.text_frames, o.logit_score, o.lm_score) for o in f]
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g], _expected(orc, x, {"beam_width": 100}), what="flat")
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g], _expected(orc, x, kw), what="flat")
+    assert "node arenas outgrown" in capfd.readouterr().err  # (the first decode did take the redo)
