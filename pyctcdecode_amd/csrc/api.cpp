@@ -196,7 +196,7 @@ struct ctcdec_decoder {
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
       w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_tscr, w_tsoff, w_tpool,
-      d_toktext, d_tokbytes;
+      d_toktext, d_tokbytes, w_slow;
   uint32_t max_label_bytes = 1;
   bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
   HostBuf h_tok, h_out, h_small;
@@ -206,7 +206,7 @@ struct ctcdec_decoder {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
                      &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold,
-                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes};
+                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
       d_xuni[k].drop();
@@ -1024,7 +1024,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     size_t rows = (size_t)std::max<int64_t>(R, 1);
     if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
         dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
-        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err))
+        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err) || dec->w_slow.ensure(rows * 4, &err))
       return fail(CTCDEC_ERR_DEVICE, err);
     if (be::zero(dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     be::PruneArgs pa;
@@ -1044,6 +1044,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     pa.overflow = (uint32_t*)dec->w_flags.p;
     pa.pass = 0;
     pa.row_base = 0;
+    pa.slow_rows = (uint32_t*)dec->w_slow.p;
     pa.rows_aligned16 = 1;
     for (const void* q : ptrs)
       if (((uintptr_t)q & 15u) != 0) pa.rows_aligned16 = 0;
@@ -1373,7 +1374,8 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   }
   if (upload(dec->w_ptrs, ptrs, &err) || upload(dec->w_row0, row0, &err) || dec->w_rowsum.ensure(rows * 8, &err) ||
       dec->w_isprob.ensure(4, &err) || dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
-      dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err) || be::zero(dec->w_flags.p, 16, &err))
+      dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err) || be::zero(dec->w_flags.p, 16, &err) ||
+      dec->w_slow.ensure(rows * 4, &err))
     return fail(CTCDEC_ERR_DEVICE, err);
   be::PruneArgs pa;
   pa.utt_logits = (const void* const*)dec->w_ptrs.p;
@@ -1392,6 +1394,7 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   pa.overflow = (uint32_t*)dec->w_flags.p;
   pa.row_base = 0;
   pa.pass = 0;
+  pa.slow_rows = (uint32_t*)dec->w_slow.p;
   pa.rows_aligned16 = (((uintptr_t)ptrs[0]) & 15u) == 0 ? 1 : 0;
   if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   uint32_t flags[4] = {0, 0, 0, 0};

@@ -57,9 +57,12 @@ struct PruneArgs {
   double* surv_lp;       // [n_rows * max_surv]
   uint32_t* overflow;    // [4] [0]: a row had more than max_surv survivors, [1]: a probability-like utterance exists,
                          // [2]: an utterance is marked 2 in utt_is_prob (its rows sum to about 1: launch_sniff_exact decides)
+                         // [3]: device-side counter of slow_rows
   int32_t pass;          // 0: all utterances as logits + row sums + sniff; 1: redo the probability-like ones
   int32_t rows_aligned16; // every utterance base pointer is 16-byte aligned
   int64_t row_base;      // first row of this launch (utt_row0 and the row-indexed arrays are absolute); n_rows rows follow
+  uint32_t* slow_rows;   // [n_rows] scratch, or nullptr: rows (relative to row_base) the 64-rows-per-wave kernel hands to the
+                         // per-row one; their count is kept in overflow[3]
 };
 int launch_prune(const PruneArgs& a, std::string* err);
 // decoder.py:760 in the input dtype and numpy's summation order for the utterances pass 0 marked ambiguous

@@ -11,6 +11,7 @@
 //                             per utterance, beam table / candidates / merge table in LDS
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <algorithm>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -19,6 +20,7 @@
 #include "beam_core.h"
 #include "beam_wave.h"
 #include "set_order.h"
+#include "set_order_small.h"
 #include "np_sum.h"
 
 namespace ctc {
@@ -673,13 +675,7 @@ __device__ __forceinline__ double log_ge1(double s) {
 // coalesced) and all three sweeps run out of registers: the logits cross HBM exactly once.
 // PK: the exponentials of the clean-row path as packed float32 polynomials (the default; CTCDEC_PRUNE_EXP=f64: fp64)
 template <int NC, bool PK>
-__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs a, uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t row = a.row_base + (int64_t)blockIdx.x * PRUNE_WAVES + wave;
-  if (row >= a.row_base + a.n_rows) return;
-  const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
+__device__ __forceinline__ void prune_row_f32x4(const PruneArgs& a, int64_t row, const PruneLds& w, int lane) {
   const int V = a.n_labels;
   const int u = find_utt(a.utt_row0, a.n_utts, row);
   const bool is_prob = a.pass == 1;
@@ -754,7 +750,8 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
       // survivors: an fp32 screen that cannot miss (threshold rounded down, with a margin far above the fp64
       // rounding of the exact test), then the exact fp64 test only in the 256-label chunks that have a candidate
       const double xthr = m + lse + a.token_min_logp;
-      const float pre = __double2float_rd(xthr - 1e-6 * (1.0 + fabs(xthr)));
+      // (a threshold at or below the clip keeps every label: decoder.py:444 tests the clipped values)
+      const float pre = a.token_min_logp <= -34.538776394910684 ? -INFINITY : __double2float_rd(xthr - 1e-6 * (1.0 + fabs(xthr)));
       uint32_t n = 0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
@@ -827,6 +824,313 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs 
   }
   prune_finish(a, row, lane, w, n, best, best_id);
 }
+template <int NC, bool PK>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = a.row_base + (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  if (row >= a.row_base + a.n_rows) return;
+  prune_row_f32x4<NC, PK>(a, row, prune_lds(smem, wave, (uint32_t)a.max_surv, cap), lane);
+}
+// the rows frame_prune_fast left on its list (a.slow_rows, a.overflow[3] of them), one wave per row
+template <int NC>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4_listed(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
+  const uint32_t count = a.overflow[3];
+  for (uint32_t k = blockIdx.x * PRUNE_WAVES + wave; k < count; k += gridDim.x * PRUNE_WAVES) {
+    prune_row_f32x4<NC, true>(a, a.row_base + (int64_t)a.slow_rows[k], w, lane);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame_prune_fast: 64 frames per wavefront, in two phases
+// ---------------------------------------------------------------------------------------------
+// The per-row kernel above spends most of its instructions on what follows the log-softmax: finding the survivors, ordering
+// them the way a CPython set would, writing them out -- a serial tail of a few hundred instructions that 63 of the 64 lanes
+// sit through. Here a wave takes 64 consecutive rows and
+//   phase A (one row at a time, 64 lanes x 16 logits, the next row's loads in flight): row maximum and sum, the sum of
+//     exponentials (packed float32 polynomials, see exp_nonpos_f32x2m), the first maximum, and the labels that pass a float32
+//     screen of the threshold, left UNORDERED in a 16-slot LDS column of the row; the row's scalars land in lane `row`;
+//   phase B (one row per LANE): the exact fp64 test of the candidates, an insertion sort by label id, the CPython set order
+//     (set_order_small.h: 48 table slots per lane) and the output records -- the serial tail, 64 rows at a time.
+// Rows this does not cover (non-finite maximum or NaN, more than 16 candidates / 15 survivors, survivor counts at the
+// max_surv bound) go onto a list and frame_prune_f32x4_listed runs the per-row code on them right behind this kernel.
+constexpr int PF_ROWS = 64;
+constexpr int PF_CAND = 16;
+constexpr size_t PF_LDS_IDS = (size_t)PF_ROWS * PF_CAND * 2;
+constexpr size_t PF_LDS_X = (size_t)PF_ROWS * PF_CAND * 4;
+constexpr size_t PF_LDS = PF_LDS_IDS + PF_LDS_X + (size_t)PF_ROWS * SMALL_SET_SLOTS * 2;  // 12 KiB: 13 waves per CU
+
+// exp(d), d <= 0, two at a time, as exp_nonpos_f32x2 with the rounding and the scaling done by the 1.5 * 2^23 trick
+// (t = d * log2(e) + magic holds round(d * log2 e) in its low mantissa bits: n = t - magic, and bits(t) << 23 is n in the
+// exponent field: 2^n * p is one integer add, no v_rndne / v_cvt / v_ldexp) and the degree-7 polynomial. Same operations
+// on the host (20 M arguments in [-14, 0]): mean relative error -5.8e-10, mean |error| 2.2e-8, maximum 7.7e-8
+// (degree 8: 1.5e-11 / 2.2e-8 / 7.4e-8; libm's expf: 3.5e-11 / 2.1e-8).
+__device__ __forceinline__ f32x2 exp_nonpos_f32x2m(f32x2 d) {
+  d.x = fmaxf(d.x, -80.0f);  // exp(-80) = 1.8e-35 does not register in a sum >= 1; also maps -inf masks
+  d.y = fmaxf(d.y, -80.0f);
+  const f32x2 magic = (f32x2)(12582912.0f);
+  const f32x2 t = __builtin_elementwise_fma(d, (f32x2)(1.44269504088896340736f), magic);
+  const f32x2 n = t - magic;
+  f32x2 r = __builtin_elementwise_fma(n, (f32x2)(-0.693145751953125f), d);
+  r = __builtin_elementwise_fma(n, (f32x2)(-1.42860682030941723212e-6f), r);
+  f32x2 p = (f32x2)(1.98412698412698413e-04f);                              // 1/7!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.38888888888888889e-03f));   // 1/6!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(8.33333333333333333e-03f));   // 1/5!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(4.16666666666666667e-02f));   // 1/4!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.66666666666666667e-01f));   // 1/3!
+  p = __builtin_elementwise_fma(p, r, (f32x2)(0.5f));
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.0f));
+  p = __builtin_elementwise_fma(p, r, (f32x2)(1.0f));
+  f32x2 out;
+  out.x = __uint_as_float(__float_as_uint(p.x) + (__float_as_uint(t.x) << 23));
+  out.y = __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(t.y) << 23));
+  return out;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float ident, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// v_max3_f32 / v_max_f32_dpp by hand: fmaxf() makes the compiler quiet each operand first (v_max_f32 x, x, x), which doubles
+// the instructions of a maximum over loaded values. NaNs need no care here: a row that holds one is recognised by its sum
+// and handed to the per-row kernel.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float o;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+  return o;
+}
+// (lanes a DPP step has no source for keep their value: the destination is the second operand; s_nop 1: the two wait
+// states a DPP read needs after the VALU write of its source -- the compiler cannot see into the asm)
+#define CTC_MAX_DPP(V, CTRL) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL : "+v"(V))
+__device__ __forceinline__ float wave_max_f32(float v) {
+  CTC_MAX_DPP(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+  CTC_MAX_DPP(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+  CTC_MAX_DPP(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+  CTC_MAX_DPP(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+  CTC_MAX_DPP(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+  CTC_MAX_DPP(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  asm volatile("s_nop 1" ::: "memory");
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_f32<0x111, 0xf>(0.f, v);
+  v += dpp_f32<0x112, 0xf>(0.f, v);
+  v += dpp_f32<0x114, 0xf>(0.f, v);
+  v += dpp_f32<0x118, 0xf>(0.f, v);
+  v += dpp_f32<0x142, 0xa>(0.f, v);
+  v += dpp_f32<0x143, 0xc>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {  // set bits of `mask` below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// one lane's 48 table slots, interleaved with the other lanes' (slot k of lane l at [k * 64 + l])
+struct LaneTab {
+  uint16_t* t;
+  __device__ __forceinline__ uint16_t get(uint32_t k) const { return t[k * PF_ROWS]; }
+  __device__ __forceinline__ void put(uint32_t k, uint16_t v) { t[k * PF_ROWS] = v; }
+};
+
+template <int NC>
+__global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int64_t row_lo = a.row_base + (int64_t)blockIdx.x * PF_ROWS;
+  const int64_t row_end = a.row_base + a.n_rows;
+  if (row_lo >= row_end) return;
+  const int nrows = (int)(row_end - row_lo < (int64_t)PF_ROWS ? row_end - row_lo : (int64_t)PF_ROWS);
+  uint16_t* ar_id = (uint16_t*)smem;                       // [PF_CAND][64 rows]
+  float* ar_x = (float*)(smem + PF_LDS_IDS);               // [PF_CAND][64 rows]
+  uint16_t* tabs = (uint16_t*)(smem + PF_LDS_IDS + PF_LDS_X);  // [SMALL_SET_SLOTS][64 rows]
+  const int V = a.n_labels;
+  const int n4 = V >> 2;
+  const float tminf = (float)a.token_min_logp;
+
+  // rows are walked in order: the utterance of the first one by bisection, the rest by stepping
+  int u = find_utt(a.utt_row0, a.n_utts, row_lo);
+  int64_t u_r0 = a.utt_row0[u], u_r1 = a.utt_row0[u + 1];
+  const float* u_base = (const float*)a.utt_logits[u];
+  auto load_row = [&](int64_t row, float4(&r)[NC]) {
+    while (row >= u_r1) {
+      ++u;
+      u_r0 = u_r1;
+      u_r1 = a.utt_row0[u + 1];
+      u_base = (const float*)a.utt_logits[u];
+    }
+    const float4* x4 = (const float4*)(u_base + (size_t)(row - u_r0) * V);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int i4 = k * 64 + lane;
+      r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+  };
+
+  // what phase A leaves for row i, in lane i
+  float my_m = 0.f, my_rs = 0.f;
+  double my_s = 1.0;
+  int my_first = 0;
+  uint32_t my_cnt = 0;
+
+  auto phase_a = [&](int i, const float4(&r)[NC]) {
+    float mf = -INFINITY, rsf;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) mf = max3_raw(max3_raw(mf, r[k].x, r[k].y), r[k].z, r[k].w);
+    if (n4 == NC * 64) {  // (see prune_row_f32x4 on this sum)
+      f32x2 rs2 = (f32x2)(0.f);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) rs2 += (f32x2){r[k].x, r[k].y} + (f32x2){r[k].z, r[k].w};
+      rsf = rs2.x + rs2.y;
+    } else {  // lanes past the row hold -inf for the maximum: nothing for the sum
+      rsf = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) rsf += (k * 64 + lane < n4) ? (r[k].x + r[k].y) + (r[k].z + r[k].w) : 0.f;
+    }
+    const float m = wave_max_f32(mf);
+    const float rs = wave_sum_f32(rsf);
+    uint32_t cnt = 0xFFFFu;  // "not a clean row": the per-row kernel takes it
+    int first = 0;
+    double s = 1.0;
+    if (isfinite(m) && rs == rs) {
+      // sum of exponentials: float32 per lane (16 terms), fp64 across the lanes
+      f32x2 acc = (f32x2)(0.f);
+      const f32x2 mm = (f32x2)(m);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        acc += exp_nonpos_f32x2m((f32x2){r[k].x, r[k].y} - mm);
+        acc += exp_nonpos_f32x2m((f32x2){r[k].z, r[k].w} - mm);
+      }
+      s = wave_sum((double)(acc.x + acc.y));
+      // the first maximum (numpy.argmax), from the lane masks of `== m`
+      first = 0x7FFFFFFF;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (first == 0x7FFFFFFF) {
+          const uint64_t b0 = __ballot(r[k].x == m), b1 = __ballot(r[k].y == m), b2 = __ballot(r[k].z == m),
+                         b3 = __ballot(r[k].w == m);
+          const uint64_t any = b0 | b1 | b2 | b3;
+          if (any) {
+            const int l = __builtin_ctzll(any);
+            const int e = ((b0 >> l) & 1ull) ? 0 : ((b1 >> l) & 1ull) ? 1 : ((b2 >> l) & 1ull) ? 2 : 3;
+            first = (k * 64 + l) * 4 + e;
+          }
+        }
+      }
+      // candidates: a float32 screen that cannot miss a survivor -- the threshold on the logits from a float32 logarithm
+      // (|error| < 1e-6 (1 + lse)), lowered by a margin two orders above that and above the rounding of the sum
+      const float xthr = (m + __logf((float)s)) + tminf;
+      const float pre = xthr - 3e-5f * (4.0f + fabsf(xthr));
+      cnt = 0;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = e == 0 ? r[k].x : e == 1 ? r[k].y : e == 2 ? r[k].z : r[k].w;
+          const bool c = x >= pre;
+          const uint64_t mk = __ballot(c);
+          if (mk) {
+            const uint32_t pos = cnt + lanes_below(mk);
+            if (c && pos < (uint32_t)PF_CAND) {
+              ar_id[pos * PF_ROWS + i] = (uint16_t)((k * 64 + lane) * 4 + e);
+              ar_x[pos * PF_ROWS + i] = x;
+            }
+            cnt += (uint32_t)__popcll(mk);
+          }
+        }
+      }
+    }
+    if (lane == i) {
+      my_m = m;
+      my_rs = rs;
+      my_s = s;
+      my_first = first;
+      my_cnt = cnt;
+    }
+  };
+
+  {
+    float4 ra[NC], rb[NC];
+    load_row(row_lo, ra);
+    for (int i = 0; i < nrows; i += 2) {
+      const bool two = i + 1 < nrows;
+      if (two) load_row(row_lo + i + 1, rb);
+      phase_a(i, ra);
+      if (two) {
+        if (i + 2 < nrows) load_row(row_lo + i + 2, ra);
+        phase_a(i + 1, rb);
+      }
+    }
+  }
+  __syncthreads();  // (one wave: orders phase A's LDS writes before phase B's reads)
+
+  // ---- phase B: lane = row
+  const int64_t row = row_lo + lane;
+  const uint32_t ms = (uint32_t)a.max_surv;
+  bool slow = false;
+  if (lane < nrows) {
+    const uint32_t cnt = my_cnt;
+    slow = cnt > (uint32_t)PF_CAND;
+    if (!slow) {
+      const double s = my_s;
+      const double md = (double)my_m;
+      const double lse = log_ge1(s);
+      const double best = to_logp(md, false, md, lse);
+      uint16_t* ids = ar_id + lane;
+      float* xs = ar_x + lane;
+      // the exact test (fp64, as in the per-row kernel) + insertion sort by id, in place
+      uint32_t n = 0;
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const uint16_t id = ids[j * PF_ROWS];
+        const float x = xs[j * PF_ROWS];
+        if (to_logp((double)x, false, md, lse) >= a.token_min_logp) {
+          uint32_t p = n;
+          while (p > 0 && ids[(p - 1) * PF_ROWS] > id) {
+            ids[p * PF_ROWS] = ids[(p - 1) * PF_ROWS];
+            xs[p * PF_ROWS] = xs[(p - 1) * PF_ROWS];
+            --p;
+          }
+          ids[p * PF_ROWS] = id;
+          xs[p * PF_ROWS] = x;
+          ++n;
+        }
+      }
+      slow = n > SMALL_SET_MAX_KEYS || n >= ms;  // (n == ms with the argmax outside: the per-row kernel's overflow rules)
+      if (!slow) {
+        LaneTab tab{tabs + lane};
+        const SmallSet r = small_set_order(tab, n, [ids](uint32_t k) { return (uint32_t)ids[k * PF_ROWS]; },
+                                           (uint32_t)my_first);
+        uint16_t* out_id = a.surv_id + (size_t)row * ms;
+        double* out_lp = a.surv_lp + (size_t)row * ms;
+        uint32_t pos = 0;
+        for (uint32_t k = 0; k <= r.mask; ++k) {
+          const uint16_t v = tab.get(r.base + k);
+          if (v != SMALL_SET_EMPTY) {
+            const uint32_t pay = v >> 10;
+            out_id[pos] = (uint16_t)(v & 1023u);
+            out_lp[pos] = pay == SMALL_SET_ARGMAX ? best : to_logp((double)xs[pay * PF_ROWS], false, md, lse);
+            ++pos;
+          }
+        }
+        a.surv_cnt[row] = pos;
+        a.row_sum[row] = (double)my_rs;
+      }
+    }
+  }
+  const uint64_t sm = __ballot(slow);
+  if (sm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.overflow[3], (uint32_t)__popcll(sm));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (slow) a.slow_rows[base + lanes_below(sm)] = (uint32_t)(row - a.row_base);
+  }
+}
 
 int launch_prune(const PruneArgs& a, std::string* err) {
   if (a.pass == 0) {
@@ -848,9 +1152,28 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     HIP_TRY(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
     hipLaunchKernelGGL(KERN, grid, block, lds, g_stream, a, cap);                                              \
   } while (0)
-    if (vec4) {
+    const char* ex = getenv("CTCDEC_PRUNE_EXP");  // "f64": the fp64 exponential of round 2 (diagnostics)
+    const char* pk = getenv("CTCDEC_PRUNE_KERNEL");  // "row": one wave per row for every row (diagnostics)
+    const bool rows64 = vec4 && a.pass == 0 && a.slow_rows && a.max_surv < a.n_labels && a.n_rows < (1ll << 32) &&
+                        !(ex && ex[0] == 'f') && !(pk && pk[0] == 'r');
+    if (rows64) {
       const int nc = (a.n_labels / 4 + 63) / 64;
-      const char* ex = getenv("CTCDEC_PRUNE_EXP");  // "f64": the fp64 exponential of round 2 (diagnostics)
+      const dim3 fgrid((unsigned)((a.n_rows + PF_ROWS - 1) / PF_ROWS)), fblock(64);
+      const unsigned rest = (unsigned)std::min<int64_t>((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES, 2048);
+#define CTC_LAUNCH_FAST(NCV)                                                                                              \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL((frame_prune_fast<NCV>), fgrid, fblock, PF_LDS, g_stream, a);                                      \
+    HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_f32x4_listed<NCV>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)lds));                                                                               \
+    hipLaunchKernelGGL((frame_prune_f32x4_listed<NCV>), dim3(rest), block, lds, g_stream, a, cap);                         \
+  } while (0)
+      if (nc <= 1) CTC_LAUNCH_FAST(1);
+      else if (nc == 2) CTC_LAUNCH_FAST(2);
+      else if (nc == 3) CTC_LAUNCH_FAST(3);
+      else CTC_LAUNCH_FAST(4);
+#undef CTC_LAUNCH_FAST
+    } else if (vec4) {
+      const int nc = (a.n_labels / 4 + 63) / 64;
       if (!(ex && ex[0] == 'f')) {
         if (nc <= 1) CTC_LAUNCH_PRUNE((frame_prune_f32x4<1, true>));
         else if (nc == 2) CTC_LAUNCH_PRUNE((frame_prune_f32x4<2, true>));

@@ -440,6 +440,48 @@ def test_hip_frame_survivors_in_cpython_set_order():
     assert border < frames // 20
 
 
+def test_hip_rows64_prune_kernel_shapes(monkeypatch):
+    """frame_prune_fast (64 rows per wave, one row per lane for the set order) where its shape matters: partial last
+    batches, label counts that do not fill the 256-label chunks, rows it hands to the per-row kernel (non-finite rows,
+    more than 16 candidates, 15 < survivors), and the same rows through the per-row kernel (CTCDEC_PRUNE_KERNEL=row): equal
+    lists, equal to a real CPython set."""
+    from pyctcdecode_amd import build_ctcdecoder
+    from tests.survivor_util import check_against_cpython, survivors
+
+    _loaded_native()
+    rng = np.random.default_rng(23)
+    frames = border = 0
+    for V, T, scale, tmin in [(1024, 1, 2.0, -5.0), (1024, 63, 2.0, -5.0), (1024, 64, 3.0, -4.0), (1024, 65, 2.0, -5.0),
+                              (1024, 200, 1.3, -5.5), (1020, 130, 2.0, -5.0), (772, 70, 2.0, -5.0), (512, 129, 2.0, -4.5),
+                              (260, 67, 2.0, -4.0), (256, 64, 1.5, -4.0), (32, 500, 1.0, -3.0), (64, 100, 0.7, -3.9),
+                              (8, 77, 1.0, -1.5), (4, 5, 1.0, -1.0)]:
+        dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
+        x = (rng.standard_normal((T, V)) * scale).astype(np.float32)
+        if T >= 64:
+            x[5, :] = -np.inf           # an all-masked row
+            x[9, 3] = np.inf
+            x[11, V // 2] = np.nan
+            x[17, : V // 2] = -np.inf   # half the labels masked: a clean row
+            x[20, :] = 0.25             # every label ties for the maximum
+            x[21, :] = 0.0
+            x[21, [V - 1, V // 3]] = 9.0  # two maxima: the first one is the argmax
+        good = np.ones(T, bool)
+        if T >= 64:
+            good[[5, 9, 11]] = False
+        monkeypatch.delenv("CTCDEC_PRUNE_KERNEL", raising=False)
+        fast = survivors(dec, x, tmin)
+        monkeypatch.setenv("CTCDEC_PRUNE_KERNEL", "row")
+        per_row = survivors(dec, x, tmin)
+        monkeypatch.delenv("CTCDEC_PRUNE_KERNEL")
+        for t in range(T):
+            assert fast[t][0] == per_row[t][0], (V, T, t)
+            if good[t]:
+                np.testing.assert_allclose(fast[t][1], per_row[t][1], rtol=0, atol=2e-6)
+        border += check_against_cpython(dec, x[good], tmin, 1e-4)
+        frames += int(good.sum())
+    assert border < frames // 20
+
+
 def test_hip_random_differential_slice():
     """The same random differential hunt as tests/test_sim_vs_oracle.py, against the HIP build."""
     from tools import fuzz_sim_vs_oracle as fuzz
