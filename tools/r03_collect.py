@@ -29,7 +29,7 @@ def main():
                 "tools/pmc_run.sh); counter values are KiB per dispatch, mean over the 3 dispatches of a pass; 4096 "
                 "utterances x T=1000 x V=1024, beam 100, 4-gram + hot words",
         "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced "
-                      "streaming read (16 B/lane) -> doubled for frame_prune_f32x4 (float4 loads; the doubled value lands within "
+                      "streaming read (16 B/lane) -> doubled for frame_prune_fast (float4 loads; the doubled value lands within "
                       "0.01 % of the algorithmic T*V*4 bytes, which is the calibration). The beam kernel and assemble_texts do "
                       "scattered 1-128 B accesses: the guide calls those widths uncalibrated, so their FETCH_SIZE is reported raw "
                       "(fetch_bytes_corrected == raw). WRITE_SIZE is uncalibrated everywhere (raw).",
@@ -39,7 +39,7 @@ def main():
     for k in f:
         if k.startswith("__amd") or k.startswith("utt_sniff"):
             continue
-        name = "frame_prune" if k.startswith("frame_prune") else k.split("<")[0]
+        name = "frame_prune" if k.startswith("frame_prune_fast") else k.split("<")[0]
         raw = f[k]["FETCH_SIZE"] * KIB
         d[name] = {"kernel": k, "dispatches": f[k]["dispatches"], "grid": f[k]["grid"], "FETCH_SIZE_KiB_raw": f[k]["FETCH_SIZE"],
                    "WRITE_SIZE_KiB_raw": w[k]["WRITE_SIZE"], "fetch_bytes_corrected": raw * 2 if name == "frame_prune" else raw,
@@ -72,10 +72,15 @@ def main():
               "cycles %.3f" % (per["SQ_INSTS_VALU"] / w_, per["SQ_INSTS_SALU"] / w_, per["SQ_INSTS_LDS"] / w_, per["SQ_INSTS_VMEM_RD"] / w_,
                                per["SQ_INSTS_VMEM_WR"] / w_, per["SQ_WAVE_CYCLES"] / w_, per["SQ_WAIT_ANY"] / w_,
                                per["SQ_ACTIVE_INST_VALU"] / per["SQ_WAVE_CYCLES"]))
-    pr = next((v for k, v in merged.items() if k.startswith("frame_prune_f32x4")), {})
+    pr = next((v for k, v in merged.items() if k.startswith("frame_prune_fast")), {})
     if pr:
-        print("frame_prune per row: VALU %.0f SALU %.0f LDS %.0f" % (pr["SQ_INSTS_VALU"] / pr["SQ_WAVES"], pr["SQ_INSTS_SALU"] / pr["SQ_WAVES"],
-                                                                     pr["SQ_INSTS_LDS"] / pr["SQ_WAVES"]))
+        rows = pr["SQ_WAVES"] * 64.0
+        print("frame_prune_fast per row: VALU %.0f SALU %.0f LDS %.1f; VALU active / wave cycles %.3f" % (
+            pr["SQ_INSTS_VALU"] / rows, pr["SQ_INSTS_SALU"] / rows, pr["SQ_INSTS_LDS"] / rows,
+            pr["SQ_ACTIVE_INST_VALU"] / pr["SQ_WAVE_CYCLES"]))
+    ls = next((v for k, v in merged.items() if k.startswith("frame_prune_f32x4_listed")), {})
+    if ls:
+        print("frame_prune_f32x4_listed: %d waves launched per dispatch (rows handed over by the fast kernel are processed by these)" % ls["SQ_WAVES"])
 
 
 if __name__ == "__main__":
