@@ -190,8 +190,8 @@ struct ctcdec_decoder {
   int hist_order() const { return multi ? multi->order : lm_ptr->order; }
   HostHotwords hot;
   bool tables_dirty = true, hot_dirty = true;
-  DevBuf d_tok, d_tok_hot, d_uni, d_ngr, d_pref, d_hot;
-  DevBuf d_xuni[MAX_LMS - 1], d_xngr[MAX_LMS - 1], d_winfo[MAX_LMS], w_xstate, w_impx;
+  DevBuf d_tok, d_tok_hot, d_uni, d_pref, d_hot;  // (the n-gram tables: NgramStore::device, shared between decoders)
+  DevBuf d_xuni[MAX_LMS - 1], d_winfo[MAX_LMS], w_xstate, w_impx;
   HostBuf h_xstate;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
@@ -203,14 +203,13 @@ struct ctcdec_decoder {
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
-    DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_ngr,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
+    DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
                      &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold,
                      &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
       d_xuni[k].drop();
-      d_xngr[k].drop();
     }
     for (int k = 0; k < MAX_LMS; ++k) d_winfo[k].drop();
     w_xstate.drop();
@@ -278,6 +277,22 @@ struct ctcdec_stream {
   }
 };
 
+// the device copy of a model's n-gram table: uploaded once per NgramStore, shared by every decoder that holds the model
+// or a clone of it, released with the last of them
+static const NgramEntry* device_ngrams(const HostLM& lm) {
+  return lm.ngr->device ? (const NgramEntry*)static_cast<DevBuf*>(lm.ngr->device.get())->p : nullptr;
+}
+static int upload_ngrams(const HostLM& lm, std::string* err) {
+  if (lm.ngr->device) return 0;
+  std::shared_ptr<DevBuf> buf(new DevBuf(), [](DevBuf* b) {
+    b->drop();
+    delete b;
+  });
+  if (upload(*buf, lm.ngr->table, err)) return -1;
+  lm.ngr->device = buf;
+  return 0;
+}
+
 static int sync_tables(ctcdec_decoder* d, std::string* err) {
   if (d->tables_dirty) {
     if (d->multi) fill_token_starts_from(d->multi->prefix_table, d->multi->prefix_mask, &d->alpha);
@@ -305,14 +320,14 @@ static int sync_tables(ctcdec_decoder* d, std::string* err) {
     }
     if (d->has_lm) {
       if (upload(d->d_uni, d->lm_ref().unigrams, err)) return -1;
-      if (upload(d->d_ngr, d->lm_ref().ngram_table, err)) return -1;
+      if (upload_ngrams(d->lm_ref(), err)) return -1;
       if (upload(d->d_pref, d->multi ? d->multi->prefix_table : d->lm_ref().prefix_table, err)) return -1;
     }
     if (d->multi) {
       for (int k = 0; k < d->n_lms(); ++k) {
         if (upload(d->d_winfo[k], d->multi->winfo[(size_t)k], err)) return -1;
         if (k > 0 && (upload(d->d_xuni[k - 1], d->multi->lms[(size_t)k]->unigrams, err) ||
-                      upload(d->d_xngr[k - 1], d->multi->lms[(size_t)k]->ngram_table, err)))
+                      upload_ngrams(*d->multi->lms[(size_t)k], err)))
           return -1;
       }
     }
@@ -338,7 +353,7 @@ static void device_tables(const ctcdec_decoder* d, DeviceTables* t) {
   t->max_label_bytes = d->max_label_bytes;
   if (d->has_lm) {
     t->unigrams = (const UnigramEntry*)d->d_uni.p;
-    t->ngrams = (const NgramEntry*)d->d_ngr.p;
+    t->ngrams = device_ngrams(d->lm_ref());
     t->prefixes = (const PrefixEntry*)d->d_pref.p;
     if (d->multi) {
       t->prefix_mask = d->multi->prefix_mask;
@@ -349,7 +364,7 @@ static void device_tables(const ctcdec_decoder* d, DeviceTables* t) {
         const HostLM& lm = *d->multi->lms[(size_t)k];
         LmExtra& x = t->x[k - 1];
         x.unigrams = (const UnigramEntry*)d->d_xuni[k - 1].p;
-        x.ngrams = (const NgramEntry*)d->d_xngr[k - 1].p;
+        x.ngrams = device_ngrams(*d->multi->lms[(size_t)k]);
         x.ngram_mask = lm.ngram_mask;
         x.winfo = (const uint32_t*)d->d_winfo[k].p;
         x.lm_order = (uint32_t)lm.order;

@@ -233,6 +233,8 @@ std::string HostLM::load_arpa(const std::string& path) {
   n_ngrams = raw.size();
   uint64_t size = 16;
   while (size < 4 * raw.size() + 1) size <<= 1;  // load <= 1/4: a miss (the common case when backing off) costs ~1.2 probes
+  ngr = std::make_shared<NgramStore>();  // (never the table another model may be sharing)
+  std::vector<NgramEntry>& ngram_table = ngr->table;
   ngram_table.assign(size, NgramEntry{0, 0.f, 0.f});
   ngram_mask = size - 1;
   for (const RawGram& g : raw) table_put(ngram_table, ngram_mask, g.key, g.prob, g.backoff);
@@ -259,6 +261,7 @@ std::string HostLM::save_cache(const std::string& path) const {
   std::vector<uint64_t> ends(words.size());
   uint64_t blob = 0;
   for (size_t i = 0; i < words.size(); ++i) ends[i] = (blob += words[i].size());
+  const std::vector<NgramEntry>& ngram_table = ngr->table;
   const uint64_t h64[3] = {(uint64_t)n_ngrams, (uint64_t)ngram_table.size(), blob};
   ok = ok && fwrite(h32, 4, 4, f) == 4 && fwrite(h64, 8, 3, f) == 3;
   ok = ok && fwrite(ends.data(), 8, ends.size(), f) == ends.size();
@@ -312,7 +315,8 @@ std::string HostLM::load_cache(const std::string& path) {
   eos_id = h32[3];
   n_ngrams = h64[0];
   unigrams.swap(uni);
-  ngram_table.swap(tab);
+  ngr = std::make_shared<NgramStore>();
+  ngr->table.swap(tab);
   ngram_mask = tsize - 1;
   in_uniset.assign(words.size(), 0);
   has_trie = false;
@@ -453,7 +457,7 @@ void HostLM::start_state(bool begin_sentence, LmState* out) const {
 void HostLM::tables(DeviceTables* t) const {
   memset(t, 0, sizeof(*t));
   t->unigrams = unigrams.data();
-  t->ngrams = ngram_table.data();
+  t->ngrams = ngr->table.data();
   t->ngram_mask = ngram_mask;
   t->prefixes = prefix_table.data();
   t->prefix_mask = prefix_mask;

@@ -27,12 +27,22 @@ struct HostAlphabet {
   void build(const std::vector<std::string>& labels_, bool is_bpe_);
 };
 
+// The hashed n-gram table: by far the largest part of a model (64 MB per million n-grams) and immutable once loaded, so
+// a model, its clones (ctcdec_lm_clone: own unigram set and prefix table over the same n-grams) and every decoder that
+// holds one of them share ONE host copy and ONE device upload. `device` is owned by whoever uploads (api.cpp: a DevBuf
+// released with the last reference).
+struct NgramStore {
+  std::vector<NgramEntry> table;  // open addressing, empty key 0
+  std::shared_ptr<void> device;
+};
+
 struct HostLM {
   int order = 0;
   std::vector<std::string> words;  // id -> string, id 0 = <unk>
   std::unordered_map<std::string, uint32_t> vocab;
   std::vector<UnigramEntry> unigrams;
-  std::vector<NgramEntry> ngram_table;  // open addressing, empty key 0
+  std::shared_ptr<NgramStore> ngr = std::make_shared<NgramStore>();  // copies of a HostLM share it
+  const std::vector<NgramEntry>& ngram_table() const { return ngr->table; }
   uint64_t ngram_mask = 0;
   uint32_t bos_id = 0, eos_id = 0;
   bool has_trie = false;          // unigrams is not None
