@@ -1008,21 +1008,6 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
         acc += exp_nonpos_f32x2m((f32x2){r[k].z, r[k].w} - mm);
       }
       s = wave_sum((double)(acc.x + acc.y));
-      // the first maximum (numpy.argmax), from the lane masks of `== m`
-      first = 0x7FFFFFFF;
-#pragma unroll
-      for (int k = 0; k < NC; ++k) {
-        if (first == 0x7FFFFFFF) {
-          const uint64_t b0 = __ballot(r[k].x == m), b1 = __ballot(r[k].y == m), b2 = __ballot(r[k].z == m),
-                         b3 = __ballot(r[k].w == m);
-          const uint64_t any = b0 | b1 | b2 | b3;
-          if (any) {
-            const int l = __builtin_ctzll(any);
-            const int e = ((b0 >> l) & 1ull) ? 0 : ((b1 >> l) & 1ull) ? 1 : ((b2 >> l) & 1ull) ? 2 : 3;
-            first = (k * 64 + l) * 4 + e;
-          }
-        }
-      }
       // candidates: a float32 screen that cannot miss a survivor -- the threshold on the logits from a float32 logarithm
       // (|error| < 1e-6 (1 + lse)), lowered by a margin two orders above that and above the rounding of the sum
       const float xthr = (m + __logf((float)s)) + tminf;
@@ -1042,6 +1027,25 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
               ar_x[pos * PF_ROWS + i] = x;
             }
             cnt += (uint32_t)__popcll(mk);
+          }
+        }
+      }
+      // the first maximum (numpy.argmax): when the maximum passes the screen, every label that ties for it is among the
+      // candidates and phase B picks the smallest id; only a row whose maximum is below the threshold is searched here,
+      // from the lane masks of `== m`
+      if (cnt == 0) {
+        first = 0x7FFFFFFF;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          if (first == 0x7FFFFFFF) {
+            const uint64_t b0 = __ballot(r[k].x == m), b1 = __ballot(r[k].y == m), b2 = __ballot(r[k].z == m),
+                           b3 = __ballot(r[k].w == m);
+            const uint64_t any = b0 | b1 | b2 | b3;
+            if (any) {
+              const int l = __builtin_ctzll(any);
+              const int e = ((b0 >> l) & 1ull) ? 0 : ((b1 >> l) & 1ull) ? 1 : ((b2 >> l) & 1ull) ? 2 : 3;
+              first = (k * 64 + l) * 4 + e;
+            }
           }
         }
       }
@@ -1086,9 +1090,11 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       float* xs = ar_x + lane;
       // the exact test (fp64, as in the per-row kernel) + insertion sort by id, in place
       uint32_t n = 0;
+      uint32_t first = cnt > 0 ? 0xFFFFu : (uint32_t)my_first;  // (candidates: the smallest id whose logit is the maximum)
       for (uint32_t j = 0; j < cnt; ++j) {
         const uint16_t id = ids[j * PF_ROWS];
         const float x = xs[j * PF_ROWS];
+        if (x == my_m && id < first) first = id;
         if (to_logp((double)x, false, md, lse) >= a.token_min_logp) {
           uint32_t p = n;
           while (p > 0 && ids[(p - 1) * PF_ROWS] > id) {
@@ -1105,7 +1111,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       if (!slow) {
         LaneTab tab{tabs + lane};
         const SmallSet r = small_set_order(tab, n, [ids](uint32_t k) { return (uint32_t)ids[k * PF_ROWS]; },
-                                           (uint32_t)my_first);
+                                           first);
         uint16_t* out_id = a.surv_id + (size_t)row * ms;
         double* out_lp = a.surv_lp + (size_t)row * ms;
         uint32_t pos = 0;
