@@ -196,7 +196,7 @@ struct ctcdec_decoder {
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
       w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_tscr, w_tsoff, w_tpool,
-      d_toktext, d_tokbytes, w_slow;
+      d_toktext, d_tokbytes, w_slow, w_order;
   uint32_t max_label_bytes = 1;
   bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
   HostBuf h_tok, h_out, h_small;
@@ -206,7 +206,7 @@ struct ctcdec_decoder {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
                      &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold,
-                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow};
+                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow, &w_order};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
       d_xuni[k].drop();
@@ -1013,6 +1013,19 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.carry_stride = 0;
   ba.want_out = 1;
   ba.resident_in = 0;
+  // ragged batches of more utterances than fit the device at once: longest first (BeamArgs::order)
+  ba.order = nullptr;
+  if (n_utts > be::cus() * 2 && !getenv("CTCDEC_NO_LPT_ORDER")) {
+    bool ragged = false;
+    for (int32_t u = 1; u < n_utts; ++u) ragged = ragged || utt_frames[u] != utt_frames[0];
+    if (ragged) {
+      std::vector<int32_t> order((size_t)n_utts);
+      for (int32_t u = 0; u < n_utts; ++u) order[(size_t)u] = u;
+      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return utt_frames[x] > utt_frames[y]; });
+      if (upload(dec->w_order, order, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      ba.order = (const int32_t*)dec->w_order.p;
+    }
+  }
   if (rs) {
     ba.emit_nodes = (EmitNode*)rs->emit.p;
     ba.emit_off = (const uint64_t*)rs->eoff.p;

@@ -111,6 +111,9 @@ struct BeamArgs {
   const uint64_t* text_soff;   // [n_utts + 1] (device)
   uint8_t* text_pool;
   unsigned long long text_pool_cap;
+  const int32_t* order;        // [n_utts] (device) or nullptr: workgroup b decodes utterance order[b] -- longest first, so
+                               // that a ragged batch that needs several rounds of resident waves ends evenly (the hardware
+                               // hands the next workgroup to the first free slot: longest-processing-time-first scheduling)
   int32_t resident_in;         // 1: `imports` is the carry buffer itself (stream u: imports + u * carry_stride, sstate[u].n_carry
                                // beams; import_xstates likewise), import_off is not used
 };

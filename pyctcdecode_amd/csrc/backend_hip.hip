@@ -1275,7 +1275,7 @@ struct GpuCtx {
 template <int BW, int NT, bool MULTI>
 __global__ __launch_bounds__(NT, 2) void beam_decode(BeamArgs a, int surv_cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int u = blockIdx.x;
+  const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   // compile-time layout: every LDS array sits at a constant offset (ds_* immediate offsets)
   LdsShape shape;
   shape.bw = BW;
@@ -1427,7 +1427,7 @@ struct WaveGpuCtx {
 template <int BW>
 __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int u = blockIdx.x;
+  const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   WaveLds view;
   wave_lds_carve<BW>(view, (lds_bytes_t)smem);
   UttIO io;

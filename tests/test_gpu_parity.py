@@ -491,6 +491,32 @@ def test_hip_random_differential_slice():
     assert sum(stats.values()) == 60 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 57, stats
 
 
+def test_hip_ragged_batch_is_dispatched_longest_first(lm, monkeypatch):
+    """A ragged batch of more utterances than the device holds at once hands the workgroups out longest utterance first
+    (BeamArgs::order); results land where the caller's order says, equal to the plain dispatch and to the oracle."""
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    _loaded_native()
+    rng = np.random.default_rng(77)
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, lm.path)
+    lens = [int(t) for t in rng.integers(0, 60, size=700)]
+    lens[3] = 0
+    lens[10] = 150
+    xs = [synth.d_words(9, u, t, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=5.0).astype(np.float32)
+          if t else np.zeros((0, 29), np.float32) for u, t in enumerate(lens)]
+    got = dec.decode_batch(None, xs, beam_width=16)
+    beams = dec.decode_beams_batch(None, xs, beam_width=16)
+    monkeypatch.setenv("CTCDEC_NO_LPT_ORDER", "1")
+    plain = dec.decode_batch(None, xs, beam_width=16)
+    assert got == plain and [b[0].text for b in beams] == got
+    alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    for u in (0, 3, 10, 11, 350, 699):
+        assert got[u] == orc.decode(xs[u].astype(np.float64), beam_width=16), u
+
+
 def test_hip_device_binding_and_kernel_choice(lm, monkeypatch):
     """One process drives one GPU (LOCAL_RANK / CTCDEC_DEVICE), logits on another device are refused, and the two
     beam kernels are chosen by batch size unless CTCDEC_BEAM_KERNEL says otherwise."""
