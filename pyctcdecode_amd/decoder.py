@@ -355,6 +355,25 @@ class _DeviceStreams:
                 list.extend(lst, got[u])
                 lst._filled = True
 
+    def peek_best(self) -> None:
+        """`beams[0]` on an unread list (a streaming caller showing the transcript so far): one native read with
+        n_best = 1 fetches the best beam of every stream; the lists stay unread otherwise."""
+        dec = self.decoder
+        with dec._call_lock:
+            p = B.Params.from_buffer_copy(self.params)
+            p.n_best = 1
+            res = C.c_void_p()
+            self.lib.check(self.lib.dll.ctcdec_stream_read(self.handle, C.byref(p), C.byref(res)))
+            try:
+                got = self.unpack(res)
+            finally:
+                self.lib.dll.ctcdec_result_free(res)
+        for u, ref in enumerate(self.lists):
+            lst = ref()
+            if lst is not None and not lst._filled:
+                lst._best = got[u][0] if got[u] else None
+                lst._peeked = True
+
     def unpack(self, res) -> List[List[LMBeam]]:
         dec = self.decoder
         lib = self.lib
@@ -419,6 +438,18 @@ class _ResidentBeams(list):
         self._gen = gen
         self._filled = False
         self._edited = False
+        self._peeked = False
+        self._best: Optional[LMBeam] = None
+
+    def __getitem__(self, key):
+        # the best beam alone is a cheap read (n_best = 1); anything else fills the list
+        if not self._filled and type(key) is int and key == 0 and self._gen == self._streams.gen:
+            if not self._peeked:
+                self._streams.peek_best()
+            if self._best is not None:
+                return self._best
+        self._fill()
+        return list.__getitem__(self, key)
 
     def _current(self) -> bool:
         return not self._edited and self._gen == self._streams.gen
@@ -455,7 +486,7 @@ def _writer(name):
     return method
 
 
-for _n in ("__len__", "__iter__", "__getitem__", "__contains__", "__repr__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__",
+for _n in ("__len__", "__iter__", "__contains__", "__repr__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__",
            "__ge__", "__add__", "__mul__", "__rmul__", "__reversed__", "index", "count", "copy"):
     setattr(_ResidentBeams, _n, _reader(_n))
 for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort",

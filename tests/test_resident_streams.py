@@ -123,6 +123,33 @@ def _scenario_many_streams_long(build, to_input, n_streams, n_chunks, chunk, bea
     check_beams(_lm_beams(beams[0]), _oracle_beams(exp), what="stream 0")
 
 
+def _scenario_best_beam_per_chunk(build, to_input):
+    """A caller that shows the transcript so far reads beams[0] after every chunk: that is a cheap read of the best beam
+    alone (the list stays unread and the stream resident), it is the first beam of the full list, and the stream ends
+    exactly where an unwatched one ends."""
+    from pyctcdecode_amd.decoder import _ResidentBeams
+
+    dec = build(BPE, LM.path)
+    alpha = Alphabet.build_alphabet(BPE)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, LM.path, None)
+    x = synth.d_words(4, 2, 160, BPE, True, LM.words, LM.sentences, len(BPE), boost=6.0).astype(np.float64)
+    cuts = [0, 40, 80, 120, 160]
+    beams, c1, c2 = dec.get_starting_state()
+    st = orc.get_starting_state()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        beams = dec.partial_decode_beams(to_input(x[a:b]), c1, c2, beams, a, is_end=(b == 160), beam_width=50)
+        with np.errstate(all="ignore"):
+            ob = orc.partial_decode_beams(x[a:b], st, a, is_end=(b == 160), beam_width=50)
+        best = beams[0]
+        assert (best.text, best.partial_word) == (ob[0].text, ob[0].partial) and abs(best.lm_score - ob[0].lm) < 1e-9
+        if b == 80:  # the full list after a peek: same first beam
+            assert isinstance(beams, _ResidentBeams) and not beams._filled
+            assert list(beams)[0] == best and len(beams) == len(ob)
+        elif b < 160:
+            assert isinstance(beams, _ResidentBeams) and not beams._filled
+    check_beams(_lm_beams(beams), _oracle_beams(ob), what="watched stream")
+
+
 def _build():
     from pyctcdecode_amd import build_ctcdecoder
 
@@ -140,6 +167,10 @@ def test_reads_edits_force_next_word_and_hotwords(sim_library, both_beam_kernels
 
 def test_many_streams_and_a_growing_history(sim_library, both_beam_kernels):  # noqa: F811
     _scenario_many_streams_long(_build(), lambda a: a, n_streams=5, n_chunks=12, chunk=25, beam_width=30)
+
+
+def test_best_beam_per_chunk_is_a_cheap_read(sim_library, both_beam_kernels):  # noqa: F811
+    _scenario_best_beam_per_chunk(_build(), lambda a: a)
 
 
 def test_plain_lists_on_request(sim_library, monkeypatch):  # noqa: F811
@@ -195,6 +226,11 @@ def test_hip_reads_edits_force_next_word_and_hotwords(both_beam_kernels):
 @pytest.mark.gpu
 def test_hip_many_streams_and_a_growing_history(both_beam_kernels):
     _scenario_many_streams_long(_build(), _dev, n_streams=64, n_chunks=20, chunk=50, beam_width=200)
+
+
+@pytest.mark.gpu
+def test_hip_best_beam_per_chunk_is_a_cheap_read(both_beam_kernels):
+    _scenario_best_beam_per_chunk(_build(), _dev)
 
 
 @pytest.mark.gpu
