@@ -535,13 +535,7 @@ __device__ __forceinline__ double to_logp(double xv, bool is_prob, double mx, do
 //         probability sniff are produced on the way; pass 1 (only launched when utt_sniff found
 //         probability-like utterances) redoes just those utterances with log(clip(p)).
 template <typename T>
-__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uint32_t cap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t row = a.row_base + (int64_t)blockIdx.x * PRUNE_WAVES + wave;
-  if (row >= a.row_base + a.n_rows) return;
-  const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
+__device__ __forceinline__ void prune_row_generic(const PruneArgs& a, int64_t row, const PruneLds& w, int lane) {
   const int V = a.n_labels;
   const int u = find_utt(a.utt_row0, a.n_utts, row);
   const bool is_prob = a.pass == 1;
@@ -589,6 +583,29 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uin
     n += (uint32_t)__popcll(mask);
   }
   prune_finish(a, row, lane, w, n, best, best_id);
+}
+template <typename T>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = a.row_base + (int64_t)blockIdx.x * PRUNE_WAVES + wave;
+  if (row >= a.row_base + a.n_rows) return;
+  prune_row_generic<T>(a, row, prune_lds(smem, wave, (uint32_t)a.max_surv, cap), lane);
+}
+// the rows frame_prune_fast left on its list for 16-bit inputs (a.slow_rows, a.overflow[3] of them), one wave per row
+template <typename T>
+__global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_listed(PruneArgs a, uint32_t cap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const PruneLds w = prune_lds(smem, wave, (uint32_t)a.max_surv, cap);
+  const uint32_t count = a.overflow[3];
+  for (uint32_t k = blockIdx.x * PRUNE_WAVES + wave; k < count; k += gridDim.x * PRUNE_WAVES) {
+    prune_row_generic<T>(a, a.row_base + (int64_t)a.slow_rows[k], w, lane);
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
 }
 
 // exp(d) for d <= 0 (d = logit - row max), fp64, ~1 ulp: 2^k * exp(r) with k = rint(d / ln 2), |r| <= ln2/2,
@@ -939,7 +956,26 @@ struct LaneTab {
   __device__ __forceinline__ void put(uint32_t k, uint16_t v) { t[k * PF_ROWS] = v; }
 };
 
-template <int NC>
+// DT: ctcdec_dtype of the rows -- 0 float32 (NC 16-byte loads of four labels per lane), 2 float16 / 3 bfloat16 (NC / 2 loads
+// of eight labels, widened exactly to the same NC float4 groups: the arithmetic below never knows the difference)
+template <int DT>
+struct PfRaw {
+  typedef float4 type;
+};
+template <>
+struct PfRaw<2> {
+  typedef uint4 type;
+};
+template <>
+struct PfRaw<3> {
+  typedef uint4 type;
+};
+template <int DT>
+__device__ __forceinline__ float pf_widen(uint32_t h16) {
+  return DT == 2 ? __half2float(__ushort_as_half((unsigned short)h16)) : __uint_as_float(h16 << 16);
+}
+
+template <int NC, int DT>
 __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -950,26 +986,53 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   uint16_t* ar_id = (uint16_t*)smem;                       // [PF_CAND][64 rows]
   float* ar_x = (float*)(smem + PF_LDS_IDS);               // [PF_CAND][64 rows]
   uint16_t* tabs = (uint16_t*)(smem + PF_LDS_IDS + PF_LDS_X);  // [SMALL_SET_SLOTS][64 rows]
+  constexpr bool WIDE = DT == 0;                 // float32 rows
+  constexpr int NL = WIDE ? NC : NC / 2;         // 16-byte loads per lane and row
+  constexpr int PER = WIDE ? 4 : 8;              // labels per load
+  static_assert(WIDE || NC % 2 == 0, "16-bit rows: two float4 groups per load");
+  typedef typename PfRaw<DT>::type Raw;
   const int V = a.n_labels;
-  const int n4 = V >> 2;
+  const int n4 = V / PER;                        // loads per row
   const float tminf = (float)a.token_min_logp;
+  // label id of element e of group k in this lane; is group k inside the row?
+  auto id_of = [&](int k, int e) { return WIDE ? (k * 64 + lane) * 4 + e : ((k >> 1) * 64 + lane) * 8 + (k & 1) * 4 + e; };
+  auto in_row = [&](int k) { return (WIDE ? k : (k >> 1)) * 64 + lane < n4; };
 
   // rows are walked in order: the utterance of the first one by bisection, the rest by stepping
   int u = find_utt(a.utt_row0, a.n_utts, row_lo);
   int64_t u_r0 = a.utt_row0[u], u_r1 = a.utt_row0[u + 1];
-  const float* u_base = (const float*)a.utt_logits[u];
-  auto load_row = [&](int64_t row, float4(&r)[NC]) {
+  const char* u_base = (const char*)a.utt_logits[u];
+  auto load_row = [&](int64_t row, Raw(&r)[NL]) {
     while (row >= u_r1) {
       ++u;
       u_r0 = u_r1;
       u_r1 = a.utt_row0[u + 1];
-      u_base = (const float*)a.utt_logits[u];
+      u_base = (const char*)a.utt_logits[u];
     }
-    const float4* x4 = (const float4*)(u_base + (size_t)(row - u_r0) * V);
+    const Raw* x4 = (const Raw*)(u_base + (size_t)(row - u_r0) * V * (WIDE ? 4 : 2));
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
+    for (int k = 0; k < NL; ++k) {
       const int i4 = k * 64 + lane;
-      r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if constexpr (WIDE) {
+        r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      } else {
+        const uint32_t ninf = DT == 2 ? 0xFC00FC00u : 0xFF80FF80u;  // -inf twice
+        r[k] = i4 < n4 ? x4[i4] : make_uint4(ninf, ninf, ninf, ninf);
+      }
+    }
+  };
+  auto widen = [&](const Raw(&raw)[NL], float4(&r)[NC]) {
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int k = 0; k < NC; ++k) r[k] = raw[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) {
+        r[2 * k] = make_float4(pf_widen<DT>(raw[k].x & 0xFFFFu), pf_widen<DT>(raw[k].x >> 16), pf_widen<DT>(raw[k].y & 0xFFFFu),
+                               pf_widen<DT>(raw[k].y >> 16));
+        r[2 * k + 1] = make_float4(pf_widen<DT>(raw[k].z & 0xFFFFu), pf_widen<DT>(raw[k].z >> 16), pf_widen<DT>(raw[k].w & 0xFFFFu),
+                                   pf_widen<DT>(raw[k].w >> 16));
+      }
     }
   };
 
@@ -979,11 +1042,13 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   int my_first = 0;
   uint32_t my_cnt = 0;
 
-  auto phase_a = [&](int i, const float4(&r)[NC]) {
+  auto phase_a = [&](int i, const Raw(&raw)[NL]) {
+    float4 r[NC];
+    widen(raw, r);
     float mf = -INFINITY, rsf;
 #pragma unroll
     for (int k = 0; k < NC; ++k) mf = max3_raw(max3_raw(mf, r[k].x, r[k].y), r[k].z, r[k].w);
-    if (n4 == NC * 64) {  // (see prune_row_f32x4 on this sum)
+    if (n4 == NL * 64) {  // (see prune_row_f32x4 on this sum)
       f32x2 rs2 = (f32x2)(0.f);
 #pragma unroll
       for (int k = 0; k < NC; ++k) rs2 += (f32x2){r[k].x, r[k].y} + (f32x2){r[k].z, r[k].w};
@@ -991,7 +1056,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     } else {  // lanes past the row hold -inf for the maximum: nothing for the sum
       rsf = 0.f;
 #pragma unroll
-      for (int k = 0; k < NC; ++k) rsf += (k * 64 + lane < n4) ? (r[k].x + r[k].y) + (r[k].z + r[k].w) : 0.f;
+      for (int k = 0; k < NC; ++k) rsf += in_row(k) ? (r[k].x + r[k].y) + (r[k].z + r[k].w) : 0.f;
     }
     const float m = wave_max_f32(mf);
     const float rs = wave_sum_f32(rsf);
@@ -1023,7 +1088,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
           if (mk) {
             const uint32_t pos = cnt + lanes_below(mk);
             if (c && pos < (uint32_t)PF_CAND) {
-              ar_id[pos * PF_ROWS + i] = (uint16_t)((k * 64 + lane) * 4 + e);
+              ar_id[pos * PF_ROWS + i] = (uint16_t)id_of(k, e);
               ar_x[pos * PF_ROWS + i] = x;
             }
             cnt += (uint32_t)__popcll(mk);
@@ -1037,14 +1102,17 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
         first = 0x7FFFFFFF;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-          if (first == 0x7FFFFFFF) {
+          if (first == 0x7FFFFFFF || (!WIDE && (k & 1))) {
             const uint64_t b0 = __ballot(r[k].x == m), b1 = __ballot(r[k].y == m), b2 = __ballot(r[k].z == m),
                            b3 = __ballot(r[k].w == m);
             const uint64_t any = b0 | b1 | b2 | b3;
             if (any) {
               const int l = __builtin_ctzll(any);
               const int e = ((b0 >> l) & 1ull) ? 0 : ((b1 >> l) & 1ull) ? 1 : ((b2 >> l) & 1ull) ? 2 : 3;
-              first = (k * 64 + l) * 4 + e;
+              // (16-bit rows: groups 2j and 2j+1 hold labels 8l..8l+3 and 8l+4..8l+7 of lane l -- the smaller id may
+              // sit in the odd group of an earlier lane, so both groups of a load are looked at before the answer stands)
+              const int cand = WIDE ? (k * 64 + l) * 4 + e : ((k >> 1) * 64 + l) * 8 + (k & 1) * 4 + e;
+              if (cand < first) first = cand;
             }
           }
         }
@@ -1060,7 +1128,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   };
 
   {
-    float4 ra[NC], rb[NC];
+    Raw ra[NL], rb[NL];
     load_row(row_lo, ra);
     for (int i = 0; i < nrows; i += 2) {
       const bool two = i + 1 < nrows;
@@ -1160,15 +1228,18 @@ int launch_prune(const PruneArgs& a, std::string* err) {
   } while (0)
     const char* ex = getenv("CTCDEC_PRUNE_EXP");  // "f64": the fp64 exponential of round 2 (diagnostics)
     const char* pk = getenv("CTCDEC_PRUNE_KERNEL");  // "row": one wave per row for every row (diagnostics)
-    const bool rows64 = vec4 && a.pass == 0 && a.slow_rows && a.max_surv < a.n_labels && a.n_rows < (1ll << 32) &&
-                        !(ex && ex[0] == 'f') && !(pk && pk[0] == 'r');
+    const bool rows_ok = a.pass == 0 && a.slow_rows && a.max_surv < a.n_labels && a.n_rows < (1ll << 32) &&
+                         !(ex && ex[0] == 'f') && !(pk && pk[0] == 'r');
+    const bool rows64 = vec4 && rows_ok;
+    // 16-bit rows of a multiple of eight labels (16-byte loads of eight): the same kernel, widened on the fly
+    const bool rows64h = (a.dtype == 2 || a.dtype == 3) && (a.n_labels % 8) == 0 && a.n_labels <= 1024 && a.rows_aligned16 && rows_ok;
+    const dim3 fgrid((unsigned)((a.n_rows + PF_ROWS - 1) / PF_ROWS)), fblock(64);
+    const unsigned rest = (unsigned)std::min<int64_t>((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES, 2048);
     if (rows64) {
       const int nc = (a.n_labels / 4 + 63) / 64;
-      const dim3 fgrid((unsigned)((a.n_rows + PF_ROWS - 1) / PF_ROWS)), fblock(64);
-      const unsigned rest = (unsigned)std::min<int64_t>((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES, 2048);
 #define CTC_LAUNCH_FAST(NCV)                                                                                              \
   do {                                                                                                                    \
-    hipLaunchKernelGGL((frame_prune_fast<NCV>), fgrid, fblock, PF_LDS, g_stream, a);                                      \
+    hipLaunchKernelGGL((frame_prune_fast<NCV, 0>), fgrid, fblock, PF_LDS, g_stream, a);                                   \
     HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_f32x4_listed<NCV>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 (int)lds));                                                                               \
     hipLaunchKernelGGL((frame_prune_f32x4_listed<NCV>), dim3(rest), block, lds, g_stream, a, cap);                         \
@@ -1178,6 +1249,22 @@ int launch_prune(const PruneArgs& a, std::string* err) {
       else if (nc == 3) CTC_LAUNCH_FAST(3);
       else CTC_LAUNCH_FAST(4);
 #undef CTC_LAUNCH_FAST
+    } else if (rows64h) {
+      const int nl = (a.n_labels / 8 + 63) / 64;  // 16-byte loads per lane: 1 (up to 512 labels) or 2
+#define CTC_LAUNCH_FAST16(NCV, DTV, T)                                                                                    \
+  do {                                                                                                                    \
+    hipLaunchKernelGGL((frame_prune_fast<NCV, DTV>), fgrid, fblock, PF_LDS, g_stream, a);                                 \
+    HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_listed<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((frame_prune_listed<T>), dim3(rest), block, lds, g_stream, a, cap);                                 \
+  } while (0)
+      if (a.dtype == 2) {
+        if (nl <= 1) CTC_LAUNCH_FAST16(2, 2, half_bits);
+        else CTC_LAUNCH_FAST16(4, 2, half_bits);
+      } else {
+        if (nl <= 1) CTC_LAUNCH_FAST16(2, 3, bf16_bits);
+        else CTC_LAUNCH_FAST16(4, 3, bf16_bits);
+      }
+#undef CTC_LAUNCH_FAST16
     } else if (vec4) {
       const int nc = (a.n_labels / 4 + 63) / 64;
       if (!(ex && ex[0] == 'f')) {
