@@ -188,7 +188,8 @@ static void run_wave(const BeamArgs& a) {
   const size_t bytes = wave_lds_bytes<BW>();
   std::vector<char> lds(bytes + 64);
   char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-  for (int u = 0; u < a.n_utts; ++u) {
+  for (int b = 0; b < a.n_utts; ++b) {
+    const int u = a.order ? a.order[b] : b;  // (the dispatch order of the HIP launch: longest utterance first)
     memset(base, 0xCD, bytes);  // poison: catch reads of never-written LDS
     WaveLds view;
     wave_lds_carve<BW>(view, base);
@@ -251,7 +252,8 @@ static int launch_beam_kernels(const BeamArgs& a, std::string*) {
   size_t bytes = lds_bytes(shape);
   std::vector<char> lds(bytes + 64);
   char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
-  for (int u = 0; u < a.n_utts; ++u) {
+  for (int b = 0; b < a.n_utts; ++b) {
+    const int u = a.order ? a.order[b] : b;
     memset(base, 0xCD, bytes);  // poison: catch reads of never-written LDS
     LdsView view;
     lds_carve(view, base, shape);

@@ -357,6 +357,25 @@ def test_decode_batch_texts_come_from_the_device(kind, sim_library, both_beam_ke
     assert got[1] == "" and all(t == " ".join(t.split()) for t in got)
 
 
+def test_ragged_batch_dispatched_longest_first(sim_library, both_beam_kernels, monkeypatch):  # noqa: F811
+    """More utterances than the device holds at once and of different lengths: the beam stage takes them longest first
+    (BeamArgs::order; the simulator walks the same order); every result lands in the caller's slot."""
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(synth.LIBRI_LABELS, LM.path)
+    lens = [7, 31, 0, 12, 55, 3, 31, 18, 44, 1, 26, 9, 38]
+    xs = [synth.d_words(2, u, t, synth.LIBRI_LABELS, False, LM.words, LM.sentences, 28, boost=5.0) if t
+          else np.zeros((0, 29)) for u, t in enumerate(lens)]
+    got = dec.decode_beams_batch(None, xs, beam_width=12)
+    monkeypatch.setenv("CTCDEC_NO_LPT_ORDER", "1")
+    plain = dec.decode_beams_batch(None, xs, beam_width=12)
+    single = [dec.decode_beams(x, beam_width=12) for x in xs]
+    for g, p, o in zip(got, plain, single):
+        key = [(b.text, b.text_frames, b.logit_score, b.lm_score) for b in g]
+        assert key == [(b.text, b.text_frames, b.logit_score, b.lm_score) for b in p]
+        assert key == [(b.text, b.text_frames, b.logit_score, b.lm_score) for b in o]
+
+
 def test_node_arenas_outgrown_and_redone(sim_library, both_beam_kernels, monkeypatch, capfd):  # noqa: F811
     """The node arenas are reserved for 16 nodes per frame; flat posteriors over a char vocabulary complete a word for
     every beam in almost every frame (~100 per frame at beam 100): the kernels report the overflow and the beam stage
