@@ -1360,7 +1360,7 @@ struct GpuCtx {
 // second launch-bound caps the allocator at 256 VGPRs -- left alone it drifts above that with small code
 // changes and silently halves the residency (measured: 13.2 ms -> 25.4 ms).
 template <int BW, int NT, bool MULTI>
-__global__ __launch_bounds__(NT, 2) void beam_decode(BeamArgs a, int surv_cap) {
+__global__ __launch_bounds__(NT, NT > 256 ? 1 : 2) void beam_decode(BeamArgs a, int surv_cap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   // compile-time layout: every LDS array sits at a constant offset (ds_* immediate offsets)
@@ -1634,7 +1634,14 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     // Threads per utterance: four waves (measured on MI355X, 512 utterances, beam 100: 256 threads 13.0 ms,
     // 128 threads 15.2 ms, 64 threads 19.7 ms for this kernel).
     int rc;
+    // Eight waves per utterance instead of four when every CU holds at most one utterance (the LDS of a workgroup allows
+    // two per CU, the registers 2 x 256 threads or 1 x 512): measured on MI355X, 256 utterances x T=1000 -- BASELINE config 2
+    // (~2 500 candidates per frame) 84.2 -> 70.4 ms, the headline workload (a few dozen candidates) 12.1 -> 11.8 ms.
+    // CTCDEC_GROUP_THREADS=256|512 forces one.
+    const char* gt = getenv("CTCDEC_GROUP_THREADS");
+    const bool wide = gt ? gt[0] == '5' : a.n_utts <= g_cus;
     if (a.tables.n_lms > 1) rc = launch_beam_nt<256, true>(a, shape, lds, err);  // MultiLanguageModel
+    else if (wide) rc = launch_beam_nt<512, false>(a, shape, lds, err);
     else rc = launch_beam_nt<256, false>(a, shape, lds, err);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());

@@ -500,6 +500,33 @@ def test_hip_random_differential_slice():
     assert sum(stats.values()) == 60 and stats.get("ok", 0) + stats.get("ok+chunked", 0) >= 57, stats
 
 
+@pytest.mark.parametrize("threads", ["256", "512"])
+def test_hip_workgroup_kernel_with_four_and_eight_waves(lm, bpe, threads, monkeypatch):
+    """The workgroup kernel runs an utterance on eight waves when every CU holds at most one utterance, on four otherwise
+    (CTCDEC_GROUP_THREADS forces one): the same beams either way, and the oracle's."""
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    _loaded_native()
+    monkeypatch.setenv("CTCDEC_BEAM_KERNEL", "group")
+    monkeypatch.setenv("CTCDEC_GROUP_THREADS", threads)
+    for labels, is_bpe, bw, kw in ((synth.LIBRI_LABELS, False, 100, {}), (bpe, True, 200, {"hotwords": lm.hotwords(5, 3)}),
+                                   (bpe, True, 30, {})):
+        dec = build_ctcdecoder(labels, lm.path)
+        alpha = Alphabet.build_alphabet(labels)
+        orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+        xs = [synth.d_words(6, u, 90, labels, is_bpe, lm.words, lm.sentences, len(labels), boost=4.0)
+              for u in range(3)]
+        xs.append(synth.d_flat(6, 9, 60, len(labels) + 1))
+        got = dec.decode_beams_batch(None, xs, beam_width=bw, **kw)
+        for x, g in zip(xs, got):
+            with np.errstate(all="ignore"):
+                exp = orc.decode_beams(x.astype(np.float64), beam_width=bw, **kw)
+            expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
+            check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g], expd, what="threads " + threads, **_tol(x))
+
+
 def test_hip_ragged_batch_is_dispatched_longest_first(lm, monkeypatch):
     """A ragged batch of more utterances than the device holds at once hands the workgroups out longest utterance first
     (BeamArgs::order); results land where the caller's order says, equal to the plain dispatch and to the oracle."""
