@@ -202,6 +202,10 @@ def _pytexts():
                 dll.ctcdec_py_split_texts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_char]
                 dll.ctcdec_py_texts_from_blocks.restype = C.py_object
                 dll.ctcdec_py_texts_from_blocks.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64]
+                dll.ctcdec_py_output_beams.restype = C.py_object
+                dll.ctcdec_py_output_beams.argtypes = [C.py_object, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.py_object]
                 _PYTEXTS = dll
             except (OSError, AttributeError):
                 _PYTEXTS = False
@@ -219,6 +223,15 @@ def texts_of(lib: "Library", res) -> Optional[list]:
     if n.value == 0:
         return []
     return dll.ctcdec_py_texts_from_blocks(pool, off, ln, n.value)
+
+
+def output_beams(cls, pk: "Packed", states: Optional[list]) -> Optional[list]:
+    """The OutputBeam lists of a packed result, built in C (csrc/pytexts.c); None when the helper was not built."""
+    dll = _pytexts()
+    if not dll:
+        return None
+    return dll.ctcdec_py_output_beams(cls, pk.n_utts, pk.beam_off, pk.text_off, pk.text_blob, pk.logit_score, pk.lm_score,
+                                      pk.word_cnt_off, pk.word_start, pk.word_end, states)
 
 
 def split_texts(blob_ptr, nbytes: int, n: int, sep: bytes):

@@ -45,3 +45,111 @@ PyObject* ctcdec_py_texts_from_blocks(const char* pool, const int64_t* off, cons
   }
   return list;
 }
+
+/* ---- decode_beams / decode_beams_batch: the OutputBeam lists of a packed result (ctcdec_result_pack) ----------------------
+ * What BeamSearchDecoderCTC._unpack does in Python, in one C loop: per utterance a list of
+ *   cls(text, last_lm_state, text_frames = [(word, (start, end)), ...], logit_score, lm_score)
+ * `cls` is the (frozen) dataclass OutputBeam: instances are allocated and their five attributes set directly -- what the
+ * generated __init__ does through object.__setattr__. `states`: None, or a list with the last_lm_state of every beam in
+ * packed order. A text with fewer words than word frames raises IndexError, like words[j] would. */
+static PyObject *k_text, *k_state, *k_frames, *k_logit, *k_lm;
+
+static int beam_attr_names(void) {
+  if (k_text) return 0;
+  k_text = PyUnicode_InternFromString("text");
+  k_state = PyUnicode_InternFromString("last_lm_state");
+  k_frames = PyUnicode_InternFromString("text_frames");
+  k_logit = PyUnicode_InternFromString("logit_score");
+  k_lm = PyUnicode_InternFromString("lm_score");
+  return (k_text && k_state && k_frames && k_logit && k_lm) ? 0 : -1;
+}
+
+/* [(word, (start, end)), ...] for the first n_words words of the UTF-8 text [p, p + len) */
+static PyObject* word_frames(const char* p, int64_t len, int64_t n_words, const int32_t* ws, const int32_t* we) {
+  PyObject* frames = PyList_New((Py_ssize_t)n_words);
+  if (!frames) return NULL;
+  const char* end = p + len;
+  for (int64_t j = 0; j < n_words; ++j) {
+    if (len == 0 || p > end) {  /* "".split(" ") is [] for an empty text; past the last word otherwise */
+      Py_DECREF(frames);
+      PyErr_SetString(PyExc_IndexError, "list index out of range");
+      return NULL;
+    }
+    const char* q = (const char*)memchr(p, ' ', (size_t)(end - p));
+    if (!q) q = end;
+    PyObject* w = PyUnicode_DecodeUTF8(p, (Py_ssize_t)(q - p), "strict");
+    PyObject* a = w ? PyLong_FromLong((long)ws[j]) : NULL;
+    PyObject* b = a ? PyLong_FromLong((long)we[j]) : NULL;
+    PyObject* span = b ? PyTuple_Pack(2, a, b) : NULL;
+    PyObject* item = span ? PyTuple_Pack(2, w, span) : NULL;
+    Py_XDECREF(w);
+    Py_XDECREF(a);
+    Py_XDECREF(b);
+    Py_XDECREF(span);
+    if (!item) {
+      Py_DECREF(frames);
+      return NULL;
+    }
+    PyList_SET_ITEM(frames, (Py_ssize_t)j, item);
+    p = q + 1;
+  }
+  return frames;
+}
+
+PyObject* ctcdec_py_output_beams(PyObject* cls, int64_t n_utts, const int64_t* beam_off, const int64_t* text_off,
+                                 const char* text_blob, const double* logit, const double* lm, const int64_t* word_cnt_off,
+                                 const int32_t* word_start, const int32_t* word_end, PyObject* states) {
+  if (beam_attr_names() < 0) return NULL;
+  if (!PyType_Check(cls)) {
+    PyErr_SetString(PyExc_TypeError, "OutputBeam class expected");
+    return NULL;
+  }
+  PyTypeObject* tp = (PyTypeObject*)cls;
+  const int with_states = states != NULL && states != Py_None;
+  PyObject* out = PyList_New((Py_ssize_t)n_utts);
+  if (!out) return NULL;
+  for (int64_t u = 0; u < n_utts; ++u) {
+    const int64_t k0 = beam_off[u], k1 = beam_off[u + 1];
+    PyObject* beams = PyList_New((Py_ssize_t)(k1 - k0));
+    if (!beams) goto fail;
+    PyList_SET_ITEM(out, (Py_ssize_t)u, beams);
+    for (int64_t k = k0; k < k1; ++k) {
+      const char* tp0 = text_blob + text_off[k];
+      const int64_t tlen = text_off[k + 1] - text_off[k];
+      const int64_t w0 = word_cnt_off[k], w1 = word_cnt_off[k + 1];
+      PyObject* obj = tp->tp_alloc(tp, 0);
+      if (!obj) goto fail;
+      PyList_SET_ITEM(beams, (Py_ssize_t)(k - k0), obj);
+      PyObject* text = PyUnicode_DecodeUTF8(tp0, (Py_ssize_t)tlen, "strict");
+      PyObject* frames = text ? word_frames(tp0, tlen, w1 - w0, word_start ? word_start + w0 : NULL, word_end ? word_end + w0 : NULL) : NULL;
+      PyObject* lg = frames ? PyFloat_FromDouble(logit[k]) : NULL;
+      PyObject* ls = lg ? PyFloat_FromDouble(lm[k]) : NULL;
+      PyObject* st = Py_None;
+      if (ls && with_states) {
+        st = PyList_GetItem(states, (Py_ssize_t)k); /* borrowed */
+        if (!st) {
+          Py_DECREF(text);
+          Py_DECREF(frames);
+          Py_DECREF(lg);
+          Py_DECREF(ls);
+          goto fail;
+        }
+      }
+      int rc = ls ? 0 : -1;
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_text, text);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_state, st);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_frames, frames);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_logit, lg);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_lm, ls);
+      Py_XDECREF(text);
+      Py_XDECREF(frames);
+      Py_XDECREF(lg);
+      Py_XDECREF(ls);
+      if (rc < 0) goto fail;
+    }
+  }
+  return out;
+fail:
+  Py_DECREF(out);
+  return NULL;
+}

@@ -694,6 +694,17 @@ class BeamSearchDecoderCTC:
         out: List[List[OutputBeam]] = []
         if nb == 0:
             return [[] for _ in range(nu)]
+        has_lm = self._language_model is not None
+        if not os.environ.get("CTCDEC_PY_UNPACK"):  # the same lists from one C loop (csrc/pytexts.c)
+            states = None
+            if with_state and has_lm:
+                states = []
+                for u in range(nu):
+                    for k in range(int(beam_off[u]), int(beam_off[u + 1])):
+                        states.append(self._beam_state(res, pk, u, k, k - int(beam_off[u])))
+            built = B.output_beams(OutputBeam, pk, states)
+            if built is not None:
+                return built
         text_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
         blob = C.string_at(pk.text_blob, int(text_off[nb])) if text_off[nb] else b""
         logit = np.ctypeslib.as_array(pk.logit_score, shape=(nb,))
@@ -702,7 +713,6 @@ class BeamSearchDecoderCTC:
         if nw:
             wstart = np.ctypeslib.as_array(pk.word_start, shape=(nw,))
             wend = np.ctypeslib.as_array(pk.word_end, shape=(nw,))
-        has_lm = self._language_model is not None
         for u in range(nu):
             beams = []
             for k in range(int(beam_off[u]), int(beam_off[u + 1])):
@@ -710,20 +720,22 @@ class BeamSearchDecoderCTC:
                 words = text.split(" ") if text else []
                 w0, w1 = int(wco[k]), int(wco[k + 1])
                 frames = [(words[j], (int(wstart[w0 + j]), int(wend[w0 + j]))) for j in range(w1 - w0)]
-                state = None
-                if with_state and has_lm:
-                    state = KenlmState(NgramState.from_c(pk.lm_state[k]))
-                    if len(self._members) > 1:
-                        parts = [state]
-                        for j in range(1, len(self._members)):
-                            cst = B.LmState()
-                            self._lib.check(self._lib.dll.ctcdec_result_lm_state_of(
-                                res, u, k - int(beam_off[u]), j, C.byref(cst)))
-                            parts.append(KenlmState(NgramState.from_c(cst)))
-                        state = MultiLanguageModelState(parts)
+                state = self._beam_state(res, pk, u, k, k - int(beam_off[u])) if (with_state and has_lm) else None
                 beams.append(OutputBeam(text, state, frames, float(logit[k]), float(lm[k])))
             out.append(beams)
         return out
+
+    def _beam_state(self, res, pk, u: int, k: int, j_in_utt: int) -> AbstractLMState:
+        """last_lm_state of packed beam k (beam j_in_utt of utterance u)."""
+        state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[k]))
+        if len(self._members) > 1:
+            parts = [state]
+            for j in range(1, len(self._members)):
+                cst = B.LmState()
+                self._lib.check(self._lib.dll.ctcdec_result_lm_state_of(res, u, j_in_utt, j, C.byref(cst)))
+                parts.append(KenlmState(NgramState.from_c(cst)))
+            state = MultiLanguageModelState(parts)
+        return state
 
     # -- public decode surface (decoder.py:730-945) ----------------------------------------------
     def decode_beams(

@@ -357,6 +357,50 @@ def test_decode_batch_texts_come_from_the_device(kind, sim_library, both_beam_ke
     assert got[1] == "" and all(t == " ".join(t.split()) for t in got)
 
 
+def test_output_beams_built_in_c_equal_the_python_ones(sim_library, monkeypatch):  # noqa: F811
+    """decode_beams / decode_beams_batch build their OutputBeam lists in one C loop (csrc/pytexts.c: ctcdec_py_output_beams);
+    CTCDEC_PY_UNPACK=1 takes the Python loop it replaces: same objects field by field (types included), with and without
+    LM states, several LMs, empty utterances, non-ASCII labels; and the instances are the frozen dataclass they claim to be."""
+    import dataclasses
+
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.decoder import OutputBeam
+    from pyctcdecode_amd.language_model import LanguageModel, MultiLanguageModel, NgramModel
+
+    def key(o):
+        st = o.last_lm_state
+        parts = [] if st is None else (st.states if hasattr(st, "states") else [st])
+        assert type(o) is OutputBeam and type(o.text) is str and type(o.logit_score) is float and type(o.lm_score) is float
+        assert all(type(f) is tuple and type(f[0]) is str and type(f[1]) is tuple and type(f[1][0]) is int for f in o.text_frames)
+        return (o.text, o.text_frames, o.logit_score, o.lm_score, [bytes(p.state.to_c()) for p in parts])
+
+    lm2 = synth.SynthLM(LM_DIR + "_b", 200, 300, order=3, seed=5)
+    multi = MultiLanguageModel([LanguageModel(NgramModel(LM.path), LM.words), LanguageModel(NgramModel(lm2.path), lm2.words)])
+    from pyctcdecode_amd.alphabet import Alphabet
+    from pyctcdecode_amd.decoder import BeamSearchDecoderCTC
+
+    uni = ["\u00e9", "\u4e2d", "a", "b", " "]
+    decs = [(build_ctcdecoder(synth.LIBRI_LABELS, LM.path), 29), (build_ctcdecoder(synth.LIBRI_LABELS), 29),
+            (BeamSearchDecoderCTC(Alphabet.build_alphabet(synth.LIBRI_LABELS), multi), 29), (build_ctcdecoder(uni), 6)]
+    rng = np.random.default_rng(3)
+    for dec, V in decs:
+        xs = [rng.standard_normal((40, V)) * 3.0, np.zeros((0, V)), rng.standard_normal((7, V)) * 2.0]
+        got = {}
+        for mode in ("c", "py"):
+            if mode == "py":
+                monkeypatch.setenv("CTCDEC_PY_UNPACK", "1")
+            else:
+                monkeypatch.delenv("CTCDEC_PY_UNPACK", raising=False)
+            got[mode] = ([[key(o) for o in dec.decode_beams(x, beam_width=20)] for x in xs if len(x)],
+                         [[key(o) for o in u] for u in dec.decode_beams_batch(None, xs, beam_width=20)])
+        assert got["c"] == got["py"]
+        monkeypatch.delenv("CTCDEC_PY_UNPACK", raising=False)
+        beam = dec.decode_beams(xs[0], beam_width=20)[0]
+        with pytest.raises(dataclasses.FrozenInstanceError):
+            beam.text = "x"
+        assert dataclasses.replace(beam) == beam and beam.get_mp_safe_beam().text == beam.text
+
+
 def test_ragged_batch_dispatched_longest_first(sim_library, both_beam_kernels, monkeypatch):  # noqa: F811
     """More utterances than the device holds at once and of different lengths: the beam stage takes them longest first
     (BeamArgs::order; the simulator walks the same order); every result lands in the caller's slot."""
