@@ -206,6 +206,12 @@ def _pytexts():
                 dll.ctcdec_py_output_beams.argtypes = [C.py_object, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
                                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.py_object]
+                dll.ctcdec_py_lm_beams.restype = C.py_object
+                dll.ctcdec_py_lm_beams.argtypes = [C.py_object, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
+                                                   C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32), C.py_object,
+                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                                   C.POINTER(C.c_double)]
                 _PYTEXTS = dll
             except (OSError, AttributeError):
                 _PYTEXTS = False
@@ -232,6 +238,16 @@ def output_beams(cls, pk: "Packed", states: Optional[list]) -> Optional[list]:
         return None
     return dll.ctcdec_py_output_beams(cls, pk.n_utts, pk.beam_off, pk.text_off, pk.text_blob, pk.logit_score, pk.lm_score,
                                       pk.word_cnt_off, pk.word_start, pk.word_end, states)
+
+
+def lm_beams(cls, n_streams: int, pk: "Packed", labels: list) -> Optional[list]:
+    """The LMBeam lists of a packed streaming result, built in C (csrc/pytexts.c); None when the helper was not built."""
+    dll = _pytexts()
+    if not dll:
+        return None
+    return dll.ctcdec_py_lm_beams(cls, n_streams, pk.beam_off, pk.text_off, pk.text_blob, pk.partial_off, pk.partial_blob,
+                                  pk.last_char, labels, pk.word_cnt_off, pk.word_start, pk.word_end, pk.partial_start,
+                                  pk.partial_end, pk.logit_score, pk.lm_score)
 
 
 def split_texts(blob_ptr, nbytes: int, n: int, sep: bytes):

@@ -153,3 +153,95 @@ fail:
   Py_DECREF(out);
   return NULL;
 }
+
+/* ---- partial_decode_beams(_batch): the LMBeam lists of a packed streaming result -----------------------------------------
+ * What _DeviceStreams.unpack does per beam in Python:
+ *   cls(text, next_word = "", partial_word, last_char, text_frames = [(start, end), ...], partial_frames = (ps, pe),
+ *       logit_score, lm_score)
+ * `cls` is the frozen dataclass LMBeam; `labels`: list of str, last_char = labels[k] for k >= 0, None below. */
+static PyObject *k_next, *k_partial, *k_last, *k_pframes;
+
+PyObject* ctcdec_py_lm_beams(PyObject* cls, int64_t n_streams, const int64_t* beam_off, const int64_t* text_off,
+                             const char* text_blob, const int64_t* partial_off, const char* partial_blob, const int32_t* last_char,
+                             PyObject* labels, const int64_t* word_cnt_off, const int32_t* word_start, const int32_t* word_end,
+                             const int32_t* pstart, const int32_t* pend, const double* logit, const double* lm) {
+  if (beam_attr_names() < 0) return NULL;
+  if (!k_next) {
+    k_next = PyUnicode_InternFromString("next_word");
+    k_partial = PyUnicode_InternFromString("partial_word");
+    k_last = PyUnicode_InternFromString("last_char");
+    k_pframes = PyUnicode_InternFromString("partial_frames");
+    if (!k_next || !k_partial || !k_last || !k_pframes) return NULL;
+  }
+  if (!PyType_Check(cls) || !PyList_Check(labels)) {
+    PyErr_SetString(PyExc_TypeError, "LMBeam class and a list of labels expected");
+    return NULL;
+  }
+  PyTypeObject* tp = (PyTypeObject*)cls;
+  PyObject* empty = PyUnicode_FromStringAndSize("", 0);
+  if (!empty) return NULL;
+  PyObject* out = PyList_New((Py_ssize_t)n_streams);
+  if (!out) {
+    Py_DECREF(empty);
+    return NULL;
+  }
+  for (int64_t u = 0; u < n_streams; ++u) {
+    const int64_t k0 = beam_off[u], k1 = beam_off[u + 1];
+    PyObject* beams = PyList_New((Py_ssize_t)(k1 - k0));
+    if (!beams) goto fail;
+    PyList_SET_ITEM(out, (Py_ssize_t)u, beams);
+    for (int64_t k = k0; k < k1; ++k) {
+      PyObject* obj = tp->tp_alloc(tp, 0);
+      if (!obj) goto fail;
+      PyList_SET_ITEM(beams, (Py_ssize_t)(k - k0), obj);
+      const int64_t w0 = word_cnt_off[k], w1 = word_cnt_off[k + 1];
+      PyObject* text = PyUnicode_DecodeUTF8(text_blob + text_off[k], (Py_ssize_t)(text_off[k + 1] - text_off[k]), "strict");
+      PyObject* part = text ? PyUnicode_DecodeUTF8(partial_blob + partial_off[k], (Py_ssize_t)(partial_off[k + 1] - partial_off[k]), "strict") : NULL;
+      PyObject* frames = part ? PyList_New((Py_ssize_t)(w1 - w0)) : NULL;
+      int ok = frames != NULL;
+      for (int64_t w = w0; ok && w < w1; ++w) {
+        PyObject* a = PyLong_FromLong((long)word_start[w]);
+        PyObject* b = a ? PyLong_FromLong((long)word_end[w]) : NULL;
+        PyObject* span = b ? PyTuple_Pack(2, a, b) : NULL;
+        Py_XDECREF(a);
+        Py_XDECREF(b);
+        if (!span) ok = 0;
+        else PyList_SET_ITEM(frames, (Py_ssize_t)(w - w0), span);
+      }
+      PyObject* pa = ok ? PyLong_FromLong((long)pstart[k]) : NULL;
+      PyObject* pb = pa ? PyLong_FromLong((long)pend[k]) : NULL;
+      PyObject* pf = pb ? PyTuple_Pack(2, pa, pb) : NULL;
+      PyObject* lg = pf ? PyFloat_FromDouble(logit[k]) : NULL;
+      PyObject* ls = lg ? PyFloat_FromDouble(lm[k]) : NULL;
+      PyObject* last = Py_None; /* borrowed either way */
+      if (ls && last_char[k] >= 0) {
+        last = PyList_GetItem(labels, (Py_ssize_t)last_char[k]);
+        if (!last) ls = (Py_DECREF(ls), (PyObject*)NULL);
+      }
+      int rc = ls ? 0 : -1;
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_text, text);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_next, empty);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_partial, part);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_last, last);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_frames, frames);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_pframes, pf);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_logit, lg);
+      if (rc == 0) rc = PyObject_GenericSetAttr(obj, k_lm, ls);
+      Py_XDECREF(text);
+      Py_XDECREF(part);
+      Py_XDECREF(frames);
+      Py_XDECREF(pa);
+      Py_XDECREF(pb);
+      Py_XDECREF(pf);
+      Py_XDECREF(lg);
+      Py_XDECREF(ls);
+      if (rc < 0) goto fail;
+    }
+  }
+  Py_DECREF(empty);
+  return out;
+fail:
+  Py_DECREF(empty);
+  Py_DECREF(out);
+  return NULL;
+}

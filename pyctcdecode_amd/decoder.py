@@ -386,6 +386,21 @@ class _DeviceStreams:
         if nb == 0:
             return [[] for _ in range(n)]
         b_off = np.ctypeslib.as_array(pk.beam_off, shape=(n + 1,))
+        if self.parents is None and not os.environ.get("CTCDEC_PY_UNPACK"):
+            # the same lists from one C loop (csrc/pytexts.c); the memo entries of new texts are added here
+            built = B.lm_beams(LMBeam, n, pk, dec._labels_list)
+            if built is not None:
+                if has_lm:
+                    raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,))
+                    for u in range(n):
+                        memo = self.memos[u] if u < len(self.memos) else {}
+                        j = int(b_off[u])
+                        for beam in built[u]:
+                            key = (beam.text, False)
+                            if key not in memo:
+                                memo[key] = (float(raw[j]), float(raw[j]), self._state_of(res, pk, u, j, j - int(b_off[u]), n_lms))
+                            j += 1
+                return built
         t_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
         tblob = C.string_at(pk.text_blob, int(t_off[nb])) if t_off[nb] else b""
         p_off = np.ctypeslib.as_array(pk.partial_off, shape=(nb + 1,))
@@ -414,17 +429,20 @@ class _DeviceStreams:
                 last = None if lch[j] < 0 else dec._idx2vocab[int(lch[j])]
                 outs.append(LMBeam(text, "", partial, last, new_frames, (int(ps[j]), int(pe[j])), float(logit[j]), float(lms[j])))
                 if has_lm and (text, False) not in memo:
-                    state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[j]))
-                    if n_lms > 1:
-                        parts = [state]
-                        for x in range(1, n_lms):
-                            cst = B.LmState()
-                            lib.check(lib.dll.ctcdec_result_lm_state_of(res, u, j - int(b_off[u]), x, C.byref(cst)))
-                            parts.append(KenlmState(NgramState.from_c(cst)))
-                        state = MultiLanguageModelState(parts)
-                    memo[(text, False)] = (float(raw[j]), float(raw[j]), state)
+                    memo[(text, False)] = (float(raw[j]), float(raw[j]), self._state_of(res, pk, u, j, j - int(b_off[u]), n_lms))
             out.append(outs)
         return out
+
+    def _state_of(self, res, pk, u: int, j: int, j_in_stream: int, n_lms: int) -> AbstractLMState:
+        state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[j]))
+        if n_lms > 1:
+            parts = [state]
+            for x in range(1, n_lms):
+                cst = B.LmState()
+                self.lib.check(self.lib.dll.ctcdec_result_lm_state_of(res, u, j_in_stream, x, C.byref(cst)))
+                parts.append(KenlmState(NgramState.from_c(cst)))
+            state = MultiLanguageModelState(parts)
+        return state
 
 
 class _ResidentBeams(list):
@@ -504,6 +522,7 @@ class BeamSearchDecoderCTC:
     def __init__(self, alphabet: Alphabet, language_model: Optional[AbstractLanguageModel] = None) -> None:
         self._alphabet = alphabet
         self._idx2vocab = {n: c for n, c in enumerate(self._alphabet.labels)}
+        self._labels_list = list(self._alphabet.labels)
         self._vocab2idx = {c: n for n, c in enumerate(self._alphabet.labels)}
         self._is_bpe = alphabet.is_bpe
         self._model_key = os.urandom(16)

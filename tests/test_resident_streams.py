@@ -173,6 +173,32 @@ def test_best_beam_per_chunk_is_a_cheap_read(sim_library, both_beam_kernels):  #
     _scenario_best_beam_per_chunk(_build(), lambda a: a)
 
 
+def test_lm_beams_built_in_c_equal_the_python_ones(sim_library, monkeypatch):  # noqa: F811
+    """The LMBeam lists of a stream read are built in one C loop (csrc/pytexts.c: ctcdec_py_lm_beams); CTCDEC_PY_UNPACK=1 takes
+    the Python loop it replaces: same beams field by field, same memo entries (cached_lm_scores) in the caller's dicts."""
+
+    def run(py):
+        if py:
+            monkeypatch.setenv("CTCDEC_PY_UNPACK", "1")
+        else:
+            monkeypatch.delenv("CTCDEC_PY_UNPACK", raising=False)
+        dec = _build()(BPE, LM.path)
+        n = 5
+        xs = [synth.d_words(5, u, 120, BPE, True, LM.words, LM.sentences, len(BPE), boost=4.0) for u in range(n)]
+        states = [dec.get_starting_state() for _ in range(n)]
+        beams = [s[0] for s in states]
+        outs = []
+        for k in range(3):
+            beams = dec.partial_decode_beams_batch([x[k * 40:(k + 1) * 40] for x in xs], [s[1] for s in states], [s[2] for s in states],
+                                                   beams, [k * 40] * n, beam_width=60, is_end=(k == 2))
+            outs.append([[(type(b).__name__, b.text, b.next_word, b.partial_word, b.last_char, b.text_frames, b.partial_frames,
+                           b.logit_score, b.lm_score) for b in bl] for bl in beams])
+        memos = [sorted((k[0], v[0], v[1], bytes(v[2].state.to_c())) for k, v in s[1].items()) for s in states]
+        return outs, memos
+
+    assert run(False) == run(True)
+
+
 def test_plain_lists_on_request(sim_library, monkeypatch):  # noqa: F811
     """CTCDEC_RESIDENT_STREAMS=0: every call returns ordinary, filled lists (and fills the caller's memo) like the reference."""
     from pyctcdecode_amd.decoder import _ResidentBeams
