@@ -133,6 +133,42 @@ def one_case(rng):
     return dec, orc, x, dkw
 
 
+def _parted_at_a_tie(dec, orc, x, dkw, win):
+    """Frame by frame through partial_decode_beams on both sides: at the first frame whose beam lists differ, is every beam
+    that only one side kept within `win` of the worst score the OTHER side kept (i.e. the cut fell between equal scores)?"""
+    kw = {k: v for k, v in dkw.items() if k not in ("hotwords", "hotword_weight")}
+    okw = dict(dkw)
+    kw["hotword_scorer"] = HotwordScorer.build_scorer(dkw["hotwords"], weight=dkw["hotword_weight"])
+    beams, c1, c2 = dec.get_starting_state()
+    st = orc.get_starting_state()
+    x64 = x.astype(np.float64)
+    T = x.shape[0]
+    for t in range(T):
+        try:
+            beams = dec.partial_decode_beams(x[t:t + 1], c1, c2, beams, t, is_end=(t == T - 1), **kw)
+            with np.errstate(all="ignore"):
+                ob = orc.partial_decode_beams(x64[t:t + 1], st, t, is_end=(t == T - 1), **okw)
+        except ValueError:
+            return False
+        g = {(b.text, b.partial_word): b.lm_score for b in beams}
+        e = {(o.text, o.partial): o.lm for o in ob}
+        if list(g) == list(e):
+            continue
+        if set(g) == set(e):  # same beams in another order: equal scores swapped
+            return all(abs(g[k] - e[k]) <= win for k in g) and _order_is_tie(list(g), list(e), e, win)
+        if not g or not e:
+            return False
+        g_cut, e_cut = min(g.values()), min(e.values())
+        only_g = [v for k, v in g.items() if k not in e]
+        only_e = [v for k, v in e.items() if k not in g]
+        return all(abs(v - e_cut) <= win for v in only_g) and all(abs(v - g_cut) <= win for v in only_e)
+    return False
+
+
+def _order_is_tie(a, b, score, win):
+    return all(x == y or abs(score[x] - score[y]) <= win for x, y in zip(a, b))
+
+
 def run_case(rng, execute=True):
     dec, orc, x, dkw = one_case(rng)
     if not execute:  # replaying the generator up to the case of interest (FUZZ_ONLY)
@@ -181,6 +217,10 @@ def run_case(rng, execute=True):
         thr = max(list(gm.values()) + list(em.values())) + dkw["beam_prune_logp"]
         on_thr = lambda a: all(abs(v - thr) <= win for v in a)  # noqa: E731
         if common_ok and (only_g or only_e) and on_thr(only_g) and on_thr(only_e):
+            return "near-tie at a cut"
+        # ... or the tie was at a cut in the MIDDLE of the utterance and the two searches have long since gone separate
+        # ways (no twins at the end): step both sides frame by frame and look at the first frame they part at
+        if _parted_at_a_tie(dec, orc, x, dkw, win):
             return "near-tie at a cut"
         raise
     # batch entry points: ragged batch (incl. an empty utterance) == utterance by utterance
