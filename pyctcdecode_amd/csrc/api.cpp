@@ -18,6 +18,7 @@
 #include "../../include/ctcdec.h"
 #include "backend.h"
 #include "beam_core.h"
+#include "beam_wave.h"
 #include "host_tables.h"
 
 using namespace ctc;
@@ -195,7 +196,7 @@ struct ctcdec_decoder {
   HostBuf h_xstate;
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
-      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_tscr, w_tsoff, w_tpool,
+      w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_pay, w_tscr, w_tsoff, w_tpool,
       d_toktext, d_tokbytes, w_slow, w_order;
   uint32_t max_label_bytes = 1;
   bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
@@ -205,7 +206,7 @@ struct ctcdec_decoder {
   ~ctcdec_decoder() {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
-                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold,
+                     &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold, &w_pay,
                      &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow, &w_order};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
@@ -1080,6 +1081,14 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     ba.surv_id = (const uint16_t*)dec->w_sid.p;
     ba.surv_lp = (const double*)dec->w_slp.p;
     dp.max_surv = max_surv;
+    // the wave kernel's payload lines (one per candidate a frame can push into its pool)
+    ba.pay = nullptr;
+    ba.pay_stride = 0;
+    if (wave_eligible(ba.tables, dp)) {
+      ba.pay_stride = (uint64_t)wave_pay_stride(dp);
+      if (dec->w_pay.ensure((size_t)n_utts * (size_t)ba.pay_stride * sizeof(PoolPay), &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      ba.pay = (PoolPay*)dec->w_pay.p;
+    }
     auto run_beam = [&]() -> int {
       if (be::zero(dec->w_head.p, 16, &err)) return -1;
       return be::launch_beam(ba, &err);

@@ -96,6 +96,8 @@ struct BeamArgs {
   const int64_t* import_off;   // [n_utts + 1] (device)
   const int32_t* first_frames; // [n_utts] processed_frames per utterance (device), or nullptr
   ColdRec* cold;               // [n_utts * 2 * COLD_STRIDE] scratch of the wave kernel
+  PoolPay* pay;                // [n_utts * pay_stride] scratch of the wave kernel (nullptr: the decode is not eligible for it)
+  uint64_t pay_stride;
   int32_t max_import;          // streaming: the largest number of beams any stream carries in
   // device-resident streams (ctcdec_stream_*), else nullptr / 0: where stream u's finalisation leaves its beams for the
   // next chunk (carry_out + u * carry_stride; several LMs: carry_xstates + u * carry_stride * (n_lms - 1)), its counters

@@ -1397,6 +1397,7 @@ __global__ __launch_bounds__(NT, NT > 256 ? 1 : 2) void beam_decode(BeamArgs a, 
     io.import_xstates = (a.imports && a.import_xstates && !a.resident_in) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   io.cold = nullptr;
+  io.pay = nullptr;
   io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
   io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (n_lms - 1) : nullptr;
   io.sstate = a.sstate ? a.sstate + u : nullptr;
@@ -1511,8 +1512,8 @@ struct WaveGpuCtx {
   }
 };
 
-template <int BW>
-__global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
+template <int BW, int OCC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void beam_wave(BeamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   WaveLds view;
@@ -1541,6 +1542,7 @@ __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   io.import_xstates = nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   io.cold = a.cold + (size_t)u * 2 * COLD_STRIDE;
+  io.pay = a.pay + (size_t)u * a.pay_stride;
   io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
   io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (1u - 1) : nullptr;
   io.sstate = a.sstate ? a.sstate + u : nullptr;
@@ -1556,11 +1558,11 @@ __global__ __launch_bounds__(64) void beam_wave(BeamArgs a) {
   dec.run();
 }
 
-template <int BW>
+template <int BW, int OCC = 2>
 static int launch_wave_t(const BeamArgs& a, std::string* err) {
   const size_t lds = wave_lds_bytes<BW>();
-  HIP_TRY(hipFuncSetAttribute((const void*)beam_wave<BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((beam_wave<BW>), dim3((unsigned)a.n_utts), dim3(64), lds, g_stream, a);
+  HIP_TRY(hipFuncSetAttribute((const void*)beam_wave<BW, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((beam_wave<BW, OCC>), dim3((unsigned)a.n_utts), dim3(64), lds, g_stream, a);
   return 0;
 }
 
@@ -1613,9 +1615,13 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");
   const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
   // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
-  const bool wave_ok = wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width);
+  const bool wave_ok = wave_eligible(a.tables, a.params) && a.pay && a.max_import <= wave_bucket(a.params.beam_width);
   if (a.n_utts > 0 && wave_ok && !want_group) {
     int rc;
+    const char* occ = getenv("CTCDEC_WAVE_OCC");
+    if (a.params.beam_width <= 24 && occ) {  // EXPERIMENT: occupancy scaling of the wave kernel
+      rc = occ[0] == '4' ? launch_wave_t<24, 4>(a, err) : occ[0] == '3' ? launch_wave_t<24, 3>(a, err) : launch_wave_t<24, 2>(a, err);
+    } else
     switch (wave_bucket(a.params.beam_width)) {
       case 64: rc = launch_wave_t<64>(a, err); break;
       case 100: rc = launch_wave_t<100>(a, err); break;

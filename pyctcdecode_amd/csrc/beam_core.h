@@ -197,11 +197,24 @@ CTC_HD size_t lds_bytes(const LdsShape& s) {
   return lds_carve(tmp, (lds_bytes_t) nullptr, s);
 }
 
-// wave kernel (beam_wave.h): what only the table build and the finalisation need of a beam -- the frames of its open
-// word and the length of its emission chain -- lives outside LDS, two buffers of COLD_STRIDE records per utterance
-struct ColdRec {  // 16 B
-  int32_t pstart, pend;  // partial_frames of the open word
-  uint32_t depth;        // emission nodes on the beam's chain
+// wave kernel (beam_wave.h): what the candidate passes do not read per (label, beam) lives outside LDS, two buffers of
+// COLD_STRIDE records per utterance used alternately by the table builds
+struct ColdRec {  // 64 B
+  double c_lmhw;           // lm + hot-word score of text (+) open word, once that completion exists (M2_COMP)
+  double pscore;           // partial score of the open word
+  uint64_t hist_h;         // hash of the text's last n_hist words (decoder.py:250-251)
+  uint64_t c_hist_h;       // ... of the completion
+  uint32_t cnode;          // TextNode of the completion
+  uint32_t enode;          // end of the beam's emission chain
+  int32_t pstart, pend;    // partial_frames of the open word
+  uint32_t depth;          // emission nodes on the beam's chain
+  uint32_t pad[3];
+};
+// ... and what only the table build needs of a pooled candidate: one line per push, per utterance and frame
+struct PoolPay {  // 32 B
+  double logit;            // summed over the merged duplicates
+  uint64_t part_h;         // the new open word (finalisation: the exact lm_score)
+  uint32_t plen, wid, m2;  // its code points, word id and table view
   uint32_t pad;
 };
 constexpr int COLD_STRIDE = 128;
@@ -230,6 +243,7 @@ struct UttIO {
   int32_t n_import;
   int32_t first_frame;        // processed_frames of this utterance (decoder.py:443)
   ColdRec* cold;              // wave kernel: [2 * COLD_STRIDE]
+  PoolPay* pay;               // wave kernel: [wave_pay_stride(params)] payload lines of the current frame's pool
   // device-resident streams (nullptr / 0 otherwise): where the finalisation leaves the beams for the next chunk (and
   // their LM states of model 1.. for several LMs), the stream's counters, the first free emission node at entry
   // (0: a fresh arena), and whether output records + emission lists are wanted at all for this chunk
@@ -285,9 +299,58 @@ CTC_HD uint64_t score_sort_key(double s) {
   return ~asc;
 }
 
-CTC_HD double lse2(double a, double b) {  // decoder.py:170-177
-  if (a >= b) return a + log(1.0 + exp(b - a));
-  return b + log(1.0 + exp(a - b));
+// decoder.py:170-177: s_hi + math.log(1 + math.exp(s_lo - s_hi)). exp and log are written out here (the same source on
+// the device and in the CPU simulator) instead of calling the math library: the argument ranges are known -- the exponent
+// is in [-37, 0] (below that 1 + e rounds to 1 and the logarithm is exactly 0, as in the reference), the logarithm's
+// argument in [1, 2] -- so neither needs the library versions' range checks, denormal and overflow handling: ~75
+// instructions instead of ~200 per merged duplicate. Both stay below one ulp (against glibc on 2*10^7 random arguments:
+// never more than one ulp apart; the merged score differs in the last bit in 0.2 % of the cases, the rate at which any
+// two libms disagree).
+CTC_HD double lse_bits_f64(uint64_t u) {
+  union { uint64_t u; double d; } c;
+  c.u = u;
+  return c.d;
+}
+CTC_HD double exp_m37_0(double d) {  // e^d, -37 <= d <= 0
+  const double kf = rint(d * 1.4426950408889634074);
+  double r = fma(-kf, 6.93147180369123816490e-01, d);
+  r = fma(-kf, 1.90821492927058770002e-10, r);  // |r| <= ln2 / 2
+  // e^r = 1 + r + r^2 q(r), Taylor to r^13 (truncation 4e-18)
+  double q = 1.0 / 6227020800.0;
+  q = fma(q, r, 1.0 / 479001600.0);
+  q = fma(q, r, 1.0 / 39916800.0);
+  q = fma(q, r, 1.0 / 3628800.0);
+  q = fma(q, r, 1.0 / 362880.0);
+  q = fma(q, r, 1.0 / 40320.0);
+  q = fma(q, r, 1.0 / 5040.0);
+  q = fma(q, r, 1.0 / 720.0);
+  q = fma(q, r, 1.0 / 120.0);
+  q = fma(q, r, 1.0 / 24.0);
+  q = fma(q, r, 1.0 / 6.0);
+  q = fma(q, r, 0.5);
+  const double p = fma(r * r, q, r) + 1.0;
+  const int64_t k = (int64_t)kf;  // >= -54: the scale is a normal number
+  return p * lse_bits_f64((uint64_t)(k + 1023) << 52);
+}
+CTC_HD double log_1_2(double x) {  // log x, 1 <= x <= 2 (the classic s = f / (2 + f) series, Sun's coefficients)
+  const bool big = x > 1.4142135623730951;
+  const double m = big ? x * 0.5 : x, dk = big ? 1.0 : 0.0;
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                            6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+CTC_HD double lse2(double a, double b) {
+  const bool ge = a >= b;
+  const double hi = ge ? a : b, lo = ge ? b : a;
+  const double d = lo - hi;
+  if (d < -37.0) return hi;  // 1 + e^d == 1
+  return hi + log_1_2(1.0 + exp_m37_0(d));  // (a NaN falls through and stays a NaN)
 }
 
 CTC_HD uint64_t hist_hash(const uint64_t* ring, uint32_t cnt) {

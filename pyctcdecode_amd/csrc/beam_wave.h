@@ -4,34 +4,41 @@
 //
 // Same semantics as beam_core.h (which stays the general path: several language models, beam widths
 // above 128, survivor bounds above WAVE_SURV_CAP) but shaped for what a frame of the recursion really is on
-// CDNA4: a few dozen live beams, a handful of surviving labels, ~100 candidates -- and for TWO wavefronts per
-// SIMD (round 3): at beam_width 100 a wave needs 20 KB of LDS and fewer than 256 registers, so eight utterances
-// are resident per CU and each wave's LDS / L2 round trips are covered by its neighbour instead of by
-// software pipelining inside the wave (which is what cost the registers in round 2).
-//   * the beam table is an array of 96-byte records in LDS, read and written 16 bytes at a time
-//     (ds_read_b128 / ds_write_b128); what only the table build touches (frames of the open word, length of the
-//     emission chain) lives in a 16-byte record per beam in global memory;
+// CDNA4: a few dozen live beams, a handful of surviving labels, ~100 candidates -- and, since round 4, for FOUR
+// wavefronts per SIMD: at beam_width 100 a wave owns 9 920 bytes of LDS and is compiled for 128 registers, so
+// sixteen utterances are resident per CU and a batch of 4096 utterances is one round on the 256 CUs.
+//   * LDS holds only what the candidate passes read per (label, beam): three 16-byte columns per beam
+//     ({text hash, partial hash} {logit, last label | length, table view} {lm + hot-word score, text node, word id}),
+//     column-wise so that consecutive lanes read consecutive 16-byte words;
+//   * everything else of a beam -- the scores of its pending word completion, its history hashes, its emission
+//     chain, the frames of the open word -- is a 64-byte record in global memory (ColdRec, two buffers used
+//     alternately by the table builds; L2 resident), fetched by the lanes that need it while they wait for the
+//     table probes anyway;
 //   * candidates (label s, beam i) are spread densely over the lanes, whole labels per pass, one candidate per
-//     lane; with more than 64 live beams (3.7 % of the frames of the bench input) a label is two half passes
-//     matched together, everything but the keys regenerated per half;
+//     lane; with more than 64 live beams a label is two half passes matched together;
 //   * duplicates are found by a wave-wide hash match: one ds_max_u64 per candidate on
 //     (57-bit key tag | 127 - candidate) and one read back -- the smallest candidate of the largest tag
 //     owns a slot, losers move on to their next slot; the members of a group announce themselves to
 //     their representative through one ds_or on a 64-bit mask, which gives the representative the
 //     fold order (ascending beam rank, decoder.py:217-223) and the donor (last arrival) at once;
-//   * the pool of merged, scored candidates holds beam_width + 32 entries; a push that would not fit first
-//     compacts it to its best beam_width (exact: pruning is monotone);
+//   * the pool of merged, scored candidates keeps 24 bytes per entry in LDS -- {score key, history key} for the
+//     ranking walk, {arrival, payload index, donor} -- and the rest (summed logit, new partial word, its table
+//     view) in a per-utterance payload line in global memory that only the table build reads; the pool holds
+//     beam_width + 28 entries, a push that would not fit first compacts it to its best beam_width (exact:
+//     pruning is monotone);
 //   * threshold, top-B and the history prune are one counting sweep over the pool's {score key, history
-//     key} chunks that every lane reads at the same address (an LDS broadcast);
-//   * the next table is built by gathering (pool entry, donor record, label record) per kept rank;
+//     key} words that every lane reads at the same address (an LDS broadcast);
+//   * the next table is built in place by gathering (pool entry, payload, donor columns, donor record) per kept rank;
 //   * runs of frames whose only survivor is the label every beam already ends in (most frames of a real
 //     posterior) are consumed in place, 64 at a time, each checked to leave the order intact (label_run).
 // Diagnostics, all off by default: CTC_WAVE_TRACE (device printf of pool / beam records), CTC_RUN_TRACE
 // (host: which frames label_run consumed), CTC_SIM_DEBUG (index checks in the simulator), CTC_STATS (simulator:
 // live beams / survivors / pool entries per frame), tick<>() phase timers (ctcdec_profile_phases).
-// Everything a lane shares with another lane goes through LDS or a cross-lane instruction; `wsync()`
+// Everything a lane shares with another lane goes through LDS, global memory or a cross-lane instruction; `wsync()`
 // marks the points where LDS traffic of different lanes meets (on the device a compiler fence -- one
-// wave issues its LDS operations in order --, in the 64-fiber test simulator a rendezvous).
+// wave issues its LDS operations in order --, in the 64-fiber test simulator a rendezvous). Global memory written by
+// one lane and read by another of the same wave needs no more than program order either: the accesses of a wave
+// pass through its CU's vector cache in issue order.
 #pragma once
 #include "beam_core.h"
 
@@ -39,6 +46,7 @@ namespace ctc {
 
 typedef uint32_t u32x4 __attribute__((vector_size(16)));
 typedef uint32_t u32x4a __attribute__((vector_size(16), may_alias));  // 16-byte view of a structure in global memory
+typedef uint32_t u32x2a __attribute__((vector_size(8), may_alias));
 
 CTC_HD uint64_t pack64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 CTC_HD double bits_f64(uint64_t u) {
@@ -93,80 +101,72 @@ CTC_HD uint64_t fin64(uint64_t x) {
 }
 
 // ---- layout ------------------------------------------------------------------------------------------------
-// beam record (LDS): 6 chunks of 16 bytes
-//   0: text_h, part_h          1: logit, meta1, meta2       2: c_text_h, lm_hw     3: c_lm_hw, pscore
-//   4: hist_h, c_hist_h        5: text_node, comp_node, word_id, emit_node
-// meta1 = last label | code points of the open word << 16; meta2 = prefix-table / hot-word view of the open word.
-// What only the table build and the finalisation touch -- the frames of the open word and the length of the emission
-// chain -- lives in global memory (ColdRec, two buffers used alternately: a build reads the donors' records from one
-// and writes the new ones to the other).
-constexpr int BREC = 6;
-constexpr int R64 = 2 * BREC;  // 64-bit words per record
-constexpr int R32 = 4 * BREC;  // 32-bit words per record
-enum : int { F_TEXT = 0, F_PART = 1, F_LOGIT = 2, F_CTEXT = 4, F_LMHW = 5, F_CLMHW = 6, F_PSCORE = 7, F_HIST = 8, F_CHIST = 9 };
-enum : int { W_META1 = 6, W_META2 = 7, W_TNODE = 20, W_CNODE = 21, W_WID = 22, W_ENODE = 23 };
-constexpr int WAVE_LAB = 32;        // survivors are staged in LDS (ids, modes, label constants) 32 at a time
+// A live beam, LDS part: three columns of 16-byte words
+//   A: text_h, part_h          B: logit, meta1, meta2          C: lm_hw, text_node, word_id
+// meta1 = last label | code points of the open word << 16; meta2 = prefix-table / hot-word view of the open word, plus
+// M2_COMP: the completion of the open word (text (+) word: its TextNode, scores and history hash) exists in the beam's
+// ColdRec. The rest of the beam is its ColdRec in global memory (beam_core.h).
+constexpr uint32_t M2_COMP = 64u;
+constexpr int WAVE_LAB = 16;        // survivors are staged in LDS (ids, modes, label constants) 16 at a time
 constexpr int WAVE_SURV_CAP = 480;  // survivors per frame this kernel handles: arrival = s * N + beam has to fit 16 bits
 
 template <int BW>
 struct WaveShape {
   static constexpr int SLB = (BW + 63) / 64;  // beam slots per lane (lane = beam phases)
-  static constexpr int P = BW + 32;           // pool capacity (a multiple of 4: the ranking walk reads four entries at a time);
+  static constexpr int P = BW + 28;           // pool capacity (a multiple of 4: the ranking walk reads four entries at a time);
                                               // a push that would not fit first compacts the pool to its best beam_width
   static constexpr int PE = (P + 63) / 64;    // pool entries per lane
   static constexpr int TS = 128;              // match-table slots
-  static constexpr int STAGE = BW > 64 ? (BW - 64) * 16 * BREC : 0;  // build of more than 64 beams: records of the ranks 64..
+  static constexpr int STAGE = BW > 64 ? (BW - 64) * 48 : 0;  // build of more than 64 beams: columns of the ranks 64..
   static_assert(P % 4 == 0, "pool capacity must be a multiple of 4");
   static_assert(BW <= 128, "one label's candidates are at most two per lane");
 };
 
 struct WaveLds {
-  LPtr<u32x4> beams;     // [BW * BREC]
-  // pool of merged, scored candidates: 3 chunks per entry
-  //   0: score key (ascending = better), history key   1: logit, new partial hash
-  //   2: arrival | new plen << 16, donor word, word id, meta2
+  LPtr<u32x4> hA, hB, hC;  // [BW] each
+  // pool of merged, scored candidates
+  LPtr<u32x4> pk;          // [P]  {score key (ascending = better), history key}
+  LPtr<uint64_t> pa;       // [P]  low word: arrival | payload index << 16; high word: donor
   // donor word: beam index | label << 8 | label is blank << 29 | donor's branch << 30
-  LPtr<u32x4> pool;      // [P * 3]
-  LPtr<u32x4> stage;     // the three regions below, as one: records of the ranks 64.. while a table of more than 64 beams is built
-  LPtr<u32x4> surv;      // [WAVE_LAB]       {id, mode word, lp lo, lp hi}
-  LPtr<u32x4> lab;       // [WAVE_LAB * 3]   {h_raw, pow_raw} {h_clean, len_raw, len_clean} {flags, start_flags, start_word_id, hot}
-  // merge scratch of one pass of <= 64 candidates
-  LPtr<double> c_logit;  // [64]
-  LPtr<uint32_t> c_br;   // [64]   branch of the candidate (the donor's is what the new beam is built from)
-  LPtr<uint64_t> table;  // [128]
-  LPtr<uint32_t> gmask;  // [64 * 2]  members of the group a candidate represents
-  LPtr<double> scr;      // the merge scratch as doubles (label_run: one score per live beam)
-  LPtr<uint32_t> sel;    // [BW]  rank -> pool index; end of the merge scratch (never live at the same time)
-  // scalar views of the beam records
-  LPtr<uint64_t> b64;
-  LPtr<double> bf64;
-  LPtr<uint32_t> b32;
+  LPtr<u32x4> stage;       // the regions below, as one: columns of the ranks 64.. while a table of more than 64 beams is built
+  LPtr<u32x4> lab;         // [WAVE_LAB * 4]  {id, mode word, lp lo, lp hi} {h_raw, pow_raw} {h_clean, len_raw, len_clean}
+                           //                 {flags, start_flags, start_word_id, hot}
+  LPtr<uint64_t> table;    // [128] match table of one pass of <= 128 candidates
+  // views of the table's words while no match is running (the last rendezvous of a match is behind them):
+  LPtr<uint32_t> gmask;    // [64 * 2]  members of the group a candidate represents
+  LPtr<double> scr;        // [BW]      label_run: one score per live beam
+  LPtr<uint32_t> sel;      // [BW]      rank -> pool index
+  // scalar views of the columns
+  LPtr<uint64_t> a64, b64, c64;
+  LPtr<uint32_t> b32, c32;
 };
 
 template <int BW>
 CTC_HD size_t wave_lds_carve(WaveLds& o, lds_bytes_t base) {
   typedef WaveShape<BW> S;
   lds_bytes_t p = base;
-  o.beams = lds_take<u32x4>(p, 16 * BREC * BW);
-  o.b64.p = (CTC_LDS uint64_t*)o.beams.p;
-  o.bf64.p = (CTC_LDS double*)o.beams.p;
-  o.b32.p = (CTC_LDS uint32_t*)o.beams.p;
-  o.pool = lds_take<u32x4>(p, 48 * S::P);
+  o.hA = lds_take<u32x4>(p, 16 * BW);
+  o.hB = lds_take<u32x4>(p, 16 * BW);
+  o.hC = lds_take<u32x4>(p, 16 * BW);
+  o.a64.p = (CTC_LDS uint64_t*)o.hA.p;
+  o.b64.p = (CTC_LDS uint64_t*)o.hB.p;
+  o.c64.p = (CTC_LDS uint64_t*)o.hC.p;
+  o.b32.p = (CTC_LDS uint32_t*)o.hB.p;
+  o.c32.p = (CTC_LDS uint32_t*)o.hC.p;
+  o.pk = lds_take<u32x4>(p, 16 * S::P);
+  o.pa = lds_take<uint64_t>(p, 8 * S::P);
   lds_bytes_t stage0 = p;
   o.stage.p = (CTC_LDS u32x4*)p;
-  o.surv = lds_take<u32x4>(p, 16 * WAVE_LAB);
-  o.lab = lds_take<u32x4>(p, 16 * 3 * WAVE_LAB);
+  o.lab = lds_take<u32x4>(p, 16 * 4 * WAVE_LAB);
   lds_bytes_t shared0 = p;
-  o.scr.p = (CTC_LDS double*)p;
-  o.c_logit = lds_take<double>(p, 8 * 64);
-  o.c_br = lds_take<uint32_t>(p, 4 * 64);
   o.table = lds_take<uint64_t>(p, 8 * S::TS);
-  o.gmask = lds_take<uint32_t>(p, 8 * 64);
+  o.gmask.p = (CTC_LDS uint32_t*)shared0;
+  o.scr.p = (CTC_LDS double*)shared0;
+  o.sel.p = (CTC_LDS uint32_t*)shared0;
   size_t shared = (size_t)(p - shared0);
-  if (shared < (size_t)(8 * BW)) shared = align16((size_t)(8 * BW));                   // label_run's scores
+  if (shared < (size_t)(8 * BW)) shared = align16((size_t)(8 * BW));  // label_run's scores
   if ((size_t)(shared0 - stage0) + shared < (size_t)S::STAGE) shared = (size_t)S::STAGE - (size_t)(shared0 - stage0);
   p = shared0 + shared;
-  o.sel.p = (CTC_LDS uint32_t*)(p - align16((size_t)(4 * BW)));
   return (size_t)(p - base);
 }
 template <int BW>
@@ -180,12 +180,15 @@ CTC_HD bool wave_eligible(const DeviceTables& t, const DecodeParams& p) {
   return t.n_lms <= 1 && p.beam_width <= 128 && p.max_surv <= WAVE_SURV_CAP;
 }
 CTC_HD int wave_bucket(int beam_width) { return beam_width <= 64 ? 64 : beam_width <= 100 ? 100 : 128; }
+// payload lines per utterance: one per candidate that can be pushed in a frame
+CTC_HD size_t wave_pay_stride(const DecodeParams& p) { return (size_t)p.max_surv * (size_t)wave_bucket(p.beam_width); }
 
 constexpr int W_PROF_LOAD = 0, W_PROF_COMP = 1, W_PROF_GEN = 2, W_PROF_MATCH = 3, W_PROF_FOLD = 4, W_PROF_SCORE = 5,
               W_PROF_RANK = 6, W_PROF_BUILD = 7, W_PROF_FINAL = 8, W_PROF_COMPACT = 9, W_PROF_PUSH = 10, W_PROF_PFTOK = 11,
               W_PROF_GATHER = 12, W_PROF_BIG = 13, W_PROF_TABLES = 14, W_PROF_RUN = 15, W_PROF_N = 16;
 
-template <class Ctx, int BW>
+// ORD: the highest n-gram order compiled in (4 covers the usual models; 6 everything the tables can hold)
+template <class Ctx, int BW, int ORD = MAX_CTX + 1>
 struct WaveDecoder {
   typedef WaveShape<BW> S;
   static constexpr int SLB = S::SLB;
@@ -202,6 +205,7 @@ struct WaveDecoder {
   // wave-uniform state (every lane holds the same value)
   int N = 1;
   uint32_t pool_n = 0;
+  uint32_t pay_n = 0;    // payload lines used this frame
   uint64_t runmax = 0;   // ascending-sortable key of the best score pushed this frame
   uint64_t kth_key = 0;  // after a pool compaction: key a later candidate has to beat
   uint32_t text_next = 1, emit_next = 1, status = 0;
@@ -257,7 +261,7 @@ struct WaveDecoder {
     if (!pf_live) return;
     // (every lane loads the same count)
     pf_cnt = io.surv_cnt[t];
-    if (lane < prm.max_surv) {
+    if (lane < WAVE_LAB && lane < prm.max_surv) {
       pf_id = io.surv_id[(size_t)t * prm.max_surv + lane];
       pf_lp = io.surv_lp[(size_t)t * prm.max_surv + lane];
     }
@@ -288,10 +292,10 @@ struct WaveDecoder {
   }
   CTC_HD void tok_commit(const TokRegs& r) {
     if (tok_mine()) {
-      L.lab[lane * 3] = mk4q(r.h_raw, r.pow_raw);
-      L.lab[lane * 3 + 1] = mk4((uint32_t)r.h_clean, (uint32_t)(r.h_clean >> 32), r.len_raw, r.len_clean);
+      L.lab[lane * 4 + 1] = mk4q(r.h_raw, r.pow_raw);
+      L.lab[lane * 4 + 2] = mk4((uint32_t)r.h_clean, (uint32_t)(r.h_clean >> 32), r.len_raw, r.len_clean);
       const uint32_t hot = ((uint32_t)r.hot_raw & 0xFFFFu) | ((uint32_t)(r.hot_raw >> 32) ? 0x80000000u : 0u);
-      L.lab[lane * 3 + 2] = mk4(r.flags, r.start_flags, r.start_word_id, hot);
+      L.lab[lane * 4 + 3] = mk4(r.flags, r.start_flags, r.start_word_id, hot);
     }
     ctx.wsync();
   }
@@ -330,16 +334,15 @@ struct WaveDecoder {
   // ---- completion of a beam's open word: the (text (+) partial) prefix ------------------------
   // One TextNode per completed prefix (the reference's memo entry, decoder.py:387-396); lane = beam. Done on the
   // spot: source node -> n-gram probes -> new node are three dependent global round trips, which the other
-  // wavefronts of the SIMD cover (an earlier version spread them over the frame inside the one resident wave and paid
-  // ~70 registers for it -- the registers that kept the second wave out).
+  // wavefronts of the SIMD cover. What later phases need of the completion goes to the beam's ColdRec.
   CTC_HD void completions_now() {
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       if (j * 64 >= N) continue;
       const int i = j * 64 + lane;
       const int ii = i < N ? i : 0;
-      const u32x4 k1 = L.beams[ii * BREC + 1], k5 = L.beams[ii * BREC + 5];
-      const bool todo = i < N && (k1[2] >> 16) > 0 && k5[1] == 0;
+      const u32x4 k1 = L.hB[ii];
+      const bool todo = i < N && (k1[2] >> 16) > 0 && !(k1[3] & M2_COMP);
       const uint64_t m = ctx.ballot(todo);
       if (m == 0ull) continue;
       uint32_t idx = text_next + prefix_cnt(m);
@@ -349,12 +352,13 @@ CTC_UNROLL
         status |= ST_TEXT_OVERFLOW;  // (made wave-wide at the end of the frame)
         idx = io.text_cap - 1;
       }
-      const uint32_t wid = k5[2], m2 = k1[3];
-      const u32x4 k0 = L.beams[i * BREC];
+      const u32x4 k2 = L.hC[i];
+      const uint32_t wid = k2[3], m2 = k1[3];
+      const u32x4 k0 = L.hA[i];
       const uint64_t text = q_lo(k0), part_h = q_hi(k0);
       // TextNode as 16-byte chunks: 0 text_h, raw_lm | 2 hw_cnt, ring_cnt, state.len, words[0] | 3 words[1..4]
       // | 4 backoff[0..3] | 5 backoff[4], pad, ring[0] | 6 ring[1], ring[2] | 7 ring[3], ring[4]
-      const TextNode& sn = io.text_nodes[k5[0]];
+      const TextNode& sn = io.text_nodes[k2[2]];
       const u32x4a* src = (const u32x4a*)&sn;
       double raw = sn.raw_lm;
       const u32x4 c2 = src[2], c3 = src[3], c4 = src[4], c5 = src[5], c6 = src[6];
@@ -373,7 +377,7 @@ CTC_UNROLL
       in.backoff[4] = bits_f32(c5[0]);
       out = in;
       if (tab.has_lm) {
-        const float base = lm_base_score(tab, in, wid, &out);
+        const float base = lm_base_score<ORD>(tab, in, wid, &out);
         raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
       }
       const uint32_t cnt = c2[0] + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
@@ -399,16 +403,17 @@ CTC_UNROLL
       dst[5] = mk4(f32_bits(out.backoff[4]), 0u, (uint32_t)ring[0], (uint32_t)(ring[0] >> 32));
       dst[6] = mk4q(ring[1], ring[2]);
       dst[7] = mk4q(ring[3], ring[4]);
-      L.b64[i * R64 + F_CTEXT] = th;
-      L.b32[i * R32 + W_CNODE] = idx;
-      L.bf64[i * R64 + F_CLMHW] = lmhw;
-      L.b64[i * R64 + F_CHIST] = hh;
+      ColdRec& cr = cold_cur()[i];
+      cr.c_lmhw = lmhw;
+      cr.c_hist_h = hh;
+      cr.cnode = idx;
+      L.b32[i * 4 + 3] = m2 | M2_COMP;
     }
   }
 
   // ---- pool ranking --------------------------------------------------------------------------
   // Pool slot k (entries k * 64 + lane) against the whole pool: every lane walks the entries' {score key, history key}
-  // chunks with broadcast LDS reads, four per iteration (the caller padded the list to a multiple of four with keys
+  // words with broadcast LDS reads, four per iteration (the caller padded the list to a multiple of four with keys
   // that beat nobody), counts the entries that beat its own and notes a better one with its history key.
   // An entry below the threshold has a larger key than every entry that passes, so it never counts against one.
   // TIES: equal keys are ordered by arrival (heapq.nlargest is stable) -- only run when the plain walk found some.
@@ -417,14 +422,14 @@ CTC_UNROLL
     const uint32_t e = (uint32_t)(k * 64 + lane);
     const bool mine = e < n;
     u32x4 p0 = mk4(~0u, ~0u, 0, 0);
-    if (mine) p0 = L.pool[e * 3];
+    if (mine) p0 = L.pk[e];
     const bool ok = mine && q_lo(p0) <= thr_key;
     const uint64_t key = ok ? q_lo(p0) : ~0ull, hk = with_hist ? q_hi(p0) : 0ull;
     uint32_t rank = 0, dup = 0;
     if (!TIES) {
       if (with_hist) {
         for (uint32_t j = 0; j < n; j += 4u) {
-          const u32x4 r0 = L.pool[j * 3], r1 = L.pool[j * 3 + 3u], r2 = L.pool[j * 3 + 6u], r3 = L.pool[j * 3 + 9u];
+          const u32x4 r0 = L.pk[j], r1 = L.pk[j + 1u], r2 = L.pk[j + 2u], r3 = L.pk[j + 3u];
           const bool b0 = q_lo(r0) < key, b1 = q_lo(r1) < key, b2 = q_lo(r2) < key, b3 = q_lo(r3) < key;
           rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u) + (b2 ? 1u : 0u) + (b3 ? 1u : 0u);
           // (bitwise, not short-circuit: the latter became a ladder of exec-mask branches)
@@ -432,15 +437,15 @@ CTC_UNROLL
         }
       } else {
         for (uint32_t j = 0; j < n; j += 4u) {
-          const u32x4 r0 = L.pool[j * 3], r1 = L.pool[j * 3 + 3u], r2 = L.pool[j * 3 + 6u], r3 = L.pool[j * 3 + 9u];
+          const u32x4 r0 = L.pk[j], r1 = L.pk[j + 1u], r2 = L.pk[j + 2u], r3 = L.pk[j + 3u];
           rank += (q_lo(r0) < key ? 1u : 0u) + (q_lo(r1) < key ? 1u : 0u) + (q_lo(r2) < key ? 1u : 0u) + (q_lo(r3) < key ? 1u : 0u);
         }
       }
     } else {
-      const uint32_t arr = ok ? (L.pool[e * 3 + 2][0] & 0xFFFFu) : 0u;
+      const uint32_t arr = ok ? ((uint32_t)L.pa[e] & 0xFFFFu) : 0u;
       for (uint32_t j = 0; j < n; ++j) {
-        const u32x4 r = L.pool[j * 3];
-        const uint32_t xa = L.pool[j * 3 + 2][0] & 0xFFFFu;
+        const u32x4 r = L.pk[j];
+        const uint32_t xa = (uint32_t)L.pa[j] & 0xFFFFu;
         const bool before = q_lo(r) < key || (q_lo(r) == key && xa < arr);
         rank += before ? 1u : 0u;
         dup |= (before && q_hi(r) == hk) ? 1u : 0u;
@@ -457,7 +462,8 @@ CTC_UNROLL
   CTC_HD void filter_pool(double thr) {
     const uint32_t n = pool_n;
     const uint64_t thr_key = score_sort_key(thr);
-    u32x4 g0[PE], g1[PE], g2[PE];
+    u32x4 g0[PE];
+    uint64_t g1[PE];
     uint32_t dst[PE];
     bool ok[PE];
     uint32_t kept = 0;
@@ -466,12 +472,12 @@ CTC_UNROLL
       const uint32_t e = (uint32_t)(k * 64 + lane);
       ok[k] = false;
       dst[k] = 0;
-      g0[k] = g1[k] = g2[k] = mk4(0, 0, 0, 0);
+      g0[k] = mk4(0, 0, 0, 0);
+      g1[k] = 0;
       if ((uint32_t)(k * 64) >= n) continue;
       if (e < n) {
-        g0[k] = L.pool[e * 3];
-        g1[k] = L.pool[e * 3 + 1];
-        g2[k] = L.pool[e * 3 + 2];
+        g0[k] = L.pk[e];
+        g1[k] = L.pa[e];
         ok[k] = q_lo(g0[k]) <= thr_key;
       }
       const uint64_t m = ctx.ballot(ok[k]);
@@ -483,9 +489,8 @@ CTC_UNROLL
 CTC_UNROLL
     for (int k = 0; k < PE; ++k) {
       if (ok[k]) {
-        L.pool[dst[k] * 3] = g0[k];
-        L.pool[dst[k] * 3 + 1] = g1[k];
-        L.pool[dst[k] * 3 + 2] = g2[k];
+        L.pk[dst[k]] = g0[k];
+        L.pa[dst[k]] = g1[k];
       }
     }
     pool_n = kept;
@@ -501,7 +506,7 @@ CTC_UNROLL
     const uint32_t want = (uint32_t)prm.beam_width;
     const uint64_t thr_key = score_sort_key(thr);
     // pad the list to a multiple of four (n <= P, P % 4 == 0: the slots exist)
-    if (lane < 3 && (n & 3u) != 0u && n + (uint32_t)lane < ((n + 3u) & ~3u)) L.pool[(n + (uint32_t)lane) * 3] = mk4q(~0ull, 0ull);
+    if (lane < 3 && (n & 3u) != 0u && n + (uint32_t)lane < ((n + 3u) & ~3u)) L.pk[n + (uint32_t)lane] = mk4q(~0ull, 0ull);
     ctx.wsync();
     uint32_t np = 0, rank_sum = 0;
 CTC_UNROLL
@@ -540,7 +545,7 @@ CTC_UNROLL
       const uint32_t e = (uint32_t)(k * 64 + lane);
       key[k] = ~0ull;
       if ((uint32_t)(k * 64) < n && e < n) {
-        key[k] = q_lo(L.pool[e * 3]);
+        key[k] = q_lo(L.pk[e]);
         if (key[k] > worst) worst = key[k];
         if (~key[k] > best_inv) best_inv = ~key[k];
       }
@@ -573,16 +578,17 @@ CTC_UNROLL
     const double mx = key_to_score(runmax);
     uint32_t n = rank_pool(mx + prm.beam_prune_logp, false);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
-    u32x4 g0[SLB], g1[SLB], g2[SLB];
+    u32x4 g0[SLB];
+    uint64_t g1[SLB];
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const uint32_t r = (uint32_t)(j * 64 + lane);
-      g0[j] = g1[j] = g2[j] = mk4(0, 0, 0, 0);
+      g0[j] = mk4(0, 0, 0, 0);
+      g1[j] = 0;
       if (r < n) {
         const uint32_t e = L.sel[r] & 0x7FFFFFFFu;
-        g0[j] = L.pool[e * 3];
-        g1[j] = L.pool[e * 3 + 1];
-        g2[j] = L.pool[e * 3 + 2];
+        g0[j] = L.pk[e];
+        g1[j] = L.pa[e];
       }
     }
     ctx.wsync();
@@ -590,9 +596,8 @@ CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const uint32_t r = (uint32_t)(j * 64 + lane);
       if (r < n) {
-        L.pool[r * 3] = g0[j];
-        L.pool[r * 3 + 1] = g1[j];
-        L.pool[r * 3 + 2] = g2[j];
+        L.pk[r] = g0[j];
+        L.pa[r] = g1[j];
       }
     }
     pool_n = n;
@@ -613,25 +618,27 @@ CTC_UNROLL
   // two half passes that are matched together (pass_big).
   struct Cand {
     bool valid, is_rep, want_p, want_h;
-    uint32_t v, bi, ls, ll, lid, mw, br, pl0, m2_0, len_raw, tslot;
+    uint32_t bi, ls, ll, lid, mw, br, pl0, m2_0, len_raw, tslot;
     uint64_t kp, ck, pp_key, ph_key;
     uint32_t pp_wid, pp_fl, ph_min, ph_cmp;
-    double lg, lmhw;
+    double lg;
+    double wd;    // of the candidate's beam (ColdRec): the pending completion's lm + hot-word score when the label closes the
+    uint64_t wh;  // open word, else the open word's partial score; and the history hash that goes with the branch
   };
 
   // branch, merge key and summed logit of candidate (label l of the staged block = survivor s, beam i);
-  // FULL: also the first probe of the prefix / hot-word table of an appended partial word
+  // FULL: also the first probe of the prefix / hot-word table of an appended partial word and the request for the two
+  // words of the beam's ColdRec its score will need. closes_any (uniform): some label of the pass closes open words.
   template <bool FULL>
-  CTC_HD void gen(Cand& c, bool valid, uint32_t v, uint32_t l, uint32_t s, uint32_t i) {
+  CTC_HD void gen(Cand& c, bool valid, uint32_t l, uint32_t s, uint32_t i, bool closes_any) {
     // Straight-line: a lane without a candidate computes on label 0 / beam 0 (its fields are only looked at behind
     // `valid`), and every branch of the reference's if-ladder (decoder.py:452-534) is a select.
     const uint32_t ll = valid ? l : 0u, ii = valid ? i : 0u;
-    const u32x4 sv = L.surv[ll];
-    const u32x4 la = L.lab[ll * 3], lb = L.lab[ll * 3 + 1];
-    const u32x4 k0 = L.beams[ii * BREC], k1 = L.beams[ii * BREC + 1], k2 = L.beams[ii * BREC + 2];
+    const u32x4 sv = L.lab[ll * 4];
+    const u32x4 la = L.lab[ll * 4 + 1], lb = L.lab[ll * 4 + 2];
+    const u32x4 k0 = L.hA[ii], k1 = L.hB[ii];
     c.valid = valid;
     c.is_rep = false;
-    c.v = v;
     c.bi = i;
     c.ls = s;
     c.ll = l;
@@ -654,8 +661,13 @@ CTC_UNROLL
     c.br = b;
     const bool closes = b == BR_BOUNDARY || b == BR_SPACE;
     const bool app = b == BR_APPEND;
+    const bool closing_word = closes && pl > 0;
     // merge key parts: the text (the completed one when the open word closes) and the new partial word
-    const uint64_t kt = (closes && pl > 0) ? q_lo(k2) : q_lo(k0);
+    uint64_t kt = q_lo(k0);
+    if (closes_any) {
+      const uint64_t cth = text_push(q_lo(k0), q_hi(k0));
+      kt = closing_word ? cth : kt;
+    }
     const uint64_t p_app = str_concat(q_hi(k0), q_hi(la), q_lo(la));  // pow_raw, h_raw
     uint64_t p = q_hi(k0);
     p = app ? p_app : p;
@@ -666,6 +678,8 @@ CTC_UNROLL
     c.want_p = c.want_h = false;
     c.pp_key = c.ph_key = 0;
     c.pp_wid = c.pp_fl = c.ph_min = c.ph_cmp = 0;
+    c.wd = 0.0;
+    c.wh = 0;
     if (FULL) {  // first probe of the prefix / hot-word table of an appended partial word
       const bool probe = valid && app && p != 0;
       c.tslot = (uint32_t)table_slot(p);
@@ -683,8 +697,10 @@ CTC_UNROLL
         c.ph_min = g.min_len;
         c.ph_cmp = g.complete;
       }
+      const ColdRec* cr = cold_cur() + ii;
+      c.wd = *(closing_word ? &cr->c_lmhw : &cr->pscore);
+      if (prm.prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
     }
-    c.lmhw = bits_f64(q_hi(k2));
     c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
     c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
   }
@@ -835,18 +851,24 @@ CTC_UNROLL
     return s;
   }
 
-  // one pool entry per flagged lane, in lane order
-  CTC_HD void pool_put(bool put, u32x4 e0, u32x4 e1, u32x4 e2) {
+  // one pool entry per flagged lane, in lane order; its payload goes to the frame's next free payload line
+  CTC_HD void pool_put(bool put, u32x4 key, uint32_t arrival, uint32_t donor, double logit, uint64_t part_h, uint32_t plen,
+                       uint32_t wid, uint32_t m2) {
     const uint64_t m = ctx.ballot(put);
-    const uint32_t k = pool_n + prefix_cnt(m);
+    const uint32_t off = prefix_cnt(m);
+    const uint32_t k = pool_n + off, q = pay_n + off;
     pool_n += (uint32_t)ctx.popc64(m);
+    pay_n += (uint32_t)ctx.popc64(m);
     if (put) {
 #ifdef CTC_SIM_DEBUG
       if (k >= (uint32_t)P) { fprintf(stderr, "pool_put: k=%u P=%d\n", k, P); abort(); }
+      if (q >= 65536u) { fprintf(stderr, "pool_put: payload line %u\n", q); abort(); }
 #endif
-      L.pool[k * 3] = e0;
-      L.pool[k * 3 + 1] = e1;
-      L.pool[k * 3 + 2] = e2;
+      L.pk[k] = key;
+      L.pa[k] = pack64(arrival | (q << 16), donor);
+      u32x4a* dst = (u32x4a*)&io.pay[q];
+      dst[0] = mk4q(f64_bits(logit), part_h);
+      dst[1] = mk4(plen, wid, m2, 0u);
     }
   }
 
@@ -858,9 +880,10 @@ CTC_UNROLL
     const bool rep = c.is_rep;
     const uint32_t i = rep ? c.bi : 0u, ll = rep ? c.ll : 0u;
     const uint32_t b = c.br;
-    const u32x4 lb = L.lab[ll * 3 + 1], lc = L.lab[ll * 3 + 2];
-    const uint32_t st_wid = L.b32[i * R32 + W_WID];
-    const double st_ps = L.bf64[i * R64 + F_PSCORE], c_lmhw = L.bf64[i * R64 + F_CLMHW];
+    const u32x4 lb = L.lab[ll * 4 + 2], lc = L.lab[ll * 4 + 3];
+    const u32x4 k2 = L.hC[i];
+    const uint32_t st_wid = k2[3];
+    const double own_lmhw = bits_f64(q_lo(k2));
     const bool is0 = b == 0, isB = b == BR_BOUNDARY, isA = b == BR_APPEND;  // else: space
     // boundary: a new word starts with the clean label (or, for a bare boundary mark, nothing yet)
     const uint32_t len_clean = lb[3];
@@ -874,11 +897,11 @@ CTC_UNROLL
     const uint32_t m2A = (t.on ? (PF_ON_TABLE | (t.pf & PF_PARTIAL_MASK)) : 0u) | (t.hon ? M2_HOT_ON : 0u) |
                          ((t.hon && t.hcomp) ? M2_HOT_COMPLETE : 0u) | (a_hmin << 8);
     const uint32_t q_pl = is0 ? c.pl0 : (isB ? len_clean : (isA ? c.pl0 + c.len_raw : 0u));
-    const uint32_t q_m2 = is0 ? c.m2_0 : (isB ? m2B : (isA ? m2A : EMPTY_PARTIAL_M2));
+    const uint32_t q_m2 = is0 ? (c.m2_0 & ~M2_COMP) : (isB ? m2B : (isA ? m2A : EMPTY_PARTIAL_M2));
     const uint32_t q_wid = is0 ? st_wid : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t.on ? t.nw : 0u) : 0u));
     const double ps_new = partial_score_sel(isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
-    const double q_ps = is0 ? st_ps : ((bw || isA) ? ps_new : 0.0);
-    const double lmhw = (!is0 && !isA && c.pl0 > 0) ? c_lmhw : c.lmhw;  // boundary / space close the open word
+    const double q_ps = is0 ? c.wd : ((bw || isA) ? ps_new : 0.0);  // (blank / repeat: the open word's score as it is)
+    const double lmhw = (!is0 && !isA && c.pl0 > 0) ? c.wd : own_lmhw;  // boundary / space close the open word
     const double sc = total_score(tab, c.lg, lmhw, q_ps, q_pl);
     const double score = rep ? sc : 0.0;
     const uint64_t my_key = rep ? asc_key(sc) : 0ull;
@@ -889,16 +912,11 @@ CTC_UNROLL
     // (history, partial, last_char) folded to 64 bits (decoder.py:250-254): equality of the folds stands in
     // for equality of the triple (its members are 61/64-bit string hashes already)
     uint64_t hk = 0;
-    if (prm.prune_history) {
-      const bool closed = (b == BR_BOUNDARY || b == BR_SPACE) && c.pl0 > 0;
-      const uint64_t hh = L.b64[i * R64 + (closed ? F_CHIST : F_HIST)];
-      hk = fin64(hh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
-    }
+    if (prm.prune_history) hk = fin64(c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
     const u32x4 e0 = mk4q(score_sort_key(score), hk);
-    const u32x4 e1 = mk4q(f64_bits(c.lg), c.kp);
     const uint32_t blank = (c.mw >> 16) & TK_BLANK;
-    const u32x4 e2 = mk4((c.ls * (uint32_t)N + c.bi) | (q_pl << 16),
-                         imax | (c.lid << 8) | (blank ? (1u << 29) : 0u) | (dbr << 30), q_wid, q_m2);
+    const uint32_t arrival = c.ls * (uint32_t)N + c.bi;
+    const uint32_t donor = imax | (c.lid << 8) | (blank ? (1u << 29) : 0u) | (dbr << 30);
     bool push = rep && score >= thr && my_key > kth_key;
     uint32_t cnt = (uint32_t)ctx.popc64(ctx.ballot(push));
     if (pool_n + cnt > (uint32_t)P) filter_pool(thr);  // room, the cheap way: entries the risen threshold has left behind
@@ -911,15 +929,26 @@ CTC_UNROLL
       cnt = (uint32_t)ctx.popc64(m);
       if (pool_n + cnt > (uint32_t)P) {
         const bool part = push && prefix_cnt(m) < (uint32_t)P - pool_n;
-        pool_put(part, e0, e1, e2);
+        pool_put(part, e0, arrival, donor, c.lg, c.kp, q_pl, q_wid, q_m2);
         ctx.wsync();
         push = push && !part;
         cnt = (uint32_t)ctx.popc64(ctx.ballot(push));
       }
     }
-    pool_put(push, e0, e1, e2);
+    pool_put(push, e0, arrival, donor, c.lg, c.kp, q_pl, q_wid, q_m2);
     ctx.wsync();
     tick<W_PROF_PUSH>();
+  }
+
+  // does some label in [l0, l1) of the staged block close open words (boundary / space modes)? (uniform)
+  CTC_HD bool closing_labels(uint32_t l0, uint32_t l1) {
+    const uint32_t l = l0 + (uint32_t)lane;
+    bool cl = false;
+    if (l < l1) {
+      const uint32_t mode = L.lab[l * 4][1] & 0xFFu;
+      cl = mode == MODE_ALL_B || mode == MODE_FIRST_B || mode == MODE_C;
+    }
+    return ctx.ballot(cl) != 0ull;
   }
 
   // One pass: the candidates of the labels [l0, l1) of the staged block (survivors base + l), N <= 64 beams,
@@ -929,22 +958,19 @@ CTC_UNROLL
     const uint32_t Q = (l1 - l0) * Nn;
     const uint32_t rcpN = Nn ? 65536u / Nn + 1u : 0u;  // v / N == (v * rcpN) >> 16 for v * N < 65536
     const uint32_t v = (uint32_t)lane;
-    L.gmask[lane * 2] = 0u;
-    L.gmask[lane * 2 + 1] = 0u;
+    const bool closes_any = closing_labels(l0, l1);
     clear_table();
     const uint32_t sl = (v * rcpN) >> 16;
     const uint32_t l = l0 + sl;
     Cand c;
-    gen<true>(c, v < Q, v, l, base + l, v - sl * Nn);
-    if (c.valid) {
-      L.c_logit[v] = c.lg;
-      L.c_br[v] = c.br;
-    }
+    gen<true>(c, v < Q, l, base + l, v - sl * Nn, closes_any);
     ctx.wsync();
     tick<W_PROF_GEN>();
     uint32_t rep;
     match<1>(&c.valid, &c.ck, &rep);
-    // members announce themselves to their representative
+    // members announce themselves to their representative (the mask words take the place of the table's first half)
+    *(CTC_LDS uint64_t*)&L.gmask[lane * 2] = 0ull;
+    ctx.wsync();
     if (c.valid && rep != v) ctx.lds_or_u32(&L.gmask[rep * 2 + (v >> 5)], 1u << (v & 31u));
     c.is_rep = c.valid && rep == v;
     ctx.wsync();
@@ -956,6 +982,7 @@ CTC_UNROLL
     {
       uint32_t g0 = 0, g1 = 0;
       bool more = false;
+      double lp = 0.0;
       if (c.is_rep) {
         g0 = L.gmask[v * 2];
         g1 = L.gmask[v * 2 + 1];
@@ -964,7 +991,9 @@ CTC_UNROLL
         if (g1) top = (uint32_t)(63 - ctx.clz32(g1));
         if (top != 0xFFFFFFFFu) {
           imax = c.bi + (top - v);  // members share the label: consecutive beam indices
-          dbr = L.c_br[top];
+          dbr = branch_of(c.mw, c.lid, imax, L.b32[imax * 4 + 2] & 0xFFFFu);
+          const u32x4 sv = L.lab[c.ll * 4];
+          lp = bits_f64(pack64(sv[2], sv[3]));
           more = true;
         }
       }
@@ -977,7 +1006,8 @@ CTC_UNROLL
           if (mbit != 0xFFFFFFFFu) {
             if (mbit < 32u) g0 &= g0 - 1u;
             else g1 &= g1 - 1u;
-            c.lg = lse2(c.lg, L.c_logit[mbit]);
+            // (the member's summed logit: its beam's + the label's, as the member itself computed it)
+            c.lg = lse2(c.lg, bits_f64(L.b64[(c.bi + (mbit - v)) * 2]) + lp);
             more = (g0 | g1) != 0u;
           }
         }
@@ -992,8 +1022,9 @@ CTC_UNROLL
   // of a half is (re)generated when the half is scored, so that no second candidate lives in registers.
   CTC_HD void pass_big(uint32_t base, uint32_t l) {
     const uint32_t Nn = (uint32_t)N;
-    const u32x4 sv = L.surv[l];
+    const u32x4 sv = L.lab[l * 4];
     const double lp = bits_f64(pack64(sv[2], sv[3]));
+    const bool closes_any = closing_labels(l, l + 1u);
     bool valid[2];
     uint64_t ck[2];
     double lg[2];
@@ -1003,7 +1034,7 @@ CTC_UNROLL
     for (int h = 0; h < 2; ++h) {
       const uint32_t v = (uint32_t)(h * 64 + lane);
       Cand c;
-      gen<false>(c, v < Nn, v, l, base + l, v);
+      gen<false>(c, v < Nn, l, base + l, v, closes_any);
       valid[h] = c.valid;
       ck[h] = c.ck;
       lg[h] = c.lg;
@@ -1040,7 +1071,7 @@ CTC_UNROLL
             mbit = (uint32_t)(64 + ctx.ctz64(mhi[h]));
             mhi[h] &= mhi[h] - 1ull;
           }
-          lg[h] = lse2(lg[h], L.bf64[mbit * R64 + F_LOGIT] + lp);
+          lg[h] = lse2(lg[h], bits_f64(L.b64[mbit * 2]) + lp);
           more = more || (mlo[h] | mhi[h]) != 0ull;
         }
       }
@@ -1050,11 +1081,11 @@ CTC_UNROLL
     for (int h = 0; h < 2; ++h) {
       const uint32_t v = (uint32_t)(h * 64 + lane);
       Cand c;
-      gen<true>(c, v < Nn, v, l, base + l, v);
+      gen<true>(c, v < Nn, l, base + l, v, closes_any);
       c.is_rep = is_rep[h];
       c.lg = lg[h];
       const uint32_t di = is_rep[h] ? imax[h] : 0u;
-      const uint32_t dbr = branch_of(sv[1], sv[0], di, L.b32[di * R32 + W_META1] & 0xFFFFu);
+      const uint32_t dbr = branch_of(sv[1], sv[0], di, L.b32[di * 4 + 2] & 0xFFFFu);
       const TabView t = resolve_tables(c);
       score_push(c, t, imax[h], dbr);
     }
@@ -1080,10 +1111,11 @@ CTC_UNROLL
       lg[j] = rest[j] = psc[j] = 0.0;
       pl[j] = 0;
       if (live[j]) {
-        lg[j] = L.bf64[i * R64 + F_LOGIT];
-        rest[j] = L.bf64[i * R64 + F_LMHW];
-        psc[j] = L.bf64[i * R64 + F_PSCORE];
-        pl[j] = L.b32[i * R32 + W_META1] >> 16;
+        const u32x4 k1 = L.hB[i];
+        lg[j] = bits_f64(q_lo(k1));
+        rest[j] = bits_f64(L.c64[i * 2]);
+        pl[j] = k1[2] >> 16;
+        if (pl[j] > 0) psc[j] = cold_cur()[i].pscore;  // (only an open word has a partial score; total_score looks at it then)
       }
     }
     double p = bits_f64(ctx.bcast64(f64_bits(pf_lp), 0));
@@ -1141,7 +1173,7 @@ CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const int i = j * 64 + lane;
       if (live[j]) {
-        L.bf64[i * R64 + F_LOGIT] = lg[j];
+        L.b64[i * 2] = f64_bits(lg[j]);
         if (!lab_is_blank) cold_cur()[i].pend = io.first_frame + tt;  // end frame of the open word: last held frame + 1
       }
     }
@@ -1164,22 +1196,23 @@ CTC_UNROLL
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
         const int i = j * 64 + lane;
-        if (i < N) same = same && (L.b32[i * R32 + W_META1] & 0xFFFFu) == lab;
+        if (i < N) same = same && (L.b32[i * 4 + 2] & 0xFFFFu) == lab;
       }
       if (ctx.ballot(!same) == 0ull) {
-        const int t2 = label_run(t, lab, (L.lab[2][0] & TK_BLANK) != 0u);
+        const int t2 = label_run(t, lab, (L.lab[3][0] & TK_BLANK) != 0u);
         if (t2 > t) return t2;
       }
     }
     pool_n = 0;
+    pay_n = 0;
     runmax = asc_key(-INFINITY);
     kth_key = 0;
     need = 0;
 #ifdef CTC_WAVE_TRACE
     if (lane < N) {
-      const u32x4 t0 = L.beams[lane * BREC], t1 = L.beams[lane * BREC + 1], t5 = L.beams[lane * BREC + 5];
-      printf("TB f=%d N=%d i=%d text=%llx part=%llx logit=%.6f meta1=%x m2=%x tn=%u cn=%u wid=%u\n", frame, N, lane, (unsigned long long)q_lo(t0),
-             (unsigned long long)q_hi(t0), bits_f64(q_lo(t1)), t1[2], t1[3], t5[0], t5[1], t5[2]);
+      const u32x4 t0 = L.hA[lane], t1 = L.hB[lane], t2 = L.hC[lane];
+      printf("TB f=%d N=%d i=%d text=%llx part=%llx logit=%.6f meta1=%x m2=%x tn=%u wid=%u\n", frame, N, lane, (unsigned long long)q_lo(t0),
+             (unsigned long long)q_hi(t0), bits_f64(q_lo(t1)), t1[2], t1[3], t2[2], t2[3]);
     }
 #endif
     // this frame's survivors (block 0: ids / log-probs in the prefetch registers, label constants already in LDS),
@@ -1192,7 +1225,7 @@ CTC_UNROLL
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const int i = j * 64 + lane;
-      lc[j] = i < N ? (L.b32[i * R32 + W_META1] & 0xFFFFu) : 0u;
+      lc[j] = i < N ? (L.b32[i * 4 + 2] & 0xFFFFu) : 0u;
     }
     uint32_t lc0 = NO_CHAR, f1 = (uint32_t)N;
     {
@@ -1216,24 +1249,24 @@ CTC_UNROLL
         if (mine) {
           id = id0;
           lp = lp0;
-          fl = L.lab[lane * 3 + 2][0];
+          fl = L.lab[lane * 4 + 3][0];
         }
       } else {
-        // (more than WAVE_LAB survivors in one frame: rare; fetched on the spot)
-        ctx.wsync();  // the previous block's passes are done with surv / lab
+        // (more than WAVE_LAB survivors in one frame: fetched on the spot)
+        ctx.wsync();  // the previous block's passes are done with the label block
         if (mine) {
           id = io.surv_id[(size_t)t * prm.max_surv + s];
           lp = io.surv_lp[(size_t)t * prm.max_surv + s];
           const TokInfo& g = tab.tok[id];
           fl = g.flags;
           const uint32_t hot = tab.tok_hot ? ((tab.tok_hot[id].min_len & 0xFFFFu) | (tab.tok_hot[id].complete ? 0x80000000u : 0u)) : 0u;
-          L.lab[lane * 3] = mk4q(g.h_raw, g.pow_raw);
-          L.lab[lane * 3 + 1] = mk4((uint32_t)g.h_clean, (uint32_t)(g.h_clean >> 32), g.len_raw, g.len_clean);
-          L.lab[lane * 3 + 2] = mk4(g.flags, g.start_flags, g.start_word_id, hot);
+          L.lab[lane * 4 + 1] = mk4q(g.h_raw, g.pow_raw);
+          L.lab[lane * 4 + 2] = mk4((uint32_t)g.h_clean, (uint32_t)(g.h_clean >> 32), g.len_raw, g.len_clean);
+          L.lab[lane * 4 + 3] = mk4(g.flags, g.start_flags, g.start_word_id, hot);
         }
       }
       const uint32_t mwd = mode_block(fl, id, lc0, f1);
-      if (mine) L.surv[lane] = mk4(id, mwd, (uint32_t)f64_bits(lp), (uint32_t)(f64_bits(lp) >> 32));
+      if (mine) L.lab[lane * 4] = mk4(id, mwd, (uint32_t)f64_bits(lp), (uint32_t)(f64_bits(lp) >> 32));
       if (base == 0) tick<W_PROF_LOAD>();
       if (need && !comp_done) {
         completions_now();
@@ -1260,8 +1293,9 @@ CTC_UNROLL
     const bool hist = prm.prune_history != 0;
 #ifdef CTC_WAVE_TRACE
     if ((uint32_t)lane < pool_n) {
-      const u32x4 t0 = L.pool[lane * 3], t2 = L.pool[lane * 3 + 2];
-      printf("TR f=%d N=%d ns=%u pool=%u e=%d key=%llx arr=%u don=%x wid=%u m2=%x\n", frame, N, ns, pool_n, lane, (unsigned long long)q_lo(t0), t2[0], t2[1], t2[2], t2[3]);
+      const u32x4 t0 = L.pk[lane];
+      const uint64_t t2 = L.pa[lane];
+      printf("TR f=%d N=%d ns=%u pool=%u e=%d key=%llx arr=%x don=%x\n", frame, N, ns, pool_n, lane, (unsigned long long)q_lo(t0), (uint32_t)t2, (uint32_t)(t2 >> 32));
     }
 #endif
     uint32_t n = rank_pool(thr, hist);
@@ -1282,46 +1316,45 @@ CTC_UNROLL
 
   // ---- next beam table from the ranked pool (decoder.py:548-554) -----------------------------------
   struct Rec {
-    u32x4 o0, o1, o2, o3, o4, o5;
+    u32x4 o0, o1, o2;
   };
-  // the record of one rank (w = its L.sel word, d = its place in the new table); also writes the beam's cold record
+  // the columns of one rank (w = its L.sel word, d = its place in the new table); also writes the beam's ColdRec
   // and, for a label that is not a blank / repeat, its emission node. All lanes call.
   CTC_HD void gather(int frame, uint32_t w, bool kept, uint32_t d, Rec& o) {
-    o.o0 = o.o1 = o.o2 = o.o3 = o.o4 = o.o5 = mk4(0, 0, 0, 0);
+    o.o0 = o.o1 = o.o2 = mk4(0, 0, 0, 0);
     // the payload is the donor's (the last-arriving duplicate, decoder.py:221-223), its branch included
-    u32x4 e1 = mk4(0, 0, 0, 0), e2 = mk4(0, 0, 0, 0);
-    if (kept) {
-      const uint32_t idx = w & 0x7FFFFFFFu;
-      e1 = L.pool[idx * 3 + 1];
-      e2 = L.pool[idx * 3 + 2];
-    }
-    const uint32_t don = e2[1];
+    uint64_t a2 = 0;
+    if (kept) a2 = L.pa[w & 0x7FFFFFFFu];
+    const uint32_t don = (uint32_t)(a2 >> 32);
     const uint32_t b = don >> 30, i = don & 0xFFu, c = (don >> 8) & 0xFFFFu;
     const uint64_t em = ctx.ballot(kept && b != 0);
     uint32_t e = emit_next + prefix_cnt(em);
     emit_next += (uint32_t)ctx.popc64(em);
     if (!kept) return;
-    const ColdRec cr = cold_cur()[i];
-    const u32x4 k0 = L.beams[i * BREC], k1 = L.beams[i * BREC + 1], k2 = L.beams[i * BREC + 2];
-    const u32x4 k3 = L.beams[i * BREC + 3], k4 = L.beams[i * BREC + 4], k5 = L.beams[i * BREC + 5];
+    const u32x4a* pay = (const u32x4a*)&io.pay[((uint32_t)a2 >> 16) & 0xFFFFu];
+    const u32x4 e1 = pay[0], e2 = pay[1];  // {summed logit, new partial hash} {plen, word id, table view}
+    const u32x4a* crp = (const u32x4a*)&cold_cur()[i];
+    const u32x4 w0 = crp[0], w1 = crp[1], w2 = crp[2];
+    uint32_t depth = cold_cur()[i].depth;
+    const u32x4 k0 = L.hA[i], k1 = L.hB[i], k2 = L.hC[i];
     const uint32_t pl = k1[2] >> 16;
-    uint64_t th = q_lo(k0), hh = q_lo(k4);
+    uint64_t th = q_lo(k0), hh = q_lo(w1);
     const uint64_t ph = q_hi(e1);  // the new partial word's hash (unchanged for a blank / repeat)
-    const uint64_t cth = q_lo(k2), chh = q_hi(k4);
-    double lmhw = bits_f64(q_hi(k2));
-    const double clm = bits_f64(q_lo(k3));
-    uint32_t tnode = k5[0], cnode = k5[1], enode = k5[3];
-    int32_t pst = cr.pstart, pen = cr.pend;
-    uint32_t depth = cr.depth;
-    const uint32_t m2 = e2[3], wid = e2[2];
-    const uint32_t npl = e2[0] >> 16;
+    uint64_t lmhw = q_lo(k2);
+    uint64_t clm = q_lo(w0), chh = q_hi(w1);
+    uint32_t tnode = k2[2], cnode = w2[0], enode = w2[1];
+    int32_t pst = (int32_t)w2[2], pen = (int32_t)w2[3];
+    uint32_t m2 = e2[2] & ~M2_COMP;
+    const uint32_t wid = e2[1];
+    const uint32_t npl = e2[0];
     if (b == 0) {
       if (!(don & (1u << 29))) pen = frame + 1;  // a repeated label extends the open word (decoder.py:453-461)
+      m2 |= k1[3] & M2_COMP;                     // ... and the pending completion stays what it is
     } else {
       const int32_t wst = pst, wen = pen;
       if (b == BR_BOUNDARY || b == BR_SPACE) {
         if (pl > 0) {  // the open word is completed (decoder.py:483-495, 501-515)
-          th = cth;
+          th = text_push(q_lo(k0), q_hi(k0));
           hh = chh;
           lmhw = clm;
           tnode = cnode;
@@ -1338,6 +1371,8 @@ CTC_UNROLL
         pen = frame + 1;
       }
       cnode = 0;
+      clm = 0;
+      chh = 0;
       if (e >= io.emit_cap) {
         status |= ST_EMIT_OVERFLOW;
         e = io.emit_cap - 1;
@@ -1346,28 +1381,21 @@ CTC_UNROLL
       enode = e;
       depth += 1;
     }
-    ColdRec nr;
-    nr.pstart = pst;
-    nr.pend = pen;
-    nr.depth = depth;
-    nr.pad = 0;
-    cold_next()[d] = nr;
     double ps = 0.0;
     if (npl > 0) ps = partial_score(tab, prm, m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
+    u32x4a* nr = (u32x4a*)&cold_next()[d];
+    nr[0] = mk4q(clm, f64_bits(ps));
+    nr[1] = mk4q(hh, chh);
+    nr[2] = mk4(cnode, enode, (uint32_t)pst, (uint32_t)pen);
+    nr[3] = mk4(depth, 0u, 0u, 0u);
     o.o0 = mk4q(th, ph);
     o.o1 = mk4(e1[0], e1[1], c | (npl << 16), m2);
-    o.o2 = mk4q(cth, f64_bits(lmhw));
-    o.o3 = mk4q(f64_bits(clm), f64_bits(ps));
-    o.o4 = mk4q(hh, chh);
-    o.o5 = mk4(tnode, cnode, wid, enode);
+    o.o2 = mk4((uint32_t)lmhw, (uint32_t)(lmhw >> 32), tnode, wid);
   }
   CTC_HD void put_rec(uint32_t d, const Rec& o) {
-    L.beams[d * BREC] = o.o0;
-    L.beams[d * BREC + 1] = o.o1;
-    L.beams[d * BREC + 2] = o.o2;
-    L.beams[d * BREC + 3] = o.o3;
-    L.beams[d * BREC + 4] = o.o4;
-    L.beams[d * BREC + 5] = o.o5;
+    L.hA[d] = o.o0;
+    L.hB[d] = o.o1;
+    L.hC[d] = o.o2;
   }
   CTC_HD void build_done(uint32_t n_new) {
     N = (int)n_new;
@@ -1377,7 +1405,7 @@ CTC_UNROLL
     ctx.wsync();
     tick<W_PROF_BUILD>();
   }
-  // at most 64 ranks (nearly every frame): gather everything the new records need, then write them in place
+  // at most 64 ranks (nearly every frame): gather everything the new columns need, then write them in place
   CTC_HD void build1(int frame, uint32_t n) {
     const uint32_t r = (uint32_t)lane;
     uint32_t w = 0;
@@ -1392,8 +1420,8 @@ CTC_UNROLL
     if (kept) put_rec(d, o);
     build_done((uint32_t)ctx.popc64(km));
   }
-  // more than 64 ranks: the records of the ranks 64.. are parked in LDS that is idle during a build (label block +
-  // merge scratch) while the ranks 0..63 are gathered, so that only one record per lane lives in registers
+  // more than 64 ranks: the columns of the ranks 64.. are parked in LDS that is idle during a build (label block +
+  // match table) while the ranks 0..63 are gathered, so that only one record per lane lives in registers
   CTC_HD void build_big(int frame, uint32_t n) {
     const uint32_t r1 = (uint32_t)(64 + lane);
     const uint32_t w0 = L.sel[lane];
@@ -1403,28 +1431,22 @@ CTC_UNROLL
     const uint64_t km0 = ctx.ballot(kept0), km1 = ctx.ballot(kept1);
     const uint32_t n0 = (uint32_t)ctx.popc64(km0);
     const uint32_t d0 = prefix_cnt(km0), d1 = n0 + prefix_cnt(km1);
-    ctx.wsync();  // (the parking area may cover L.sel)
+    ctx.wsync();  // (the parking area covers L.sel)
     Rec o;
     gather(frame, w1, kept1, d1, o);
     if (kept1) {
-      L.stage[lane * BREC] = o.o0;
-      L.stage[lane * BREC + 1] = o.o1;
-      L.stage[lane * BREC + 2] = o.o2;
-      L.stage[lane * BREC + 3] = o.o3;
-      L.stage[lane * BREC + 4] = o.o4;
-      L.stage[lane * BREC + 5] = o.o5;
+      L.stage[lane * 3] = o.o0;
+      L.stage[lane * 3 + 1] = o.o1;
+      L.stage[lane * 3 + 2] = o.o2;
     }
     gather(frame, w0, kept0, d0, o);
     ctx.wsync();
     tick<W_PROF_GATHER>();
     if (kept0) put_rec(d0, o);
     if (kept1) {
-      o.o0 = L.stage[lane * BREC];
-      o.o1 = L.stage[lane * BREC + 1];
-      o.o2 = L.stage[lane * BREC + 2];
-      o.o3 = L.stage[lane * BREC + 3];
-      o.o4 = L.stage[lane * BREC + 4];
-      o.o5 = L.stage[lane * BREC + 5];
+      o.o0 = L.stage[lane * 3];
+      o.o1 = L.stage[lane * 3 + 1];
+      o.o2 = L.stage[lane * 3 + 2];
       put_rec(d1, o);
     }
     build_done(n0 + (uint32_t)ctx.popc64(km1));
@@ -1434,18 +1456,21 @@ CTC_UNROLL
   CTC_HD void write_beam(int i, uint64_t text_h, uint64_t part_h, double logit, uint32_t meta1, uint32_t meta2, double lm_hw,
                          double pscore, uint64_t hist_h, uint32_t text_node, uint32_t emit_node, uint32_t word_id,
                          int32_t pstart, int32_t pend, uint32_t depth) {
-    const uint64_t lgb = f64_bits(logit);
-    L.beams[i * BREC] = mk4q(text_h, part_h);
-    L.beams[i * BREC + 1] = mk4((uint32_t)lgb, (uint32_t)(lgb >> 32), meta1, meta2);
-    L.beams[i * BREC + 2] = mk4q(0, f64_bits(lm_hw));
-    L.beams[i * BREC + 3] = mk4q(f64_bits(0.0), f64_bits(pscore));
-    L.beams[i * BREC + 4] = mk4q(hist_h, 0);
-    L.beams[i * BREC + 5] = mk4(text_node, 0u, word_id, emit_node);
+    const uint64_t lgb = f64_bits(logit), lmb = f64_bits(lm_hw);
+    L.hA[i] = mk4q(text_h, part_h);
+    L.hB[i] = mk4((uint32_t)lgb, (uint32_t)(lgb >> 32), meta1, meta2 & ~M2_COMP);
+    L.hC[i] = mk4((uint32_t)lmb, (uint32_t)(lmb >> 32), text_node, word_id);
     ColdRec cr;
+    cr.c_lmhw = 0.0;
+    cr.pscore = pscore;
+    cr.hist_h = hist_h;
+    cr.c_hist_h = 0;
+    cr.cnode = 0;
+    cr.enode = emit_node;
     cr.pstart = pstart;
     cr.pend = pend;
     cr.depth = depth;
-    cr.pad = 0;
+    cr.pad[0] = cr.pad[1] = cr.pad[2] = 0;
     cold_cur()[i] = cr;
   }
 
@@ -1543,6 +1568,7 @@ CTC_UNROLL
   CTC_HD void finalise() {
     const bool fold = prm.fold != 0, eos = prm.eos != 0;
     pool_n = 0;
+    pay_n = 0;
     runmax = asc_key(-INFINITY);
     kth_key = 0;
     ctx.mem_sync();
@@ -1564,10 +1590,11 @@ CTC_UNROLL
       ck[j] = 0;
       lg[j] = 0.0;
       if (valid[j]) {
-        const uint32_t pl = L.b32[v * R32 + W_META1] >> 16;
-        const uint64_t kt = pl > 0 ? L.b64[v * R64 + F_CTEXT] : L.b64[v * R64 + F_TEXT];
+        const u32x4 k0 = L.hA[v], k1 = L.hB[v];
+        const uint32_t pl = k1[2] >> 16;
+        const uint64_t kt = pl > 0 ? text_push(q_lo(k0), q_hi(k0)) : q_lo(k0);
         ck[j] = fin64(kt ^ 0x165667B19E3779F9ull);
-        lg[j] = L.bf64[v * R64 + F_LOGIT];
+        lg[j] = bits_f64(q_lo(k1));
       }
     }
     ctx.wsync();
@@ -1584,13 +1611,13 @@ CTC_UNROLL
           while (mlo[j]) {
             const uint32_t mbit = (uint32_t)ctx.ctz64(mlo[j]);
             mlo[j] &= mlo[j] - 1ull;
-            lg[j] = lse2(lg[j], L.bf64[mbit * R64 + F_LOGIT]);
+            lg[j] = lse2(lg[j], bits_f64(L.b64[mbit * 2]));
             donor[j] = mbit;
           }
           while (mhi[j]) {
             const uint32_t mbit = (uint32_t)(64 + ctx.ctz64(mhi[j]));
             mhi[j] &= mhi[j] - 1ull;
-            lg[j] = lse2(lg[j], L.bf64[mbit * R64 + F_LOGIT]);
+            lg[j] = lse2(lg[j], bits_f64(L.b64[mbit * 2]));
             donor[j] = mbit;
           }
         }
@@ -1606,11 +1633,12 @@ CTC_UNROLL
       const uint32_t v = (uint32_t)(j * 64 + lane);
       if (fold) {
         const uint32_t d = donor[j];
-        const uint32_t m2 = L.b32[d * R32 + W_META2];
-        const uint32_t pl = L.b32[d * R32 + W_META1] >> 16;
+        const u32x4 d1 = L.hB[d], d2 = L.hC[d];
+        const uint32_t m2 = d1[3];
+        const uint32_t pl = d1[2] >> 16;
         double lmhw;
         if (eos) {
-          const TextNode& src = io.text_nodes[L.b32[d * R32 + W_TNODE]];
+          const TextNode& src = io.text_nodes[d2[2]];
           const uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
           if (tab.has_lm) {
             LmState st, end;
@@ -1620,13 +1648,13 @@ CTC_UNROLL
               st.words[k] = src.state.words[k];
               st.backoff[k] = src.state.backoff[k];
             }
-            const uint32_t wid = pl > 0 ? L.b32[d * R32 + W_WID] : 0u;
+            const uint32_t wid = pl > 0 ? d2[3] : 0u;
             const uint32_t wfl = pl > 0 ? m2 : 0u;
-            const float base_s = lm_base_score(tab, st, wid, &end);
+            const float base_s = lm_base_score<ORD>(tab, st, wid, &end);
             double end_score = 0.0;
             if (prm.score_boundary) {
               LmState tmp;
-              end_score = (double)lm_base_score(tab, end, tab.eos_id, &tmp);
+              end_score = (double)lm_base_score<ORD>(tab, end, tab.eos_id, &tmp);
             }
             const double raw = src.raw_lm + lm_word_score(tab, prm, base_s, wfl, end_score, true);
             lmhw = raw + prm.hot_weight * (double)cnt;
@@ -1634,11 +1662,13 @@ CTC_UNROLL
             lmhw = prm.hot_weight * (double)cnt;
           }
         } else {
-          lmhw = pl > 0 ? L.bf64[d * R64 + F_CLMHW] : L.bf64[d * R64 + F_LMHW];  // memo entry (text (+) word, False)
+          lmhw = pl > 0 ? cold_cur()[d].c_lmhw : bits_f64(q_lo(d2));  // memo entry (text (+) word, False)
         }
         score[j] = tab.has_lm ? lg[j] + lmhw : lg[j] + lmhw + 0.0;
       } else {
-        score[j] = total_score(tab, lg[j], L.bf64[v * R64 + F_LMHW], L.bf64[v * R64 + F_PSCORE], L.b32[v * R32 + W_META1] >> 16);
+        const u32x4 k1 = L.hB[v];
+        const uint32_t pl = k1[2] >> 16;
+        score[j] = total_score(tab, lg[j], bits_f64(L.c64[v * 2]), pl > 0 ? cold_cur()[v].pscore : 0.0, pl);
       }
       const uint64_t k = asc_key(score[j]);
       if (k > pass_key) pass_key = k;
@@ -1648,9 +1678,9 @@ CTC_UNROLL
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       if ((uint32_t)(j * 64) >= Q) continue;
-      // (N <= beam_width <= P: everything fits; arrival = beam rank, donor beam; the exact score rides in chunk 1)
-      pool_put(is_rep[j], mk4q(score_sort_key(score[j]), 0), mk4q(f64_bits(lg[j]), f64_bits(score[j])),
-               mk4((uint32_t)(j * 64 + lane), donor[j], 0u, 0u));
+      // (N <= beam_width <= P: everything fits; arrival = beam rank, donor beam; the exact score rides in the payload)
+      pool_put(is_rep[j], mk4q(score_sort_key(score[j]), 0), (uint32_t)(j * 64 + lane), donor[j], lg[j], f64_bits(score[j]), 0u,
+               0u, 0u);
     }
     ctx.wsync();
     uint32_t n = rank_pool(key_to_score(runmax) + prm.beam_prune_logp, false);
@@ -1663,12 +1693,12 @@ CTC_UNROLL
       // decode_batch: only the best beam's text is wanted, and a separate launch assembles it (assemble_texts: every
       // utterance's chain walk at once instead of at the tail of this one's life) -- leave it where its chain ends
       if (lane == 0) {
-        const uint32_t idx = L.sel[0] & 0x7FFFFFFFu;
-        const u32x4 e1 = L.pool[idx * 3 + 1];
-        const uint32_t d = L.pool[idx * 3 + 2][1];
+        const uint64_t a2 = L.pa[L.sel[0] & 0x7FFFFFFFu];
+        const PoolPay& pp = io.pay[((uint32_t)a2 >> 16) & 0xFFFFu];
+        const uint32_t d = (uint32_t)(a2 >> 32);
         OutBeam& ob = io.out[0];
-        ob.logit_score = bits_f64(q_lo(e1));
-        ob.lm_score = bits_f64(q_hi(e1));
+        ob.logit_score = pp.logit;
+        ob.lm_score = bits_f64(pp.part_h);
         ob.raw_lm = 0.0;
         ob.tok_off = 0;
         ob.tok_cnt = 0;
@@ -1676,7 +1706,7 @@ CTC_UNROLL
         ob.last_char = NO_CHAR;
         ob.pstart = ob.pend = -1;
         ob.pad[0] = 0;
-        ob.pad[1] = L.b32[d * R32 + W_ENODE];
+        ob.pad[1] = cold_cur()[d].enode;
         *io.n_out = 1;
         *io.status = status;
       }
@@ -1691,9 +1721,8 @@ CTC_UNROLL
       len[j] = 0;
       off[j] = 0;
       if (r < n_out) {
-        const uint32_t idx = L.sel[r] & 0x7FFFFFFFu;
-        const uint32_t d = L.pool[idx * 3 + 2][1];
-        len[j] = cold_cur()[d].depth + ((fold && (L.b32[d * R32 + W_META1] >> 16) > 0) ? 1u : 0u);
+        const uint32_t d = (uint32_t)(L.pa[L.sel[r] & 0x7FFFFFFFu] >> 32);
+        len[j] = cold_cur()[d].depth + ((fold && (L.b32[d * 4 + 2] >> 16) > 0) ? 1u : 0u);
       }
       off[j] = total + ctx.wave_excl_sum_u32(len[j]);
       total += ctx.wave_sum_u32(len[j]);
@@ -1713,14 +1742,15 @@ CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       const uint32_t r = (uint32_t)(j * 64 + lane);
       if (r >= n_out) continue;
-      const uint32_t idx = L.sel[r] & 0x7FFFFFFFu;
-      const u32x4 e1 = L.pool[idx * 3 + 1];
-      const uint32_t d = L.pool[idx * 3 + 2][1];
+      const uint64_t a2 = L.pa[L.sel[r] & 0x7FFFFFFFu];
+      const PoolPay& pp = io.pay[((uint32_t)a2 >> 16) & 0xFFFFu];
+      const uint32_t d = (uint32_t)(a2 >> 32);
       const ColdRec cr = cold_cur()[d];
       OutBeam& ob = io.out[r];
-      ob.logit_score = bits_f64(q_lo(e1));
-      ob.lm_score = bits_f64(q_hi(e1));
-      const uint32_t meta1 = L.b32[d * R32 + W_META1];
+      ob.logit_score = pp.logit;
+      ob.lm_score = bits_f64(pp.part_h);
+      const u32x4 d1 = L.hB[d], d2 = L.hC[d];
+      const uint32_t meta1 = d1[2];
       const uint32_t pl = meta1 >> 16;
       const bool closes = fold && pl > 0;
       const uint32_t o = (uint32_t)(base + off[j]);
@@ -1732,7 +1762,7 @@ CTC_UNROLL
       ob.pstart = fold ? -1 : cr.pstart;
       ob.pend = fold ? -1 : cr.pend;
       // the text's memo entry: raw LM sum and the state after its last word
-      const TextNode& node = io.text_nodes[closes ? L.b32[d * R32 + W_CNODE] : L.b32[d * R32 + W_TNODE]];
+      const TextNode& node = io.text_nodes[closes ? cr.cnode : d2[2]];
       ob.raw_lm = node.raw_lm;
       if (!tab.has_lm) {
         ob.state.len = -1;
@@ -1744,7 +1774,7 @@ CTC_UNROLL
       } else if (eos) {
         // last_lm_state: state after the last word, before </s> (language_model.py:357); an empty
         // last word is still scored as a word (decoder.py:387-395)
-        const TextNode& src = io.text_nodes[L.b32[d * R32 + W_TNODE]];
+        const TextNode& src = io.text_nodes[d2[2]];
         LmState st;
         st.len = src.state.len;
 CTC_UNROLL
@@ -1752,7 +1782,7 @@ CTC_UNROLL
           st.words[k] = src.state.words[k];
           st.backoff[k] = src.state.backoff[k];
         }
-        lm_base_score(tab, st, pl > 0 ? L.b32[d * R32 + W_WID] : 0u, &ob.state);
+        lm_base_score<ORD>(tab, st, pl > 0 ? d2[3] : 0u, &ob.state);
       } else {
         ob.state.len = node.state.len;
 CTC_UNROLL
@@ -1771,7 +1801,7 @@ CTC_UNROLL
           fin.wend = cr.pend;
           io.tok_pool[--pos] = fin;
         }
-        uint32_t e = L.b32[d * R32 + W_ENODE];
+        uint32_t e = cr.enode;
         while (e != 0 && pos > o) {
           const EmitNode en = io.emit_nodes[e];
           io.tok_pool[--pos] = en;
@@ -1803,11 +1833,12 @@ CTC_UNROLL
       uint32_t d = 0;
       double lg = 0.0;
       if (mine) {
-        const uint32_t idx = L.sel[r] & 0x7FFFFFFFu;
-        d = L.pool[idx * 3 + 2][1];
-        lg = bits_f64(q_lo(L.pool[idx * 3 + 1]));
+        const uint64_t a2 = L.pa[L.sel[r] & 0x7FFFFFFFu];
+        d = (uint32_t)(a2 >> 32);
+        lg = io.pay[((uint32_t)a2 >> 16) & 0xFFFFu].logit;
       }
-      const uint32_t meta1 = L.b32[d * R32 + W_META1];
+      const u32x4 d0 = L.hA[d], d1 = L.hB[d], d2 = L.hC[d];
+      const uint32_t meta1 = d1[2];
       const uint32_t pl = meta1 >> 16;
       const bool closes = mine && fold && pl > 0;
       const uint64_t cm = ctx.ballot(closes);
@@ -1815,7 +1846,7 @@ CTC_UNROLL
       emit_next += (uint32_t)ctx.popc64(cm);
       if (!mine) continue;
       const ColdRec cr = cold_cur()[d];
-      uint32_t enode = L.b32[d * R32 + W_ENODE], depth = cr.depth;
+      uint32_t enode = cr.enode, depth = cr.depth;
       if (closes) {
         if (e >= io.emit_cap) {
           status |= ST_EMIT_OVERFLOW;
@@ -1825,20 +1856,20 @@ CTC_UNROLL
         enode = e;
         depth += 1;
       }
-      const TextNode& node = io.text_nodes[closes ? L.b32[d * R32 + W_CNODE] : L.b32[d * R32 + W_TNODE]];
+      const TextNode& node = io.text_nodes[closes ? cr.cnode : d2[2]];
       ImportBeam& m = io.carry_out[r];
       m.logit_score = lg;
       m.raw_lm = node.raw_lm;
       m.text_h = node.text_h;
-      m.part_h = fold ? 0ull : L.b64[d * R64 + F_PART];
+      m.part_h = fold ? 0ull : q_hi(d0);
 CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) m.ring[k] = node.ring[k];
       m.ring_cnt = node.ring_cnt;
       m.hw_cnt = node.hw_cnt;
       m.plen = fold ? 0u : pl;
       m.last_char = fold ? NO_CHAR : (meta1 & 0xFFFFu);
-      m.m2 = fold ? EMPTY_PARTIAL_M2 : L.b32[d * R32 + W_META2];
-      m.word_id = fold ? 0u : L.b32[d * R32 + W_WID];
+      m.m2 = fold ? EMPTY_PARTIAL_M2 : (d1[3] & ~M2_COMP);
+      m.word_id = fold ? 0u : d2[3];
       m.pstart = fold ? -1 : cr.pstart;
       m.pend = fold ? -1 : cr.pend;
       m.state.len = node.state.len;

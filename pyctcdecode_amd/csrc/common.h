@@ -367,7 +367,9 @@ struct LmProbe {
   NgramEntry e2, e3, e4, e5, e6;
 };
 
-template <class Tab>
+// MAXORD: the highest n-gram order compiled in (a kernel instantiated for models of order <= 4 carries no registers for
+// the keys and entries of orders 5 and 6)
+template <int MAXORD = MAX_CTX + 1, class Tab>
 CTC_HD void lm_probe_issue(const Tab& t, const LmState& in, uint32_t wid, LmProbe& p) {
   p.u = t.unigrams[wid];
   const int in_len = in.len;
@@ -380,13 +382,13 @@ CTC_HD void lm_probe_issue(const Tab& t, const LmState& in, uint32_t wid, LmProb
   // one chain, newest word first: the key of order n extends the key of order n-1 by one word
   uint64_t c = ngram_key_push(ngram_key_begin(), wid);
   if (max_n >= 2) { c = ngram_key_push(c, in.words[0]); p.k2 = ngram_key_end(c, 2); p.s2 = p.k2 & t.ngram_mask; p.e2 = t.ngrams[p.s2]; }
-  if (max_n >= 3) { c = ngram_key_push(c, in.words[1]); p.k3 = ngram_key_end(c, 3); p.s3 = p.k3 & t.ngram_mask; p.e3 = t.ngrams[p.s3]; }
-  if (max_n >= 4) { c = ngram_key_push(c, in.words[2]); p.k4 = ngram_key_end(c, 4); p.s4 = p.k4 & t.ngram_mask; p.e4 = t.ngrams[p.s4]; }
-  if (max_n >= 5) { c = ngram_key_push(c, in.words[3]); p.k5 = ngram_key_end(c, 5); p.s5 = p.k5 & t.ngram_mask; p.e5 = t.ngrams[p.s5]; }
-  if (max_n >= 6) { c = ngram_key_push(c, in.words[4]); p.k6 = ngram_key_end(c, 6); p.s6 = p.k6 & t.ngram_mask; p.e6 = t.ngrams[p.s6]; }
+  if (MAXORD >= 3 && max_n >= 3) { c = ngram_key_push(c, in.words[1]); p.k3 = ngram_key_end(c, 3); p.s3 = p.k3 & t.ngram_mask; p.e3 = t.ngrams[p.s3]; }
+  if (MAXORD >= 4 && max_n >= 4) { c = ngram_key_push(c, in.words[2]); p.k4 = ngram_key_end(c, 4); p.s4 = p.k4 & t.ngram_mask; p.e4 = t.ngrams[p.s4]; }
+  if (MAXORD >= 5 && max_n >= 5) { c = ngram_key_push(c, in.words[3]); p.k5 = ngram_key_end(c, 5); p.s5 = p.k5 & t.ngram_mask; p.e5 = t.ngrams[p.s5]; }
+  if (MAXORD >= 6 && max_n >= 6) { c = ngram_key_push(c, in.words[4]); p.k6 = ngram_key_end(c, 6); p.s6 = p.k6 & t.ngram_mask; p.e6 = t.ngrams[p.s6]; }
 }
 
-template <class Tab>
+template <int MAXORD = MAX_CTX + 1, class Tab>
 CTC_HD float lm_probe_finish(const Tab& t, const LmState& in, uint32_t wid, const LmProbe& p, LmState* out) {
   const int in_len = in.len;
   const int max_n = p.max_n;
@@ -395,13 +397,13 @@ CTC_HD float lm_probe_finish(const Tab& t, const LmState& in, uint32_t wid, cons
   int matched = 1;
   if (max_n >= 2 && lm_resolve(t, p.k2, p.s2, p.e2, &prob, &b1)) {
     matched = 2;
-    if (max_n >= 3 && lm_resolve(t, p.k3, p.s3, p.e3, &prob, &b2)) {
+    if (MAXORD >= 3 && max_n >= 3 && lm_resolve(t, p.k3, p.s3, p.e3, &prob, &b2)) {
       matched = 3;
-      if (max_n >= 4 && lm_resolve(t, p.k4, p.s4, p.e4, &prob, &b3)) {
+      if (MAXORD >= 4 && max_n >= 4 && lm_resolve(t, p.k4, p.s4, p.e4, &prob, &b3)) {
         matched = 4;
-        if (max_n >= 5 && lm_resolve(t, p.k5, p.s5, p.e5, &prob, &b4)) {
+        if (MAXORD >= 5 && max_n >= 5 && lm_resolve(t, p.k5, p.s5, p.e5, &prob, &b4)) {
           matched = 5;
-          if (max_n >= 6 && lm_resolve(t, p.k6, p.s6, p.e6, &prob, &b5)) matched = 6;
+          if (MAXORD >= 6 && max_n >= 6 && lm_resolve(t, p.k6, p.s6, p.e6, &prob, &b5)) matched = 6;
         }
       }
     }
@@ -431,11 +433,11 @@ CTC_HD float lm_probe_finish(const Tab& t, const LmState& in, uint32_t wid, cons
   return prob;
 }
 
-template <class Tab>
+template <int MAXORD = MAX_CTX + 1, class Tab>
 CTC_HD float lm_base_score(const Tab& t, const LmState& in, uint32_t wid, LmState* out) {
   LmProbe p;
-  lm_probe_issue(t, in, wid, p);
-  return lm_probe_finish(t, in, wid, p, out);
+  lm_probe_issue<MAXORD>(t, in, wid, p);
+  return lm_probe_finish<MAXORD>(t, in, wid, p, out);
 }
 
 }  // namespace ctc

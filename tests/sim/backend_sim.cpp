@@ -170,6 +170,7 @@ static void fill_io(const BeamArgs& a, int u, UttIO& io) {
   io.import_xstates = (a.imports && a.import_xstates && !a.resident_in) ? a.import_xstates + (size_t)a.import_off[u] * (n_lms - 1) : nullptr;
   io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
   io.cold = a.cold ? a.cold + (size_t)u * 2 * COLD_STRIDE : nullptr;
+  io.pay = a.pay ? a.pay + (size_t)u * a.pay_stride : nullptr;
   io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
   io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (n_lms - 1) : nullptr;
   io.sstate = a.sstate ? a.sstate + u : nullptr;
@@ -238,7 +239,7 @@ int launch_beam(const BeamArgs& a, std::string* err) {
 static int launch_beam_kernels(const BeamArgs& a, std::string*) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend (default here: wave)
   const bool want_group = force && force[0] == 'g';
-  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width) && !want_group) {
+  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && a.pay && a.max_import <= wave_bucket(a.params.beam_width) && !want_group) {
     switch (wave_bucket(a.params.beam_width)) {
       case 64: run_wave<64>(a); break;
       case 100: run_wave<100>(a); break;

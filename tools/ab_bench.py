@@ -36,33 +36,35 @@ def main():
     del xs
     ref_texts = {}
     for cfg in args.configs:
-        env, n = {}, args.batch
+        env, n, bw = {}, args.batch, bench.BEAM
         for kv in cfg.split(","):
             if not kv:
                 continue
             k, v = kv.split("=", 1)
             if k == "n":
                 n = int(v)
+            elif k == "bw":
+                bw = int(v)
             else:
                 env[k] = v
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
             batch = dev[:n]
-            texts = dec.decode_batch(None, batch, beam_width=bench.BEAM, hotwords=hot)  # warm-up
+            texts = dec.decode_batch(None, batch, beam_width=bw, hotwords=hot)  # warm-up
             wall, pr, bm = [], [], []
             for _ in range(args.steps):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                texts = dec.decode_batch(None, batch, beam_width=bench.BEAM, hotwords=hot)
+                texts = dec.decode_batch(None, batch, beam_width=bw, hotwords=hot)
                 wall.append(1000 * (time.perf_counter() - t0))
                 pr.append(dec.last_timing_ms[0])
                 bm.append(dec.last_timing_ms[1])
             same = None
-            if n in ref_texts:
-                same = texts == ref_texts[n]
+            if (n, bw) in ref_texts:
+                same = texts == ref_texts[(n, bw)]
             else:
-                ref_texts[n] = texts
+                ref_texts[(n, bw)] = texts
             print("AB %-60s n=%-5d wall %.2f ms (min %.2f)  prune %.2f  beam %.2f  kernel %s  %.1f Mframes/s%s" % (
                 cfg, n, float(np.median(wall)), min(wall), float(np.median(pr)), float(np.median(bm)),
                 bench.KERNEL_NAMES.get(dec.last_beam_kernel, "?"), n * args.frames / min(wall) / 1e3,
