@@ -9,8 +9,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctcdec.so")
-SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip"]
-HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "backend.h", "host_tables.h", "np_sum.h"]
+SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip", "beam_wave_hip.hip"]
+# The wave kernel is one loop over the frames with ~18 000 instructions in its body and a budget of 128 registers. LLVM's
+# machine-level loop-invariant code motion hoists every constant and address computation it finds out of that loop and
+# keeps them in registers across it: 105 registers spilled to scratch memory (and every reload of one waits for the
+# stores in flight). Without the pass: none.
+HIP_FLAGS = {"beam_wave_hip.hip": ["-mllvm", "-disable-machine-licm"]}
+HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "set_order_small.h", "backend.h", "host_tables.h", "np_sum.h",
+           "wave_ops_hip.h"]
 
 
 def hipcc() -> str:
@@ -35,19 +41,31 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     obj_dir = os.path.join(HERE, "csrc", "_obj")
     os.makedirs(obj_dir, exist_ok=True)
-    objs = []
     cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    deps = [os.path.join(SRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
+    newest_header = max(os.path.getmtime(d) for d in deps)
+    jobs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src + ".o")
+        objs.append(obj)
+        path = os.path.join(SRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(path)):
+            continue  # this translation unit is up to date
         if src.endswith(".hip"):
-            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wno-unused-result",
-                   "-c", os.path.join(SRC, src), "-o", obj]
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wno-unused-result"]
+            cmd += HIP_FLAGS.get(src, []) + ["-c", path, "-o", obj]
         else:  # pure host C++ (no HIP headers): ARPA parsing, table builders, C ABI
-            cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-DNDEBUG", "-c", os.path.join(SRC, src), "-o", obj]
+            cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-DNDEBUG", "-c", path, "-o", obj]
+        jobs.append(cmd)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-        objs.append(obj)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))  # (the translation units compile side by side; an error of any of them is raised here)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -22,6 +22,7 @@
 #include "set_order.h"
 #include "set_order_small.h"
 #include "np_sum.h"
+#include "wave_ops_hip.h"
 
 namespace ctc {
 namespace be {
@@ -182,65 +183,6 @@ void last_timing(double* prune_ms, double* beam_ms) {
   if (hipEventSynchronize(g_ev[2]) != hipSuccess) return;
   if (hipEventElapsedTime(&a, g_ev[0], g_ev[1]) == hipSuccess) *prune_ms = a;
   if (hipEventElapsedTime(&b, g_ev[1], g_ev[2]) == hipSuccess) *beam_ms = b;
-}
-
-// ---------------------------------------------------------------------------------------------
-// wave helpers (wave64)
-// ---------------------------------------------------------------------------------------------
-// Wave-wide reductions through the DPP crossbar (row_shr 1/2/4/8 inside each row of 16 lanes, then
-// row_bcast15 / row_bcast31 across the rows -- the gfx9 scan pattern): six VALU steps, no LDS round trips
-// (the __shfl_xor form goes through ds_bpermute: two dependent LDS-pipeline operations per step for 64 bits).
-// The total ends up in lane 63 and is broadcast from there. `ident` fills the lanes a step has no source for.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp_u64(uint64_t ident, uint64_t v) {
-  const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)ident, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(ident >> 32), (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
-  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-}
-__device__ __forceinline__ uint64_t bcast_lane63(uint64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
-  return ((uint64_t)hi << 32) | lo;
-}
-#define CTC_DPP_REDUCE(V, IDENT, COMBINE)                 \
-  do {                                                    \
-    V = COMBINE(V, dpp_u64<0x111, 0xf>(IDENT, V)); /* row_shr:1 */  \
-    V = COMBINE(V, dpp_u64<0x112, 0xf>(IDENT, V)); /* row_shr:2 */  \
-    V = COMBINE(V, dpp_u64<0x114, 0xf>(IDENT, V)); /* row_shr:4 */  \
-    V = COMBINE(V, dpp_u64<0x118, 0xf>(IDENT, V)); /* row_shr:8 */  \
-    V = COMBINE(V, dpp_u64<0x142, 0xa>(IDENT, V)); /* row_bcast:15 into rows 1 and 3 */ \
-    V = COMBINE(V, dpp_u64<0x143, 0xc>(IDENT, V)); /* row_bcast:31 into rows 2 and 3 */ \
-  } while (0)
-__device__ __forceinline__ uint64_t comb_add_f64(uint64_t a, uint64_t b) {
-  return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
-}
-__device__ __forceinline__ uint64_t comb_max_f64(uint64_t a, uint64_t b) {
-  return (uint64_t)__double_as_longlong(fmax(__longlong_as_double((long long)a), __longlong_as_double((long long)b)));
-}
-__device__ __forceinline__ uint64_t comb_max_u64(uint64_t a, uint64_t b) { return a > b ? a : b; }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_min_i32(int v) {
-  const int o = __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, CTRL, ROW_MASK, 0xf, false);
-  return o < v ? o : v;
-}
-__device__ __forceinline__ int wave_min_i32(int v) {
-  v = dpp_min_i32<0x111, 0xf>(v);
-  v = dpp_min_i32<0x112, 0xf>(v);
-  v = dpp_min_i32<0x114, 0xf>(v);
-  v = dpp_min_i32<0x118, 0xf>(v);
-  v = dpp_min_i32<0x142, 0xa>(v);
-  v = dpp_min_i32<0x143, 0xc>(v);
-  return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ double wave_sum(double x) {
-  uint64_t v = (uint64_t)__double_as_longlong(x);
-  CTC_DPP_REDUCE(v, 0ull, comb_add_f64);  // +0.0
-  return __longlong_as_double((long long)bcast_lane63(v));
-}
-__device__ __forceinline__ double wave_max(double x) {
-  uint64_t v = (uint64_t)__double_as_longlong(x);
-  CTC_DPP_REDUCE(v, 0xFFF0000000000000ull, comb_max_f64);  // -inf
-  return __longlong_as_double((long long)bcast_lane63(v));
 }
 
 template <typename T>
@@ -1431,140 +1373,8 @@ static int launch_beam_nt(const BeamArgs& a, const LdsShape& shape, size_t lds, 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// wave kernel: one wavefront per utterance (beam_wave.h)
-// ---------------------------------------------------------------------------------------------
-struct WaveGpuCtx {
-  int lane;
-  // One wave issues its LDS operations in order: what the lanes exchange through LDS only needs the compiler
-  // to keep the program order of the accesses.
-  __device__ __forceinline__ void wsync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  // global stores of this wave complete before anything that follows
-  __device__ __forceinline__ void mem_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  }
-  __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
-  __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
-  __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
-  __device__ __forceinline__ int ctz64(uint64_t x) { return __builtin_ctzll(x); }
-  __device__ __forceinline__ int clz32(uint32_t x) { return __clz((int)x); }
-  __device__ __forceinline__ int ctz32(uint32_t x) { return __builtin_ctz(x); }
-  __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-  // the value, but nothing computed from it may be scheduled above this point
-  __device__ __forceinline__ uint32_t opaque32(uint32_t v) {
-    asm volatile("" : "+v"(v));
-    return v;
-  }
-  __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
-  }
-  __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src) {
-    const int s = __builtin_amdgcn_readfirstlane(src);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), s);
-    return ((uint64_t)hi << 32) | lo;
-  }
-  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-    CTC_DPP_REDUCE(v, 0ull, comb_max_u64);
-    return bcast_lane63(v);
-  }
-  __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-    // (status bits: rare) any lane with a bit set makes it wave-wide
-    uint32_t r = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b)
-      if (__ballot((v >> b) & 1u)) r |= 1u << b;
-    return r | (v & ~0xFFu);
-  }
-  __device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v) {  // (finalisation only)
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
-      if ((int)(threadIdx.x & 63) >= off) incl += o;
-    }
-    return incl - v;
-  }
-  __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-    // DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): six VALU steps, no LDS round trips
-    int x = (int)v;
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
-  }
-  __device__ __forceinline__ void lds_max_u64(CTC_LDS uint64_t* p, uint64_t v) {
-    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-  __device__ __forceinline__ void lds_or_u32(CTC_LDS uint32_t* p, uint32_t v) {
-    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  }
-  __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)wall_clock64(); }
-  __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {
-    return atomicAdd(p, v);
-  }
-};
-
-template <int BW, int OCC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void beam_wave(BeamArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-  WaveLds view;
-  wave_lds_carve<BW>(view, (lds_bytes_t)smem);
-  UttIO io;
-  const int64_t r0 = a.utt_row0[u];
-  io.surv_cnt = a.surv_cnt + r0;
-  io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
-  io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
-  io.T = (int32_t)(a.utt_row0[u + 1] - r0);
-  io.text_nodes = a.text_nodes + a.text_off[u];
-  io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
-  io.emit_nodes = a.emit_nodes + a.emit_off[u];
-  io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
-  io.start_state = a.start_states ? a.start_states + (size_t)u : nullptr;
-  io.out_xstates = nullptr;
-  io.out = a.out + (size_t)u * a.out_stride;
-  io.n_out = a.n_out + u;
-  io.status = a.status + u;
-  io.tok_pool = a.tok_pool;
-  io.tok_pool_head = a.tok_pool_head;
-  io.tok_pool_cap = a.tok_pool_cap;
-  io.prof = (u == 0) ? a.prof : nullptr;
-  io.imports = (a.imports && !a.resident_in) ? a.imports + a.import_off[u] : nullptr;
-  io.n_import = (a.imports && !a.resident_in) ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
-  io.import_xstates = nullptr;
-  io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
-  io.cold = a.cold + (size_t)u * 2 * COLD_STRIDE;
-  io.pay = a.pay + (size_t)u * a.pay_stride;
-  io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
-  io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (1u - 1) : nullptr;
-  io.sstate = a.sstate ? a.sstate + u : nullptr;
-  io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
-  io.want_out = a.want_out;
-  if (a.resident_in) {
-    io.imports = a.imports + (size_t)u * a.carry_stride;
-    io.n_import = (int32_t)a.sstate[u].n_carry;
-    io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * 0 : nullptr;
-  }
-  WaveGpuCtx ctx{(int)threadIdx.x};
-  WaveDecoder<WaveGpuCtx, BW> dec(ctx, view, a.tables, a.params, io);
-  dec.run();
-}
-
-template <int BW, int OCC = 2>
-static int launch_wave_t(const BeamArgs& a, std::string* err) {
-  const size_t lds = wave_lds_bytes<BW>();
-  HIP_TRY(hipFuncSetAttribute((const void*)beam_wave<BW, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((beam_wave<BW, OCC>), dim3((unsigned)a.n_utts), dim3(64), lds, g_stream, a);
-  return 0;
-}
+// wave kernel: one wavefront per utterance (beam_wave.h), compiled in its own translation unit (beam_wave_hip.hip)
+int launch_wave(const BeamArgs& a, hipStream_t stream, std::string* err);
 
 // decode_batch (params.texts_only): the best beam's text of every utterance, assembled on the device. One wave per
 // utterance: lane 0 walks the emission chain leaf to root and writes the UTF-8 bytes backwards into the utterance's
@@ -1617,16 +1427,7 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
   const bool wave_ok = wave_eligible(a.tables, a.params) && a.pay && a.max_import <= wave_bucket(a.params.beam_width);
   if (a.n_utts > 0 && wave_ok && !want_group) {
-    int rc;
-    const char* occ = getenv("CTCDEC_WAVE_OCC");
-    if (a.params.beam_width <= 24 && occ) {  // EXPERIMENT: occupancy scaling of the wave kernel
-      rc = occ[0] == '4' ? launch_wave_t<24, 4>(a, err) : occ[0] == '3' ? launch_wave_t<24, 3>(a, err) : launch_wave_t<24, 2>(a, err);
-    } else
-    switch (wave_bucket(a.params.beam_width)) {
-      case 64: rc = launch_wave_t<64>(a, err); break;
-      case 100: rc = launch_wave_t<100>(a, err); break;
-      default: rc = launch_wave_t<128>(a, err); break;
-    }
+    const int rc = launch_wave(a, g_stream, err);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     g_last_kernel = 1;

@@ -197,8 +197,6 @@ struct WaveDecoder {
 
   Ctx& ctx;
   WaveLds& L;
-  const DeviceTables& tab;
-  const DecodeParams& prm;
   const UttIO& io;
   const int lane;
 
@@ -219,8 +217,14 @@ struct WaveDecoder {
   bool run_ok = false;   // the beam table is the output of a full frame of this launch (label_run's precondition)
   unsigned long long t_last = 0;  // (diagnostics: phase ticks are accumulated in global memory)
 
-  CTC_HD WaveDecoder(Ctx& c, WaveLds& l, const DeviceTables& t, const DecodeParams& p, const UttIO& i)
-      : ctx(c), L(l), tab(t), prm(p), io(i), lane(c.lane) {}
+  CTC_HD WaveDecoder(Ctx& c, WaveLds& l, const UttIO& i) : ctx(c), L(l), io(i), lane(c.lane) {}
+
+  // The scorer tables and the decode parameters are launch constants (the kernel's argument block). Every use fetches
+  // what it needs afresh through the execution context -- on the device a scalar load from the argument block behind an
+  // opaque copy of its address -- instead of holding ~100 launch constants in scalar registers across the frame loop,
+  // from where the compiler spills them to vector-register lanes and pays a v_readlane per use.
+  CTC_HD const DeviceTables& tab() const { return ctx.tables(); }
+  CTC_HD const DecodeParams& prm() const { return ctx.params(); }
 
   template <int PHASE>
   CTC_HD void tick() {
@@ -261,42 +265,35 @@ struct WaveDecoder {
     if (!pf_live) return;
     // (every lane loads the same count)
     pf_cnt = io.surv_cnt[t];
-    if (lane < WAVE_LAB && lane < prm.max_surv) {
-      pf_id = io.surv_id[(size_t)t * prm.max_surv + lane];
-      pf_lp = io.surv_lp[(size_t)t * prm.max_surv + lane];
+    if (lane < WAVE_LAB && lane < prm().max_surv) {
+      pf_id = io.surv_id[(size_t)t * prm().max_surv + lane];
+      pf_lp = io.surv_lp[(size_t)t * prm().max_surv + lane];
     }
   }
   // label constants of the first WAVE_LAB survivors of the prefetched frame: requested once the passes of the current
-  // frame are done with the label block, written to it after the table build (the registers only live across the
-  // ranking and the build, where little else does)
+  // frame are done with the label block, written to it after the table build. Four lanes per label: lanes 4l .. 4l+2
+  // fetch the three 16-byte chunks of TokInfo that ARE the label block's chunks 1..3, lane 4l+3 the label's hot-word view
+  // of this call (which goes into the last word of chunk 3) -- four registers across the ranking and the build.
   struct TokRegs {
-    uint64_t h_raw, pow_raw, h_clean, hot_raw;
-    uint32_t len_raw, len_clean, flags, start_flags, start_word_id;
+    u32x4 v;
   };
-  CTC_HD bool tok_mine() const { return pf_live && (uint32_t)lane < pf_cnt && lane < WAVE_LAB; }
   CTC_HD void tok_load(TokRegs& r) {
-    r.h_raw = r.pow_raw = r.h_clean = r.hot_raw = 0;
-    r.len_raw = r.len_clean = r.start_flags = r.start_word_id = 0;
-    r.flags = TK_BLANK;
-    if (!tok_mine()) return;
-    const TokInfo& g = tab.tok[pf_id];
-    r.h_raw = g.h_raw;
-    r.pow_raw = g.pow_raw;
-    r.h_clean = g.h_clean;
-    r.len_raw = g.len_raw;
-    r.len_clean = g.len_clean;
-    r.flags = g.flags;
-    r.start_flags = g.start_flags;
-    r.start_word_id = g.start_word_id;
-    r.hot_raw = tab.tok_hot ? *(const uint64_t*)&tab.tok_hot[pf_id] : 0ull;
+    r.v = mk4(0, 0, 0, 0);
+    const uint32_t l = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    const uint32_t id = ctx.shfl32(pf_id, (int)l);  // (lanes 0 .. WAVE_LAB-1 hold the ids: l < 16)
+    if (!(pf_live && l < pf_cnt)) return;
+    if (q < 3u) {
+      r.v = ((const u32x4a*)&tab().tok[id])[q];
+    } else if (tab().tok_hot) {
+      const uint64_t h = *(const uint64_t*)&tab().tok_hot[id];
+      r.v[3] = ((uint32_t)h & 0xFFFFu) | ((uint32_t)(h >> 32) ? 0x80000000u : 0u);
+    }
   }
   CTC_HD void tok_commit(const TokRegs& r) {
-    if (tok_mine()) {
-      L.lab[lane * 4 + 1] = mk4q(r.h_raw, r.pow_raw);
-      L.lab[lane * 4 + 2] = mk4((uint32_t)r.h_clean, (uint32_t)(r.h_clean >> 32), r.len_raw, r.len_clean);
-      const uint32_t hot = ((uint32_t)r.hot_raw & 0xFFFFu) | ((uint32_t)(r.hot_raw >> 32) ? 0x80000000u : 0u);
-      L.lab[lane * 4 + 3] = mk4(r.flags, r.start_flags, r.start_word_id, hot);
-    }
+    const uint32_t l = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    const bool mine = pf_live && l < pf_cnt;
+    if (mine && q < 3u) L.lab[l * 4 + 1 + q] = r.v;
+    if (mine && q == 3u) ((CTC_LDS uint32_t*)L.lab.p)[(l * 4 + 3) * 4 + 3] = r.v[3];  // (behind chunk 3's own write)
     ctx.wsync();
   }
 
@@ -306,7 +303,7 @@ struct WaveDecoder {
   // first/any: index of the first beam that does not repeat the label (N: none).
   CTC_HD uint32_t mode_block(uint32_t fl, uint32_t c, uint32_t lc0, uint32_t f1) {
     const bool blank = (fl & TK_BLANK) != 0;
-    if (!tab.is_bpe) {
+    if (!tab().is_bpe) {
       const uint32_t mode = blank ? MODE_A : ((fl & TK_SPACE) ? MODE_C : MODE_D);
       if (ctx.ballot(!blank && mode == MODE_C) != 0ull) need = 1u;
       return mode | ((uint32_t)(N & 0xFF) << 8) | (fl << 16);
@@ -376,14 +373,14 @@ CTC_UNROLL
       in.backoff[3] = bits_f32(c4[3]);
       in.backoff[4] = bits_f32(c5[0]);
       out = in;
-      if (tab.has_lm) {
-        const float base = lm_base_score<ORD>(tab, in, wid, &out);
-        raw = raw + lm_word_score(tab, prm, base, m2, 0.0, false);
+      if (tab().has_lm) {
+        const float base = lm_base_score<ORD>(tab(), in, wid, &out);
+        raw = raw + lm_word_score(tab(), prm(), base, m2, 0.0, false);
       }
       const uint32_t cnt = c2[0] + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
-      const double lmhw = raw + prm.hot_weight * (double)cnt;
+      const double lmhw = raw + prm().hot_weight * (double)cnt;
       const uint32_t rc0 = c2[1];
-      const uint32_t rc = rc0 + 1 > tab.n_hist ? tab.n_hist : rc0 + 1;
+      const uint32_t rc = rc0 + 1 > tab().n_hist ? tab().n_hist : rc0 + 1;
       // history ring, newest first: the closed word, then the source node's (its fifth entry always drops out)
       const uint64_t old0 = pack64(c5[2], c5[3]), old1 = q_lo(c6), old2 = q_hi(c6), old3 = ring3;
       uint64_t ring[MAX_CTX];
@@ -503,7 +500,7 @@ CTC_UNROLL
   CTC_HD uint32_t rank_pool(double thr, bool with_hist) {
     if (pool_n > 64u) filter_pool(thr);  // (heavy frames: usually back to one entry per lane)
     const uint32_t n = pool_n;
-    const uint32_t want = (uint32_t)prm.beam_width;
+    const uint32_t want = (uint32_t)prm().beam_width;
     const uint64_t thr_key = score_sort_key(thr);
     // pad the list to a multiple of four (n <= P, P % 4 == 0: the slots exist)
     if (lane < 3 && (n & 3u) != 0u && n + (uint32_t)lane < ((n + 3u) & ~3u)) L.pk[n + (uint32_t)lane] = mk4q(~0ull, 0ull);
@@ -532,8 +529,8 @@ CTC_UNROLL
   // later, so an equal score ranks behind the >= beam_width entries kept here. (Many exactly equal scores around the
   // cut: the full ranking decides.)
   CTC_HD void compact_pool() {
-    filter_pool(key_to_score(runmax) + prm.beam_prune_logp);
-    const uint32_t n = pool_n, want = (uint32_t)prm.beam_width;
+    filter_pool(key_to_score(runmax) + prm().beam_prune_logp);
+    const uint32_t n = pool_n, want = (uint32_t)prm().beam_width;
     if (n <= want) {
       tick<W_PROF_COMPACT>();
       return;
@@ -576,8 +573,8 @@ CTC_UNROLL
   }
   CTC_HD void compact_pool_ranked() {
     const double mx = key_to_score(runmax);
-    uint32_t n = rank_pool(mx + prm.beam_prune_logp, false);
-    if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
+    uint32_t n = rank_pool(mx + prm().beam_prune_logp, false);
+    if (n > (uint32_t)prm().beam_width) n = (uint32_t)prm().beam_width;
     u32x4 g0[SLB];
     uint64_t g1[SLB];
 CTC_UNROLL
@@ -601,7 +598,7 @@ CTC_UNROLL
       }
     }
     pool_n = n;
-    if (n >= (uint32_t)prm.beam_width) {
+    if (n >= (uint32_t)prm().beam_width) {
       const uint32_t r = n - 1;
       uint64_t k = 0;
 CTC_UNROLL
@@ -683,23 +680,23 @@ CTC_UNROLL
     if (FULL) {  // first probe of the prefix / hot-word table of an appended partial word
       const bool probe = valid && app && p != 0;
       c.tslot = (uint32_t)table_slot(p);
-      c.want_p = probe && (k1[3] & PF_ON_TABLE) && tab.prefixes;
-      c.want_h = probe && (k1[3] & M2_HOT_ON) && tab.hot;
+      c.want_p = probe && (k1[3] & PF_ON_TABLE) && tab().prefixes;
+      c.want_h = probe && (k1[3] & M2_HOT_ON) && tab().hot;
       if (c.want_p) {
-        const PrefixEntry& g = tab.prefixes[c.tslot & tab.prefix_mask];
+        const PrefixEntry& g = tab().prefixes[c.tslot & tab().prefix_mask];
         c.pp_key = g.key;
         c.pp_wid = g.word_id;
         c.pp_fl = g.flags;
       }
       if (c.want_h) {
-        const HotEntry& g = tab.hot[c.tslot & tab.hot_mask];
+        const HotEntry& g = tab().hot[c.tslot & tab().hot_mask];
         c.ph_key = g.key;
         c.ph_min = g.min_len;
         c.ph_cmp = g.complete;
       }
       const ColdRec* cr = cold_cur() + ii;
       c.wd = *(closing_word ? &cr->c_lmhw : &cr->pscore);
-      if (prm.prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
+      if (prm().prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
     }
     c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
     c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
@@ -804,12 +801,12 @@ CTC_UNROLL
     if (c.is_rep && c.br == BR_APPEND) {
       const uint64_t key = c.kp;
       if (c.want_p) {
-        uint64_t sp = c.tslot & tab.prefix_mask;
+        uint64_t sp = c.tslot & tab().prefix_mask;
         uint64_t ek = c.pp_key;
         uint32_t nw = c.pp_wid, pf = c.pp_fl;
         while (ek != key && ek != 0) {
-          sp = (sp + 1) & tab.prefix_mask;
-          const PrefixEntry& g = tab.prefixes[sp];
+          sp = (sp + 1) & tab().prefix_mask;
+          const PrefixEntry& g = tab().prefixes[sp];
           ek = g.key;
           nw = g.word_id;
           pf = g.flags;
@@ -819,12 +816,12 @@ CTC_UNROLL
         t.pf = pf;
       }
       if (c.want_h) {
-        uint64_t sh = c.tslot & tab.hot_mask;
+        uint64_t sh = c.tslot & tab().hot_mask;
         uint64_t ek = c.ph_key;
         uint32_t hmin = c.ph_min, hcomp = c.ph_cmp;
         while (ek != key && ek != 0) {
-          sh = (sh + 1) & tab.hot_mask;
-          const HotEntry& g = tab.hot[sh];
+          sh = (sh + 1) & tab().hot_mask;
+          const HotEntry& g = tab().hot[sh];
           ek = g.key;
           hmin = g.min_len;
           hcomp = g.complete;
@@ -842,12 +839,12 @@ CTC_UNROLL
   CTC_HD double partial_score_sel(uint32_t pf_flags, uint32_t hot_min_len, uint32_t plen) const {
     const double pl = (double)plen;
     double s = 0.0;
-    if (tab.has_lm) {  // (uniform)
-      const bool on_trie = tab.has_trie && (pf_flags & PF_UNI_PREFIX);
-      s = prm.unk * (on_trie ? 0.0 : 1.0);
+    if (tab().has_lm) {  // (uniform)
+      const bool on_trie = tab().has_trie && (pf_flags & PF_UNI_PREFIX);
+      s = prm().unk * (on_trie ? 0.0 : 1.0);
       if (plen > 6) s = s * pl / 6.0;  // (the two fp64 divisions stay behind branches: ~15 instructions each)
     }
-    if (hot_min_len > 0) s = prm.hot_weight * pl / (double)hot_min_len;
+    if (hot_min_len > 0) s = prm().hot_weight * pl / (double)hot_min_len;
     return s;
   }
 
@@ -902,17 +899,17 @@ CTC_UNROLL
     const double ps_new = partial_score_sel(isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
     const double q_ps = is0 ? c.wd : ((bw || isA) ? ps_new : 0.0);  // (blank / repeat: the open word's score as it is)
     const double lmhw = (!is0 && !isA && c.pl0 > 0) ? c.wd : own_lmhw;  // boundary / space close the open word
-    const double sc = total_score(tab, c.lg, lmhw, q_ps, q_pl);
+    const double sc = total_score(tab(), c.lg, lmhw, q_ps, q_pl);
     const double score = rep ? sc : 0.0;
     const uint64_t my_key = rep ? asc_key(sc) : 0ull;
     const uint64_t pass_key = ctx.wave_max_u64(my_key);
     if (pass_key > runmax) runmax = pass_key;
-    const double thr = key_to_score(runmax) + prm.beam_prune_logp;
+    const double thr = key_to_score(runmax) + prm().beam_prune_logp;
     tick<W_PROF_SCORE>();
     // (history, partial, last_char) folded to 64 bits (decoder.py:250-254): equality of the folds stands in
     // for equality of the triple (its members are 61/64-bit string hashes already)
     uint64_t hk = 0;
-    if (prm.prune_history) hk = fin64(c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
+    if (prm().prune_history) hk = fin64(c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
     const u32x4 e0 = mk4q(score_sort_key(score), hk);
     const uint32_t blank = (c.mw >> 16) & TK_BLANK;
     const uint32_t arrival = c.ls * (uint32_t)N + c.bi;
@@ -1127,11 +1124,11 @@ CTC_UNROLL
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
         nl[j] = lg[j] + p;
-        sc[j] = total_score(tab, nl[j], rest[j], psc[j], pl[j]);
+        sc[j] = total_score(tab(), nl[j], rest[j], psc[j], pl[j]);
         if (live[j]) L.scr[j * 64 + lane] = sc[j];
       }
       ctx.wsync();
-      const double thr = L.scr[0] + prm.beam_prune_logp;
+      const double thr = L.scr[0] + prm().beam_prune_logp;
       bool bad = false;
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
@@ -1153,8 +1150,8 @@ CTC_UNROLL
         bool q = false;
         if (f < io.T) {
           const uint32_t cnt = io.surv_cnt[f];
-          const uint32_t id = io.surv_id[(size_t)f * prm.max_surv];
-          w_lp = io.surv_lp[(size_t)f * prm.max_surv];
+          const uint32_t id = io.surv_id[(size_t)f * prm().max_surv];
+          w_lp = io.surv_lp[(size_t)f * prm().max_surv];
           q = cnt == 1u && id == lab;
         }
         const uint64_t qm = ctx.ballot(q);
@@ -1190,7 +1187,7 @@ CTC_UNROLL
   CTC_HD int step(int t) {
     const int frame = io.first_frame + t;
     const uint32_t ns = ctx.uni32(pf_cnt);
-    if (run_ok && ns == 1u && N > 0 && !prm.no_label_runs) {
+    if (run_ok && ns == 1u && N > 0 && !prm().no_label_runs) {
       const uint32_t lab = ctx.bcast32(pf_id, 0);
       bool same = true;
 CTC_UNROLL
@@ -1255,11 +1252,11 @@ CTC_UNROLL
         // (more than WAVE_LAB survivors in one frame: fetched on the spot)
         ctx.wsync();  // the previous block's passes are done with the label block
         if (mine) {
-          id = io.surv_id[(size_t)t * prm.max_surv + s];
-          lp = io.surv_lp[(size_t)t * prm.max_surv + s];
-          const TokInfo& g = tab.tok[id];
+          id = io.surv_id[(size_t)t * prm().max_surv + s];
+          lp = io.surv_lp[(size_t)t * prm().max_surv + s];
+          const TokInfo& g = tab().tok[id];
           fl = g.flags;
-          const uint32_t hot = tab.tok_hot ? ((tab.tok_hot[id].min_len & 0xFFFFu) | (tab.tok_hot[id].complete ? 0x80000000u : 0u)) : 0u;
+          const uint32_t hot = tab().tok_hot ? ((tab().tok_hot[id].min_len & 0xFFFFu) | (tab().tok_hot[id].complete ? 0x80000000u : 0u)) : 0u;
           L.lab[lane * 4 + 1] = mk4q(g.h_raw, g.pow_raw);
           L.lab[lane * 4 + 2] = mk4((uint32_t)g.h_clean, (uint32_t)(g.h_clean >> 32), g.len_raw, g.len_clean);
           L.lab[lane * 4 + 3] = mk4(g.flags, g.start_flags, g.start_word_id, hot);
@@ -1289,8 +1286,8 @@ CTC_UNROLL
     TokRegs tr;
     tok_load(tr);
     tick<W_PROF_PFTOK>();
-    const double thr = key_to_score(runmax) + prm.beam_prune_logp;
-    const bool hist = prm.prune_history != 0;
+    const double thr = key_to_score(runmax) + prm().beam_prune_logp;
+    const bool hist = prm().prune_history != 0;
 #ifdef CTC_WAVE_TRACE
     if ((uint32_t)lane < pool_n) {
       const u32x4 t0 = L.pk[lane];
@@ -1302,7 +1299,7 @@ CTC_UNROLL
 #ifdef CTC_STATS
     if (lane == 0) fprintf(stderr, "ST %d %u %u %u\n", N, ns, pool_n, n);
 #endif
-    if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
+    if (n > (uint32_t)prm().beam_width) n = (uint32_t)prm().beam_width;
     tick<W_PROF_RANK>();
     // nothing passed the threshold: only possible with non-finite scores (NaN rows) or a positive
     // beam_prune_logp; the reference then dies on max([]) (decoder.py:545) -- reported through the status
@@ -1382,7 +1379,7 @@ CTC_UNROLL
       depth += 1;
     }
     double ps = 0.0;
-    if (npl > 0) ps = partial_score(tab, prm, m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
+    if (npl > 0) ps = partial_score(tab(), prm(), m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
     u32x4a* nr = (u32x4a*)&cold_next()[d];
     nr[0] = mk4q(clm, f64_bits(ps));
     nr[1] = mk4q(hh, chh);
@@ -1525,7 +1522,7 @@ CTC_UNROLL
       TextNode& tn = io.text_nodes[node];
       tn.text_h = m.text_h;
       tn.raw_lm = m.raw_lm;
-      const double lmhw = m.raw_lm + prm.hot_weight * (double)m.hw_cnt;
+      const double lmhw = m.raw_lm + prm().hot_weight * (double)m.hw_cnt;
       tn.lm_hw = lmhw;
       const uint64_t hh = wave_hist_fold(m.ring, m.ring_cnt);
 CTC_UNROLL
@@ -1555,7 +1552,7 @@ CTC_UNROLL
         }
         io.emit_nodes[enode] = en;
       }
-      const double ps = m.plen > 0 ? partial_score(tab, prm, m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
+      const double ps = m.plen > 0 ? partial_score(tab(), prm(), m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
       write_beam(i, m.text_h, m.part_h, m.logit_score, (m.last_char & 0xFFFFu) | (m.plen << 16),
                  m.plen > 0 ? m.m2 : EMPTY_PARTIAL_M2, lmhw, ps, hh, node, enode, m.word_id, m.pstart, m.pend, depth);
     }
@@ -1566,7 +1563,7 @@ CTC_UNROLL
 
   // ---- finalisation: _finalize_beams(force_next_word, is_end) + output records (decoder.py:558-602,653-667)
   CTC_HD void finalise() {
-    const bool fold = prm.fold != 0, eos = prm.eos != 0;
+    const bool fold = prm().fold != 0, eos = prm().eos != 0;
     pool_n = 0;
     pay_n = 0;
     runmax = asc_key(-INFINITY);
@@ -1640,7 +1637,7 @@ CTC_UNROLL
         if (eos) {
           const TextNode& src = io.text_nodes[d2[2]];
           const uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
-          if (tab.has_lm) {
+          if (tab().has_lm) {
             LmState st, end;
             st.len = src.state.len;
 CTC_UNROLL
@@ -1650,25 +1647,25 @@ CTC_UNROLL
             }
             const uint32_t wid = pl > 0 ? d2[3] : 0u;
             const uint32_t wfl = pl > 0 ? m2 : 0u;
-            const float base_s = lm_base_score<ORD>(tab, st, wid, &end);
+            const float base_s = lm_base_score<ORD>(tab(), st, wid, &end);
             double end_score = 0.0;
-            if (prm.score_boundary) {
+            if (prm().score_boundary) {
               LmState tmp;
-              end_score = (double)lm_base_score<ORD>(tab, end, tab.eos_id, &tmp);
+              end_score = (double)lm_base_score<ORD>(tab(), end, tab().eos_id, &tmp);
             }
-            const double raw = src.raw_lm + lm_word_score(tab, prm, base_s, wfl, end_score, true);
-            lmhw = raw + prm.hot_weight * (double)cnt;
+            const double raw = src.raw_lm + lm_word_score(tab(), prm(), base_s, wfl, end_score, true);
+            lmhw = raw + prm().hot_weight * (double)cnt;
           } else {
-            lmhw = prm.hot_weight * (double)cnt;
+            lmhw = prm().hot_weight * (double)cnt;
           }
         } else {
           lmhw = pl > 0 ? cold_cur()[d].c_lmhw : bits_f64(q_lo(d2));  // memo entry (text (+) word, False)
         }
-        score[j] = tab.has_lm ? lg[j] + lmhw : lg[j] + lmhw + 0.0;
+        score[j] = tab().has_lm ? lg[j] + lmhw : lg[j] + lmhw + 0.0;
       } else {
         const u32x4 k1 = L.hB[v];
         const uint32_t pl = k1[2] >> 16;
-        score[j] = total_score(tab, lg[j], bits_f64(L.c64[v * 2]), pl > 0 ? cold_cur()[v].pscore : 0.0, pl);
+        score[j] = total_score(tab(), lg[j], bits_f64(L.c64[v * 2]), pl > 0 ? cold_cur()[v].pscore : 0.0, pl);
       }
       const uint64_t k = asc_key(score[j]);
       if (k > pass_key) pass_key = k;
@@ -1683,13 +1680,13 @@ CTC_UNROLL
                0u, 0u);
     }
     ctx.wsync();
-    uint32_t n = rank_pool(key_to_score(runmax) + prm.beam_prune_logp, false);
-    if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
+    uint32_t n = rank_pool(key_to_score(runmax) + prm().beam_prune_logp, false);
+    if (n > (uint32_t)prm().beam_width) n = (uint32_t)prm().beam_width;
     if (n == 0) status |= ST_NO_BEAMS;
     if (io.carry_out && !eos) carry_beams(n, fold);
     uint32_t n_out = io.want_out ? n : 0u;
-    if (prm.n_best > 0 && n_out > (uint32_t)prm.n_best) n_out = (uint32_t)prm.n_best;
-    if (prm.texts_only != 0 && n_out > 0) {
+    if (prm().n_best > 0 && n_out > (uint32_t)prm().n_best) n_out = (uint32_t)prm().n_best;
+    if (prm().texts_only != 0 && n_out > 0) {
       // decode_batch: only the best beam's text is wanted, and a separate launch assembles it (assemble_texts: every
       // utterance's chain walk at once instead of at the tail of this one's life) -- leave it where its chain ends
       if (lane == 0) {
@@ -1764,7 +1761,7 @@ CTC_UNROLL
       // the text's memo entry: raw LM sum and the state after its last word
       const TextNode& node = io.text_nodes[closes ? cr.cnode : d2[2]];
       ob.raw_lm = node.raw_lm;
-      if (!tab.has_lm) {
+      if (!tab().has_lm) {
         ob.state.len = -1;
 CTC_UNROLL
         for (int k = 0; k < MAX_CTX; ++k) {
@@ -1782,7 +1779,7 @@ CTC_UNROLL
           st.words[k] = src.state.words[k];
           st.backoff[k] = src.state.backoff[k];
         }
-        lm_base_score<ORD>(tab, st, pl > 0 ? d2[3] : 0u, &ob.state);
+        lm_base_score<ORD>(tab(), st, pl > 0 ? d2[3] : 0u, &ob.state);
       } else {
         ob.state.len = node.state.len;
 CTC_UNROLL

@@ -1,0 +1,192 @@
+// beam_wave_hip.hip -- the wave kernel of the beam stage (beam_wave.h: one wavefront per utterance) for gfx950, in a
+// translation unit of its own (it is the slowest part of the build and the one that is rebuilt most often).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <string>
+
+#include "backend.h"
+#include "beam_core.h"
+#include "beam_wave.h"
+#include "wave_ops_hip.h"
+
+namespace ctc {
+namespace be {
+
+#define HIP_TRY_W(expr)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      if (err) *err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+      return -1;                                                                         \
+    }                                                                                    \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// wave kernel: one wavefront per utterance (beam_wave.h)
+// ---------------------------------------------------------------------------------------------
+typedef const BeamArgs __attribute__((address_space(4))) * KernArgs;  // the kernel's argument block (constant address space)
+struct WaveGpuCtx {
+  int lane;
+  KernArgs ka;
+  // launch constants, re-read where they are used (scalar loads; see WaveDecoder::tab)
+  __device__ __forceinline__ KernArgs fresh() const {
+    KernArgs p = ka;
+    asm volatile("" : "+s"(p));
+    return p;
+  }
+  __device__ __forceinline__ const DeviceTables& tables() const { return *(const DeviceTables*)&fresh()->tables; }
+  __device__ __forceinline__ const DecodeParams& params() const { return *(const DecodeParams*)&fresh()->params; }
+  // One wave issues its LDS operations in order: what the lanes exchange through LDS only needs the compiler
+  // to keep the program order of the accesses.
+  __device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // global stores of this wave complete before anything that follows
+  __device__ __forceinline__ void mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+  __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
+  __device__ __forceinline__ int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+  __device__ __forceinline__ int clz32(uint32_t x) { return __clz((int)x); }
+  __device__ __forceinline__ int ctz32(uint32_t x) { return __builtin_ctz(x); }
+  __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+  // the value, but nothing computed from it may be scheduled above this point
+  __device__ __forceinline__ uint32_t opaque32(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  }
+  __device__ __forceinline__ uint32_t bcast32(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src));
+  }
+  __device__ __forceinline__ uint32_t shfl32(uint32_t v, int src) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+  }
+  __device__ __forceinline__ uint64_t bcast64(uint64_t v, int src) {
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), s);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+    CTC_DPP_REDUCE(v, 0ull, comb_max_u64);
+    return bcast_lane63(v);
+  }
+  __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    // (status bits: rare) any lane with a bit set makes it wave-wide
+    uint32_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (__ballot((v >> b) & 1u)) r |= 1u << b;
+    return r | (v & ~0xFFu);
+  }
+  __device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v) {  // (finalisation only)
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+      if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    return incl - v;
+  }
+  __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    // DPP crossbar (row_shr 1/2/4/8, row_bcast 15/31): six VALU steps, no LDS round trips
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  }
+  __device__ __forceinline__ void lds_max_u64(CTC_LDS uint64_t* p, uint64_t v) {
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __device__ __forceinline__ void lds_or_u32(CTC_LDS uint32_t* p, uint32_t v) {
+    __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)wall_clock64(); }
+  __device__ __forceinline__ unsigned long long global_add(unsigned long long* p, unsigned long long v) {
+    return atomicAdd(p, v);
+  }
+};
+
+// Four waves per SIMD: 128 registers per lane (the allocator is told so: left alone it takes what it likes and halves the
+// residency) and, by wave_lds_bytes, at most 10 KB of LDS at beam_width <= 100 -- sixteen utterances per CU.
+template <int BW, int ORD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void beam_wave(BeamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  WaveLds view;
+  wave_lds_carve<BW>(view, (lds_bytes_t)smem);
+  UttIO io;
+  const int64_t r0 = a.utt_row0[u];
+  io.surv_cnt = a.surv_cnt + r0;
+  io.surv_id = a.surv_id + (size_t)r0 * a.params.max_surv;
+  io.surv_lp = a.surv_lp + (size_t)r0 * a.params.max_surv;
+  io.T = (int32_t)(a.utt_row0[u + 1] - r0);
+  io.text_nodes = a.text_nodes + a.text_off[u];
+  io.text_cap = (uint32_t)(a.text_off[u + 1] - a.text_off[u]);
+  io.emit_nodes = a.emit_nodes + a.emit_off[u];
+  io.emit_cap = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+  io.start_state = a.start_states ? a.start_states + (size_t)u : nullptr;
+  io.out_xstates = nullptr;
+  io.out = a.out + (size_t)u * a.out_stride;
+  io.n_out = a.n_out + u;
+  io.status = a.status + u;
+  io.tok_pool = a.tok_pool;
+  io.tok_pool_head = a.tok_pool_head;
+  io.tok_pool_cap = a.tok_pool_cap;
+  io.prof = (u == 0) ? a.prof : nullptr;
+  io.imports = (a.imports && !a.resident_in) ? a.imports + a.import_off[u] : nullptr;
+  io.n_import = (a.imports && !a.resident_in) ? (int32_t)(a.import_off[u + 1] - a.import_off[u]) : 0;
+  io.import_xstates = nullptr;
+  io.first_frame = a.first_frames ? a.first_frames[u] : a.params.first_frame;
+  io.cold = a.cold + (size_t)u * 2 * COLD_STRIDE;
+  io.pay = a.pay + (size_t)u * a.pay_stride;
+  io.carry_out = a.carry_out ? a.carry_out + (size_t)u * a.carry_stride : nullptr;
+  io.carry_xstates = (a.carry_out && a.carry_xstates) ? a.carry_xstates + (size_t)u * a.carry_stride * (1u - 1) : nullptr;
+  io.sstate = a.sstate ? a.sstate + u : nullptr;
+  io.emit_start = a.sstate ? a.sstate[u].emit_next : 0u;
+  io.want_out = a.want_out;
+  if (a.resident_in) {
+    io.imports = a.imports + (size_t)u * a.carry_stride;
+    io.n_import = (int32_t)a.sstate[u].n_carry;
+    io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * 0 : nullptr;
+  }
+  WaveGpuCtx ctx{(int)threadIdx.x, (KernArgs)__builtin_amdgcn_kernarg_segment_ptr()};
+  WaveDecoder<WaveGpuCtx, BW, ORD> dec(ctx, view, io);
+  dec.run();
+}
+
+
+template <int BW, int ORD>
+static int launch_wave_t(const BeamArgs& a, hipStream_t stream, std::string* err) {
+  const size_t lds = wave_lds_bytes<BW>();
+  HIP_TRY_W(hipFuncSetAttribute((const void*)beam_wave<BW, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((beam_wave<BW, ORD>), dim3((unsigned)a.n_utts), dim3(64), lds, stream, a);
+  return 0;
+}
+template <int BW>
+static int launch_wave_bw(const BeamArgs& a, hipStream_t stream, std::string* err) {
+  // n-gram orders compiled in: up to 4 (the usual models; no LM at all runs here too) or up to MAX_CTX + 1
+  if (!a.tables.has_lm || a.tables.lm_order <= 4) return launch_wave_t<BW, 4>(a, stream, err);
+  return launch_wave_t<BW, MAX_CTX + 1>(a, stream, err);
+}
+
+int launch_wave(const BeamArgs& a, hipStream_t stream, std::string* err) {
+  switch (wave_bucket(a.params.beam_width)) {
+    case 64: return launch_wave_bw<64>(a, stream, err);
+    case 100: return launch_wave_bw<100>(a, stream, err);
+    default: return launch_wave_bw<128>(a, stream, err);
+  }
+}
+
+}  // namespace be
+}  // namespace ctc

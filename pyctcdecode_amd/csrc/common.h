@@ -143,16 +143,19 @@ enum : uint32_t {
   TK_LEAD = 4u,   // starts with U+2581 (BPE) decoder.py:474,478
   TK_TRAIL = 8u,  // ends with U+2581         decoder.py:480-482
 };
-struct TokInfo {  // 64 B
+struct TokInfo {  // 64 B; the first three 16-byte chunks are, as they stand, what the wave kernel stages per label in LDS
   uint64_t h_raw, pow_raw;      // label as appended by branch D (decoder.py:528)
-  uint64_t h_clean, pow_clean;  // label without boundary marks, as started by branch B (:477-481)
+  uint64_t h_clean;             // label without boundary marks, as started by branch B (:477-481)
   uint32_t len_raw, len_clean;  // code points
   uint32_t flags;
   // prefix-table view of the CLEAN label taken as the start of a new word (static per LM)
   uint32_t start_flags;  // PF_* bits, plus PF_ON_TABLE
   uint32_t start_word_id;
-  uint32_t pad[3];
+  uint32_t pad0;
+  uint64_t pow_clean;
+  uint32_t pad[2];
 };
+static_assert(sizeof(TokInfo) == 64, "TokInfo is read in 16-byte chunks");
 constexpr uint32_t PF_ON_TABLE = 8u;  // beam flag: the partial is a stored prefix
 
 // the UTF-8 bytes of a label, for the kernels that assemble decoded texts themselves (decode_batch)

@@ -198,8 +198,8 @@ static void run_wave(const BeamArgs& a) {
     fill_io(a, u, io);
     wavesim::Wave wave;
     wave.run([&](int lane) {
-      wavesim::SimWaveCtx ctx{lane, &wave};
-      WaveDecoder<wavesim::SimWaveCtx, BW> dec(ctx, view, a.tables, a.params, io);
+      wavesim::SimWaveCtx ctx{lane, &wave, &a.tables, &a.params};
+      WaveDecoder<wavesim::SimWaveCtx, BW> dec(ctx, view, io);
       dec.run();
     });
   }

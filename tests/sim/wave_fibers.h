@@ -127,6 +127,10 @@ struct Wave {
 struct SimWaveCtx {
   int lane;
   Wave* w;
+  const ctc::DeviceTables* tabp;
+  const ctc::DecodeParams* prmp;
+  const ctc::DeviceTables& tables() const { return *tabp; }
+  const ctc::DecodeParams& params() const { return *prmp; }
   const uint64_t* all(uint64_t v, int tag) { return w->rendezvous(lane, v, tag); }
   void wsync() { all(0, 1); }
   void mem_sync() { all(0, 2); }
@@ -161,6 +165,10 @@ struct SimWaveCtx {
         abort();
       }
     return (uint32_t)s[from & 63];
+  }
+  uint32_t shfl32(uint32_t v, int src) {  // lane-wise gather: every lane names its own source lane
+    const uint64_t* s = all(v, 11);
+    return (uint32_t)s[src & 63];
   }
   uint64_t bcast64(uint64_t v, int src) {
     const int from = (int)uni32((uint32_t)src) & 63;
