@@ -9,12 +9,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctcdec.so")
-SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip", "beam_wave_hip.hip"]
+SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip", "beam_wave_hip.hip", "beam_group_hip.hip"]
 # The wave kernel is one loop over the frames with ~18 000 instructions in its body and a budget of 128 registers. LLVM's
 # machine-level loop-invariant code motion hoists every constant and address computation it finds out of that loop and
 # keeps them in registers across it: 105 registers spilled to scratch memory (and every reload of one waits for the
 # stores in flight). Without the pass: none.
-HIP_FLAGS = {"beam_wave_hip.hip": ["-mllvm", "-disable-machine-licm"]}
+HIP_FLAGS = {"beam_wave_hip.hip": ["-mllvm", "-disable-machine-licm"],
+             # (the workgroup kernel: 238 -> 195 registers, 255 -> 138 scalar registers spilled to vector lanes)
+             "beam_group_hip.hip": ["-mllvm", "-disable-machine-licm"]}
 HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "set_order_small.h", "backend.h", "host_tables.h", "np_sum.h",
            "wave_ops_hip.h"]
 
@@ -53,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             continue  # this translation unit is up to date
         if src.endswith(".hip"):
             cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wno-unused-result"]
-            cmd += HIP_FLAGS.get(src, []) + ["-c", path, "-o", obj]
+            cmd += HIP_FLAGS.get(src, []) + os.environ.get("CTCDEC_HIPCC_EXTRA", "").split() + ["-c", path, "-o", obj]
         else:  # pure host C++ (no HIP headers): ARPA parsing, table builders, C ABI
             cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-DNDEBUG", "-c", path, "-o", obj]
         jobs.append(cmd)

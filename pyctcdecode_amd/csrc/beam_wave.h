@@ -185,7 +185,8 @@ CTC_HD size_t wave_pay_stride(const DecodeParams& p) { return (size_t)p.max_surv
 
 constexpr int W_PROF_LOAD = 0, W_PROF_COMP = 1, W_PROF_GEN = 2, W_PROF_MATCH = 3, W_PROF_FOLD = 4, W_PROF_SCORE = 5,
               W_PROF_RANK = 6, W_PROF_BUILD = 7, W_PROF_FINAL = 8, W_PROF_COMPACT = 9, W_PROF_PUSH = 10, W_PROF_PFTOK = 11,
-              W_PROF_GATHER = 12, W_PROF_BIG = 13, W_PROF_TABLES = 14, W_PROF_RUN = 15, W_PROF_N = 16;
+              W_PROF_GATHER = 12, W_PROF_BIG = 13, W_PROF_TABLES = 14, W_PROF_RUN = 15, W_PROF_ST_COMP = 16, W_PROF_ST_PUSH = 17,
+              W_PROF_ST_BUILD = 18, W_PROF_N = 19;
 
 // ORD: the highest n-gram order compiled in (4 covers the usual models; 6 everything the tables can hold)
 template <class Ctx, int BW, int ORD = MAX_CTX + 1>
@@ -261,13 +262,14 @@ struct WaveDecoder {
 
   // ---- survivors of a frame: ids and log-probs one frame ahead, then their label constants -> LDS ----------
   CTC_HD void prefetch(int t) {
+    const DecodeParams& P_ = prm();
     pf_live = t < io.T;
     if (!pf_live) return;
     // (every lane loads the same count)
     pf_cnt = io.surv_cnt[t];
-    if (lane < WAVE_LAB && lane < prm().max_surv) {
-      pf_id = io.surv_id[(size_t)t * prm().max_surv + lane];
-      pf_lp = io.surv_lp[(size_t)t * prm().max_surv + lane];
+    if (lane < WAVE_LAB && lane < P_.max_surv) {
+      pf_id = io.surv_id[(size_t)t * P_.max_surv + lane];
+      pf_lp = io.surv_lp[(size_t)t * P_.max_surv + lane];
     }
   }
   // label constants of the first WAVE_LAB survivors of the prefetched frame: requested once the passes of the current
@@ -278,14 +280,15 @@ struct WaveDecoder {
     u32x4 v;
   };
   CTC_HD void tok_load(TokRegs& r) {
+    const DeviceTables& T_ = tab();
     r.v = mk4(0, 0, 0, 0);
     const uint32_t l = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
     const uint32_t id = ctx.shfl32(pf_id, (int)l);  // (lanes 0 .. WAVE_LAB-1 hold the ids: l < 16)
     if (!(pf_live && l < pf_cnt)) return;
     if (q < 3u) {
-      r.v = ((const u32x4a*)&tab().tok[id])[q];
-    } else if (tab().tok_hot) {
-      const uint64_t h = *(const uint64_t*)&tab().tok_hot[id];
+      r.v = ((const u32x4a*)&T_.tok[id])[q];
+    } else if (T_.tok_hot) {
+      const uint64_t h = *(const uint64_t*)&T_.tok_hot[id];
       r.v[3] = ((uint32_t)h & 0xFFFFu) | ((uint32_t)(h >> 32) ? 0x80000000u : 0u);
     }
   }
@@ -293,7 +296,8 @@ struct WaveDecoder {
     const uint32_t l = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
     const bool mine = pf_live && l < pf_cnt;
     if (mine && q < 3u) L.lab[l * 4 + 1 + q] = r.v;
-    if (mine && q == 3u) ((CTC_LDS uint32_t*)L.lab.p)[(l * 4 + 3) * 4 + 3] = r.v[3];  // (behind chunk 3's own write)
+    ctx.wsync();  // (the hot-word view goes into the last word of chunk 3, behind that chunk's own write)
+    if (mine && q == 3u) ((CTC_LDS uint32_t*)L.lab.p)[(l * 4 + 3) * 4 + 3] = r.v[3];
     ctx.wsync();
   }
 
@@ -333,6 +337,8 @@ struct WaveDecoder {
   // spot: source node -> n-gram probes -> new node are three dependent global round trips, which the other
   // wavefronts of the SIMD cover. What later phases need of the completion goes to the beam's ColdRec.
   CTC_HD void completions_now() {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
 CTC_UNROLL
     for (int j = 0; j < SLB; ++j) {
       if (j * 64 >= N) continue;
@@ -373,14 +379,14 @@ CTC_UNROLL
       in.backoff[3] = bits_f32(c4[3]);
       in.backoff[4] = bits_f32(c5[0]);
       out = in;
-      if (tab().has_lm) {
-        const float base = lm_base_score<ORD>(tab(), in, wid, &out);
-        raw = raw + lm_word_score(tab(), prm(), base, m2, 0.0, false);
+      if (T_.has_lm) {
+        const float base = lm_base_score<ORD>(T_, in, wid, &out);
+        raw = raw + lm_word_score(T_, P_, base, m2, 0.0, false);
       }
       const uint32_t cnt = c2[0] + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
-      const double lmhw = raw + prm().hot_weight * (double)cnt;
+      const double lmhw = raw + P_.hot_weight * (double)cnt;
       const uint32_t rc0 = c2[1];
-      const uint32_t rc = rc0 + 1 > tab().n_hist ? tab().n_hist : rc0 + 1;
+      const uint32_t rc = rc0 + 1 > T_.n_hist ? T_.n_hist : rc0 + 1;
       // history ring, newest first: the closed word, then the source node's (its fifth entry always drops out)
       const uint64_t old0 = pack64(c5[2], c5[3]), old1 = q_lo(c6), old2 = q_hi(c6), old3 = ring3;
       uint64_t ring[MAX_CTX];
@@ -406,6 +412,11 @@ CTC_UNROLL
       cr.cnode = idx;
       L.b32[i * 4 + 3] = m2 | M2_COMP;
     }
+#ifdef CTC_STORE_PROBE
+    tick<W_PROF_COMP>();
+    ctx.vm_wait();
+    tick<W_PROF_ST_COMP>();
+#endif
   }
 
   // ---- pool ranking --------------------------------------------------------------------------
@@ -529,8 +540,9 @@ CTC_UNROLL
   // later, so an equal score ranks behind the >= beam_width entries kept here. (Many exactly equal scores around the
   // cut: the full ranking decides.)
   CTC_HD void compact_pool() {
-    filter_pool(key_to_score(runmax) + prm().beam_prune_logp);
-    const uint32_t n = pool_n, want = (uint32_t)prm().beam_width;
+    const DecodeParams& P_ = prm();
+    filter_pool(key_to_score(runmax) + P_.beam_prune_logp);
+    const uint32_t n = pool_n, want = (uint32_t)P_.beam_width;
     if (n <= want) {
       tick<W_PROF_COMPACT>();
       return;
@@ -572,9 +584,10 @@ CTC_UNROLL
     tick<W_PROF_COMPACT>();
   }
   CTC_HD void compact_pool_ranked() {
+    const DecodeParams& P_ = prm();
     const double mx = key_to_score(runmax);
-    uint32_t n = rank_pool(mx + prm().beam_prune_logp, false);
-    if (n > (uint32_t)prm().beam_width) n = (uint32_t)prm().beam_width;
+    uint32_t n = rank_pool(mx + P_.beam_prune_logp, false);
+    if (n > (uint32_t)P_.beam_width) n = (uint32_t)P_.beam_width;
     u32x4 g0[SLB];
     uint64_t g1[SLB];
 CTC_UNROLL
@@ -598,7 +611,7 @@ CTC_UNROLL
       }
     }
     pool_n = n;
-    if (n >= (uint32_t)prm().beam_width) {
+    if (n >= (uint32_t)P_.beam_width) {
       const uint32_t r = n - 1;
       uint64_t k = 0;
 CTC_UNROLL
@@ -628,6 +641,8 @@ CTC_UNROLL
   // words of the beam's ColdRec its score will need. closes_any (uniform): some label of the pass closes open words.
   template <bool FULL>
   CTC_HD void gen(Cand& c, bool valid, uint32_t l, uint32_t s, uint32_t i, bool closes_any) {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
     // Straight-line: a lane without a candidate computes on label 0 / beam 0 (its fields are only looked at behind
     // `valid`), and every branch of the reference's if-ladder (decoder.py:452-534) is a select.
     const uint32_t ll = valid ? l : 0u, ii = valid ? i : 0u;
@@ -680,23 +695,23 @@ CTC_UNROLL
     if (FULL) {  // first probe of the prefix / hot-word table of an appended partial word
       const bool probe = valid && app && p != 0;
       c.tslot = (uint32_t)table_slot(p);
-      c.want_p = probe && (k1[3] & PF_ON_TABLE) && tab().prefixes;
-      c.want_h = probe && (k1[3] & M2_HOT_ON) && tab().hot;
+      c.want_p = probe && (k1[3] & PF_ON_TABLE) && T_.prefixes;
+      c.want_h = probe && (k1[3] & M2_HOT_ON) && T_.hot;
       if (c.want_p) {
-        const PrefixEntry& g = tab().prefixes[c.tslot & tab().prefix_mask];
+        const PrefixEntry& g = T_.prefixes[c.tslot & T_.prefix_mask];
         c.pp_key = g.key;
         c.pp_wid = g.word_id;
         c.pp_fl = g.flags;
       }
       if (c.want_h) {
-        const HotEntry& g = tab().hot[c.tslot & tab().hot_mask];
+        const HotEntry& g = T_.hot[c.tslot & T_.hot_mask];
         c.ph_key = g.key;
         c.ph_min = g.min_len;
         c.ph_cmp = g.complete;
       }
       const ColdRec* cr = cold_cur() + ii;
       c.wd = *(closing_word ? &cr->c_lmhw : &cr->pscore);
-      if (prm().prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
+      if (P_.prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
     }
     c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
     c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
@@ -795,18 +810,19 @@ CTC_UNROLL
     uint32_t pf, nw, hmin, hcomp;
   };
   CTC_HD TabView resolve_tables(const Cand& c) {
+    const DeviceTables& T_ = tab();
     TabView t;
     t.on = t.hon = false;
     t.pf = t.nw = t.hmin = t.hcomp = 0;
     if (c.is_rep && c.br == BR_APPEND) {
       const uint64_t key = c.kp;
       if (c.want_p) {
-        uint64_t sp = c.tslot & tab().prefix_mask;
+        uint64_t sp = c.tslot & T_.prefix_mask;
         uint64_t ek = c.pp_key;
         uint32_t nw = c.pp_wid, pf = c.pp_fl;
         while (ek != key && ek != 0) {
-          sp = (sp + 1) & tab().prefix_mask;
-          const PrefixEntry& g = tab().prefixes[sp];
+          sp = (sp + 1) & T_.prefix_mask;
+          const PrefixEntry& g = T_.prefixes[sp];
           ek = g.key;
           nw = g.word_id;
           pf = g.flags;
@@ -816,12 +832,12 @@ CTC_UNROLL
         t.pf = pf;
       }
       if (c.want_h) {
-        uint64_t sh = c.tslot & tab().hot_mask;
+        uint64_t sh = c.tslot & T_.hot_mask;
         uint64_t ek = c.ph_key;
         uint32_t hmin = c.ph_min, hcomp = c.ph_cmp;
         while (ek != key && ek != 0) {
-          sh = (sh + 1) & tab().hot_mask;
-          const HotEntry& g = tab().hot[sh];
+          sh = (sh + 1) & T_.hot_mask;
+          const HotEntry& g = T_.hot[sh];
           ek = g.key;
           hmin = g.min_len;
           hcomp = g.complete;
@@ -836,15 +852,16 @@ CTC_UNROLL
 
   // partial_score (beam_core.h: language_model.py:141-150, 326-336; decoder.py:363-367, 397-409) as selects, for the
   // single-model kernel: same operations in the same order.
-  CTC_HD double partial_score_sel(uint32_t pf_flags, uint32_t hot_min_len, uint32_t plen) const {
+  CTC_HD static double partial_score_sel(const DeviceTables& T_, const DecodeParams& P_, uint32_t pf_flags, uint32_t hot_min_len,
+                                         uint32_t plen) {
     const double pl = (double)plen;
     double s = 0.0;
-    if (tab().has_lm) {  // (uniform)
-      const bool on_trie = tab().has_trie && (pf_flags & PF_UNI_PREFIX);
-      s = prm().unk * (on_trie ? 0.0 : 1.0);
+    if (T_.has_lm) {  // (uniform)
+      const bool on_trie = T_.has_trie && (pf_flags & PF_UNI_PREFIX);
+      s = P_.unk * (on_trie ? 0.0 : 1.0);
       if (plen > 6) s = s * pl / 6.0;  // (the two fp64 divisions stay behind branches: ~15 instructions each)
     }
-    if (hot_min_len > 0) s = prm().hot_weight * pl / (double)hot_min_len;
+    if (hot_min_len > 0) s = P_.hot_weight * pl / (double)hot_min_len;
     return s;
   }
 
@@ -872,6 +889,8 @@ CTC_UNROLL
   // score the representatives of a pass (decoder.py:346-424) and push what can still matter into the pool;
   // imax / dbr: the group's donor (last arrival: its beam, its branch)
   CTC_HD void score_push(const Cand& c, const TabView& t, uint32_t imax, uint32_t dbr) {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
     // Straight-line (selects, LDS reads at safe indices). Lanes that represent nothing compute on beam 0 / label 0
     // and are masked at the end.
     const bool rep = c.is_rep;
@@ -896,20 +915,20 @@ CTC_UNROLL
     const uint32_t q_pl = is0 ? c.pl0 : (isB ? len_clean : (isA ? c.pl0 + c.len_raw : 0u));
     const uint32_t q_m2 = is0 ? (c.m2_0 & ~M2_COMP) : (isB ? m2B : (isA ? m2A : EMPTY_PARTIAL_M2));
     const uint32_t q_wid = is0 ? st_wid : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t.on ? t.nw : 0u) : 0u));
-    const double ps_new = partial_score_sel(isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
+    const double ps_new = partial_score_sel(T_, P_, isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
     const double q_ps = is0 ? c.wd : ((bw || isA) ? ps_new : 0.0);  // (blank / repeat: the open word's score as it is)
     const double lmhw = (!is0 && !isA && c.pl0 > 0) ? c.wd : own_lmhw;  // boundary / space close the open word
-    const double sc = total_score(tab(), c.lg, lmhw, q_ps, q_pl);
+    const double sc = total_score(T_, c.lg, lmhw, q_ps, q_pl);
     const double score = rep ? sc : 0.0;
     const uint64_t my_key = rep ? asc_key(sc) : 0ull;
     const uint64_t pass_key = ctx.wave_max_u64(my_key);
     if (pass_key > runmax) runmax = pass_key;
-    const double thr = key_to_score(runmax) + prm().beam_prune_logp;
+    const double thr = key_to_score(runmax) + P_.beam_prune_logp;
     tick<W_PROF_SCORE>();
     // (history, partial, last_char) folded to 64 bits (decoder.py:250-254): equality of the folds stands in
     // for equality of the triple (its members are 61/64-bit string hashes already)
     uint64_t hk = 0;
-    if (prm().prune_history) hk = fin64(c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
+    if (P_.prune_history) hk = fin64(c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
     const u32x4 e0 = mk4q(score_sort_key(score), hk);
     const uint32_t blank = (c.mw >> 16) & TK_BLANK;
     const uint32_t arrival = c.ls * (uint32_t)N + c.bi;
@@ -935,6 +954,10 @@ CTC_UNROLL
     pool_put(push, e0, arrival, donor, c.lg, c.kp, q_pl, q_wid, q_m2);
     ctx.wsync();
     tick<W_PROF_PUSH>();
+#ifdef CTC_STORE_PROBE
+    ctx.vm_wait();
+    tick<W_PROF_ST_PUSH>();
+#endif
   }
 
   // does some label in [l0, l1) of the staged block close open words (boundary / space modes)? (uniform)
@@ -1098,6 +1121,8 @@ CTC_UNROLL
   // ends the run and goes through the full path. Real CTC posteriors are mostly such frames (the reference's
   // libri sample: 327 of 371 frames have one survivor). Returns the first frame not consumed (t: none was).
   CTC_HD int label_run(int t, uint32_t lab, bool lab_is_blank) {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
     double lg[SLB], rest[SLB], psc[SLB];
     uint32_t pl[SLB];
     bool live[SLB];
@@ -1124,11 +1149,11 @@ CTC_UNROLL
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
         nl[j] = lg[j] + p;
-        sc[j] = total_score(tab(), nl[j], rest[j], psc[j], pl[j]);
+        sc[j] = total_score(T_, nl[j], rest[j], psc[j], pl[j]);
         if (live[j]) L.scr[j * 64 + lane] = sc[j];
       }
       ctx.wsync();
-      const double thr = L.scr[0] + prm().beam_prune_logp;
+      const double thr = L.scr[0] + P_.beam_prune_logp;
       bool bad = false;
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
@@ -1150,8 +1175,8 @@ CTC_UNROLL
         bool q = false;
         if (f < io.T) {
           const uint32_t cnt = io.surv_cnt[f];
-          const uint32_t id = io.surv_id[(size_t)f * prm().max_surv];
-          w_lp = io.surv_lp[(size_t)f * prm().max_surv];
+          const uint32_t id = io.surv_id[(size_t)f * P_.max_surv];
+          w_lp = io.surv_lp[(size_t)f * P_.max_surv];
           q = cnt == 1u && id == lab;
         }
         const uint64_t qm = ctx.ballot(q);
@@ -1304,9 +1329,17 @@ CTC_UNROLL
     // nothing passed the threshold: only possible with non-finite scores (NaN rows) or a positive
     // beam_prune_logp; the reference then dies on max([]) (decoder.py:545) -- reported through the status
     if (n == 0) status |= ST_NO_BEAMS;
-    if (SLB == 1 || n <= 64u) build1(frame, n);
-    else build_big(frame, n);
-    tok_commit(tr);
+    // Everything requested so far -- the next frame's survivors and their label constants -- is in its registers before the
+    // build issues its stores: the accesses of a wave complete in issue order, so a load waited for behind a store waits for
+    // that store's acknowledgement too (0.3 - 0.6 us), and the first thing the next frame does is look at its survivors.
+    ctx.vm_wait();
+    if (SLB == 1 || n <= 64u) {
+      tok_commit(tr);  // (the label block is idle from here on; build_big parks records in it)
+      build1(frame, n);
+    } else {
+      build_big(frame, n);
+      tok_commit(tr);
+    }
     run_ok = true;
     return t + 1;
   }
@@ -1318,6 +1351,8 @@ CTC_UNROLL
   // the columns of one rank (w = its L.sel word, d = its place in the new table); also writes the beam's ColdRec
   // and, for a label that is not a blank / repeat, its emission node. All lanes call.
   CTC_HD void gather(int frame, uint32_t w, bool kept, uint32_t d, Rec& o) {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
     o.o0 = o.o1 = o.o2 = mk4(0, 0, 0, 0);
     // the payload is the donor's (the last-arriving duplicate, decoder.py:221-223), its branch included
     uint64_t a2 = 0;
@@ -1379,7 +1414,7 @@ CTC_UNROLL
       depth += 1;
     }
     double ps = 0.0;
-    if (npl > 0) ps = partial_score(tab(), prm(), m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
+    if (npl > 0) ps = partial_score_sel(T_, P_, m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
     u32x4a* nr = (u32x4a*)&cold_next()[d];
     nr[0] = mk4q(clm, f64_bits(ps));
     nr[1] = mk4q(hh, chh);
@@ -1401,6 +1436,10 @@ CTC_UNROLL
     status = ctx.wave_or_u32(status);
     ctx.wsync();
     tick<W_PROF_BUILD>();
+#ifdef CTC_STORE_PROBE
+    ctx.vm_wait();
+    tick<W_PROF_ST_BUILD>();
+#endif
   }
   // at most 64 ranks (nearly every frame): gather everything the new columns need, then write them in place
   CTC_HD void build1(int frame, uint32_t n) {
@@ -1513,6 +1552,8 @@ CTC_UNROLL
   // checked that there are no more of them than the table holds). Beams built by the host are rooted in fresh
   // BR_IMPORT emission nodes; beams carried over on the device (resident streams) keep their emission chains.
   CTC_HD void import_beams() {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
     const int n = io.n_import < BW ? io.n_import : BW;
     const uint32_t emit_base = emit_next;
     const bool host_built = io.imports[0].resident == 0u;
@@ -1522,7 +1563,7 @@ CTC_UNROLL
       TextNode& tn = io.text_nodes[node];
       tn.text_h = m.text_h;
       tn.raw_lm = m.raw_lm;
-      const double lmhw = m.raw_lm + prm().hot_weight * (double)m.hw_cnt;
+      const double lmhw = m.raw_lm + P_.hot_weight * (double)m.hw_cnt;
       tn.lm_hw = lmhw;
       const uint64_t hh = wave_hist_fold(m.ring, m.ring_cnt);
 CTC_UNROLL
@@ -1552,7 +1593,7 @@ CTC_UNROLL
         }
         io.emit_nodes[enode] = en;
       }
-      const double ps = m.plen > 0 ? partial_score(tab(), prm(), m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
+      const double ps = m.plen > 0 ? partial_score(T_, P_, m.m2 & PF_PARTIAL_MASK, (m.m2 & M2_HOT_ON) ? ((m.m2 >> 8) & 0xFFFFu) : 0u, m.plen) : 0.0;
       write_beam(i, m.text_h, m.part_h, m.logit_score, (m.last_char & 0xFFFFu) | (m.plen << 16),
                  m.plen > 0 ? m.m2 : EMPTY_PARTIAL_M2, lmhw, ps, hh, node, enode, m.word_id, m.pstart, m.pend, depth);
     }

@@ -49,6 +49,9 @@ struct WaveGpuCtx {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
   }
+  // every global load / store of this wave issued so far has completed
+  // (the builtin, not inline assembly: the compiler's own wait-count bookkeeping sees it and does not wait again)
+  __device__ __forceinline__ void vm_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), expcnt / lgkmcnt untouched
   __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
   __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
   __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }

@@ -134,6 +134,7 @@ struct SimWaveCtx {
   const uint64_t* all(uint64_t v, int tag) { return w->rendezvous(lane, v, tag); }
   void wsync() { all(0, 1); }
   void mem_sync() { all(0, 2); }
+  void vm_wait() {}  // (device: every global access issued so far has completed)
   uint64_t ballot(bool p) {
     const uint64_t* s = all(p ? 1u : 0u, 3);
     uint64_t m = 0;
