@@ -74,15 +74,8 @@ class Beam:
 
     @classmethod
     def from_lm_beam(cls, lm_beam: "LMBeam") -> "Beam":
-        return Beam(
-            text=lm_beam.text,
-            next_word=lm_beam.next_word,
-            partial_word=lm_beam.partial_word,
-            last_char=lm_beam.last_char,
-            text_frames=lm_beam.text_frames,
-            partial_frames=lm_beam.partial_frames,
-            logit_score=lm_beam.logit_score,
-        )
+        """The beam without its language-model score (decoder.py:81-92)."""
+        return Beam(*(getattr(lm_beam, f.name) for f in dataclasses.fields(Beam)))
 
 
 @dataclasses.dataclass(frozen=True)
@@ -101,11 +94,9 @@ class OutputBeam:
     lm_score: float
 
     def get_mp_safe_beam(self) -> "OutputBeam":
-        if self.last_lm_state is None:
-            last_lm_state = None
-        else:
-            last_lm_state = self.last_lm_state.get_mp_safe_state()
-        return dataclasses.replace(self, last_lm_state=last_lm_state)
+        """A copy that pickles: the LM state is swapped for its process-independent form (decoder.py:112-118)."""
+        state = self.last_lm_state
+        return dataclasses.replace(self, last_lm_state=state.get_mp_safe_state() if state is not None else None)
 
 
 NULL_FRAMES: Frames = (-1, -1)
@@ -585,19 +576,12 @@ class BeamSearchDecoderCTC:
         unk_score_offset: Optional[float] = None,
         lm_score_boundary: Optional[bool] = None,
     ) -> None:
-        language_model = self._language_model
-        if language_model is None:
+        """Forward the weights that were given to the language model (decoder.py:292-316); no model, nothing to do."""
+        lm = self._language_model
+        if lm is None:
             return
-        params: Dict[str, Any] = {}
-        if alpha is not None:
-            params["alpha"] = alpha
-        if beta is not None:
-            params["beta"] = beta
-        if unk_score_offset is not None:
-            params["unk_score_offset"] = unk_score_offset
-        if lm_score_boundary is not None:
-            params["score_boundary"] = lm_score_boundary
-        language_model.reset_params(**params)
+        given = {"alpha": alpha, "beta": beta, "unk_score_offset": unk_score_offset, "score_boundary": lm_score_boundary}
+        lm.reset_params(**{name: value for name, value in given.items() if value is not None})
 
     @classmethod
     def clear_class_models(cls) -> None:
@@ -868,60 +852,55 @@ class BeamSearchDecoderCTC:
     _LANGUAGE_MODEL_SERIALIZED_DIRECTORY = "language_model"
 
     def save_to_dir(self, filepath: str) -> None:
-        with open(os.path.join(filepath, self._ALPHABET_SERIALIZED_FILENAME), "w") as fi:
-            fi.write(self._alphabet.dumps())
-        lm = self._language_model
-        if lm is None:
+        """Layout of decoder.py:947-962: <dir>/alphabet.json and, with a language model, <dir>/language_model/."""
+        alphabet_file = os.path.join(filepath, self._ALPHABET_SERIALIZED_FILENAME)
+        with open(alphabet_file, "w") as out:
+            out.write(self._alphabet.dumps())
+        if self._language_model is None:
             logger.info("decoder has no language model.")
-        else:
-            lm_path = os.path.join(filepath, self._LANGUAGE_MODEL_SERIALIZED_DIRECTORY)
-            os.makedirs(lm_path)
-            logger.info("Saving language model to %s", lm_path)
-            lm.save_to_dir(lm_path)
+            return
+        lm_dir = os.path.join(filepath, self._LANGUAGE_MODEL_SERIALIZED_DIRECTORY)
+        os.makedirs(lm_dir)
+        logger.info("Saving language model to %s", lm_dir)
+        self._language_model.save_to_dir(lm_dir)
 
     @staticmethod
     def parse_directory_contents(filepath: str) -> Dict[str, Optional[str]]:
-        contents = [c for c in os.listdir(filepath) if not c.startswith(".") and not c.startswith("__")]
-        if BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME not in contents:
-            raise ValueError(
-                f"Could not find alphabet file {BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME}. Found {contents}"
-            )
-        alphabet_filepath = os.path.join(filepath, BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME)
-        contents.remove(BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME)
-        lm_directory: Optional[str] = None
-        if contents:
-            if BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY not in contents:
-                raise ValueError(
-                    f"Count not find language model directory. Looking for "
-                    f"{BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY}, found {contents}"
-                )
-            lm_directory = os.path.join(filepath, BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY)
-        return {"alphabet": alphabet_filepath, "language_model": lm_directory}
+        """Where the parts of a saved decoder are (decoder.py:964-990): {"alphabet": path, "language_model": dir or None}.
+        Hidden and dunder entries are ignored; anything else besides the two known names is an error."""
+        alphabet_name = BeamSearchDecoderCTC._ALPHABET_SERIALIZED_FILENAME
+        lm_name = BeamSearchDecoderCTC._LANGUAGE_MODEL_SERIALIZED_DIRECTORY
+        entries = sorted(e for e in os.listdir(filepath) if not e.startswith((".", "__")))
+        if alphabet_name not in entries:
+            raise ValueError(f"Could not find alphabet file {alphabet_name}. Found {entries}")
+        others = [e for e in entries if e != alphabet_name]
+        if others and lm_name not in others:
+            raise ValueError(f"Could not find language model directory. Looking for {lm_name}, found {others}")
+        return {"alphabet": os.path.join(filepath, alphabet_name),
+                "language_model": os.path.join(filepath, lm_name) if others else None}
 
     @classmethod
     def load_from_dir(cls, filepath: str, unigram_encoding: Optional[str] = None) -> "BeamSearchDecoderCTC":
-        filenames = cls.parse_directory_contents(filepath)
-        with open(filenames["alphabet"], "r") as fi:
-            alphabet = Alphabet.loads(fi.read())
-        language_model = None
-        if filenames["language_model"] is not None:
-            language_model = LanguageModel.load_from_dir(filenames["language_model"], unigram_encoding=unigram_encoding)
-        return cls(alphabet, language_model=language_model)
+        """Inverse of save_to_dir (decoder.py:992-1005)."""
+        parts = cls.parse_directory_contents(filepath)
+        with open(parts["alphabet"]) as src:
+            alphabet = Alphabet.loads(src.read())
+        lm_dir = parts["language_model"]
+        lm = None if lm_dir is None else LanguageModel.load_from_dir(lm_dir, unigram_encoding=unigram_encoding)
+        return cls(alphabet, language_model=lm)
 
     @classmethod
     def load_from_hf_hub(cls, model_id: str, cache_dir: Optional[str] = None, **kwargs: Any) -> "BeamSearchDecoderCTC":
-        """decoder.py:1007-1043: snapshot-download a decoder directory from the Hugging Face hub."""
-        from pathlib import Path
-
-        cache_dir = cache_dir or os.path.join(Path.home(), ".cache", "pyctcdecode")
+        """decoder.py:1007-1043: fetch a saved decoder directory from the Hugging Face hub (default cache
+        ~/.cache/pyctcdecode) and load it."""
         try:
-            from huggingface_hub import snapshot_download
-        except ImportError:
-            raise ImportError(
-                "You need to install huggingface_hub to use `load_from_hf_hub`. "
-                "See https://pypi.org/project/huggingface-hub/ for installation."
-            )
-        return cls.load_from_dir(snapshot_download(model_id, cache_dir=cache_dir, **kwargs))
+            import huggingface_hub
+        except ImportError as exc:
+            raise ImportError("load_from_hf_hub needs the huggingface_hub package "
+                              "(https://pypi.org/project/huggingface-hub/).") from exc
+        if cache_dir is None:
+            cache_dir = os.path.join(os.path.expanduser("~"), ".cache", "pyctcdecode")
+        return cls.load_from_dir(huggingface_hub.snapshot_download(model_id, cache_dir=cache_dir, **kwargs))
 
     # -- streaming (decoder.py:669-728) ----------------------------------------------------------
     def get_starting_state(self):
@@ -1077,30 +1056,22 @@ def build_ctcdecoder(
     unk_score_offset: float = DEFAULT_UNK_LOGP_OFFSET,
     lm_score_boundary: bool = DEFAULT_SCORE_LM_BOUNDARY,
 ) -> BeamSearchDecoderCTC:
-    """decoder.py:1051-1099."""
-    kenlm_model = None if kenlm_model_path is None else NgramModel(kenlm_model_path)
-    if kenlm_model_path is not None and kenlm_model_path.endswith(".arpa"):
+    """decoder.py:1051-1099: alphabet from `labels`; with a model path, an n-gram LanguageModel over it. The unigram list
+    of an .arpa file is read from the file itself when none is given; any other model format carries none."""
+    from_arpa = kenlm_model_path is not None and kenlm_model_path.endswith(".arpa")
+    if from_arpa:
         logger.info("Using arpa instead of binary LM file, decoder instantiation might be slow.")
-    if unigrams is None and kenlm_model_path is not None:
-        if kenlm_model_path.endswith(".arpa"):
-            unigrams = load_unigram_set_from_arpa(kenlm_model_path)
-        else:
-            logger.warning(
-                "Unigrams not provided and cannot be automatically determined from LM file (only "
-                "arpa format). Decoding accuracy might be reduced."
-            )
+    model = NgramModel(kenlm_model_path) if kenlm_model_path is not None else None
+    if unigrams is None and from_arpa:
+        unigrams = load_unigram_set_from_arpa(kenlm_model_path)
+    elif unigrams is None and model is not None:
+        logger.warning("Unigrams not provided and cannot be automatically determined from LM file (only "
+                       "arpa format). Decoding accuracy might be reduced.")
     alphabet = Alphabet.build_alphabet(labels)
     if unigrams is not None:
         verify_alphabet_coverage(alphabet, unigrams)
-    if kenlm_model is not None:
-        language_model: Optional[AbstractLanguageModel] = LanguageModel(
-            kenlm_model,
-            unigrams,
-            alpha=alpha,
-            beta=beta,
-            unk_score_offset=unk_score_offset,
-            score_boundary=lm_score_boundary,
-        )
-    else:
-        language_model = None
-    return BeamSearchDecoderCTC(alphabet, language_model)
+    if model is None:
+        return BeamSearchDecoderCTC(alphabet, None)
+    lm = LanguageModel(model, unigrams, alpha=alpha, beta=beta, unk_score_offset=unk_score_offset,
+                       score_boundary=lm_score_boundary)
+    return BeamSearchDecoderCTC(alphabet, lm)
