@@ -95,6 +95,58 @@ def test_sharded_decode_world2(tmp_path, n_items):
         assert got["blobs"] == [b"\x00", b"\x01\x01"]
 
 
+def _real_worker(rank, world, port, out_dir):
+    """The REAL decoder (Python shell + C ABI + both beam kernels' source, on the CPU simulator backend) in every rank."""
+    import synth
+    from pyctcdecode_amd import _binding as B
+    from pyctcdecode_amd import build_ctcdecoder
+    from tests.golden_util import LM_DIR
+    from tests.sim.build_sim import build
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B._LIB = B.Library(build())
+        lm = synth.SynthLM(LM_DIR, 300, 400, order=4, seed=2)
+        labels = synth.LIBRI_LABELS
+        dec = build_ctcdecoder(labels, lm.path)
+        # every rank holds the whole batch (ragged lengths) and decodes only its shard
+        xs = [synth.d_words(2, u, 40 + 13 * (u % 4), labels, False, lm.words, lm.sentences, 28, boost=6.0) for u in range(7)]
+        hot = lm.hotwords(3, 1)
+        texts = decode_batch_sharded(dec, xs, beam_width=25, hotwords=hot)
+        beams = decode_beams_batch_sharded(dec, xs, beam_width=25, hotwords=hot)
+        balanced = decode_batch_sharded(dec, xs[::-1], beam_width=25, hotwords=hot)[::-1]  # (another frame balance)
+        with open(os.path.join(out_dir, "real%d.txt" % rank), "w") as f:
+            f.write(repr({"texts": texts, "balanced": balanced,
+                          "beams": [[(b.text, b.text_frames, b.logit_score, b.lm_score) for b in bl] for bl in beams]}))
+        if rank == 0:  # the unsharded result, from the same process
+            whole = dec.decode_batch(None, xs, beam_width=25, hotwords=hot)
+            whole_beams = dec.decode_beams_batch(None, xs, beam_width=25, hotwords=hot)
+            with open(os.path.join(out_dir, "whole.txt"), "w") as f:
+                f.write(repr({"texts": whole,
+                              "beams": [[(b.text, b.text_frames, b.logit_score, b.lm_score) for b in bl] for bl in whole_beams]}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_decoder_sharded_over_two_ranks_equals_the_unsharded_decode(tmp_path):
+    """decode_batch_sharded / decode_beams_batch_sharded with the real decoder (simulator backend) in two gloo ranks:
+    every rank ends up with the whole batch's results, equal to one unsharded decode_batch (decoder.py:856, 944)."""
+    from tests.sim.build_sim import build
+
+    build()  # (once, before the ranks race for it)
+    world = 2
+    mp.spawn(_real_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    whole = eval(open(tmp_path / "whole.txt").read())  # noqa: S307 (our own repr)
+    assert len(whole["texts"]) == 7 and any(whole["texts"])
+    for r in range(world):
+        got = eval(open(tmp_path / ("real%d.txt" % r)).read())  # noqa: S307
+        assert got["texts"] == whole["texts"]
+        assert got["balanced"] == whole["texts"]
+        assert got["beams"] == whole["beams"]
+
+
 def test_shard_bounds_cover_everything():
     for n in range(0, 40):
         for w in (1, 2, 3, 8):

@@ -278,8 +278,23 @@ def test_hip_bench_n_gt_1_path_rehearsed_on_one_gpu():
                              timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads(out.stdout.strip().splitlines()[-1])
-        assert line["n_gpus"] == 1 and line["scaling"] == scaling and line["value"] > 0
+        assert line["n_gpus"] == 1 and line["scaling"] == scaling and line["value"] > 0  # n_gpus = what the process group reports
         assert "RCCL all_gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
+    # `--gpus 2` on a box with one GPU must fail loudly, not fall back to one rank
+    import torch
+
+    if torch.cuda.device_count() == 1:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CTC_BENCH_FORCE_DIST")}
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "64", "--frames", "100",
+                              "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-shard", "--no-peaky"],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode != 0
+        assert "GPU(s) visible" in (out.stderr + out.stdout)
+        # ... and a WORLD_SIZE that contradicts --gpus is refused too
+        env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--batch", "64", "--frames", "100"],
+                             env=env2, capture_output=True, text=True, timeout=600)
+        assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
 
 
 def test_more_carried_beams_than_the_wave_table_holds(sim_library, monkeypatch):  # noqa: F811
