@@ -44,3 +44,9 @@ def pytest_terminal_summary(terminalreporter):
             "parity: %d beam lists / %d beams compared; largest |score - reference| = %.3g (%s); near-tie window used for "
             "%d runs (%d beams)" % (STATS["beam_lists"], STATS["beams"], STATS["max_gap"], STATS["max_gap_what"],
                                     STATS["tie_runs"], STATS["tie_run_beams"]))
+        terminalreporter.write_line(
+            "strict order: %d of %d beam lists differ from the reference's order (%d of %d runs of EXACTLY equal reference "
+            "scores permuted, %d runs of scores within the tie window but not equal)%s" % (
+                STATS["lists_order_differs"], STATS["beam_lists"], STATS["exact_tie_runs_permuted"], STATS["exact_tie_runs"],
+                STATS["near_tie_runs_permuted"],
+                (": " + ", ".join(STATS["lists_order_differs_what"])) if STATS["lists_order_differs_what"] else ""))

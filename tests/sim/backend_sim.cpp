@@ -113,8 +113,9 @@ int launch_prune(const PruneArgs& a, std::string*) {
         double mx = -INFINITY;
         for (int v = 0; v < V; ++v) mx = fmax(mx, load(x, a.dtype, (size_t)t * V + v));
         if (!isfinite(mx)) mx = 0.0;
-        double se = 0.0;
-        for (int v = 0; v < V; ++v) se += exp(load(x, a.dtype, (size_t)t * V + v) - mx);
+        // the normaliser in numpy's own summation order (np.sum is pairwise: np_sum.h), so that for float64 input a frame's
+        // log-probabilities are the reference's bit for bit wherever exp() rounds like numpy's
+        const double se = np_pairwise<double>([&](int64_t v) { return exp(load(x, a.dtype, (size_t)t * V + (size_t)v) - mx); }, (int64_t)V);
         double lse = log(se);
         for (int v = 0; v < V; ++v) {
           double y = (load(x, a.dtype, (size_t)t * V + v) - mx) - lse;

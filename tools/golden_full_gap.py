@@ -1,5 +1,5 @@
 """Diagnostics (GPU box): largest |score - reference score| of the HIP build over the full-size golden cases, per input dtype
-(tests/golden/cases_full.json; the tests bound it at 1e-4).  python tools/golden_full_gap.py"""
+(tests/golden/cases_full.json.gz; the tests bound it at 1e-4).  python tools/golden_full_gap.py"""
 import os
 import sys
 
