@@ -34,7 +34,7 @@ enum ctcdec_status {
   CTCDEC_ERR_INTERNAL = -5
 };
 
-enum ctcdec_dtype { CTCDEC_F32 = 0, CTCDEC_F64 = 1, CTCDEC_F16 = 2, CTCDEC_BF16 = 3 };  /* 16-bit: device pointers only */
+enum ctcdec_dtype { CTCDEC_F32 = 0, CTCDEC_F64 = 1, CTCDEC_F16 = 2, CTCDEC_BF16 = 3 };  /* host or device pointers alike (host float16 matrices are staged as they are) */
 
 /* Maximum supported values (checked; CTCDEC_ERR_LIMIT otherwise). */
 #define CTCDEC_MAX_BEAM_WIDTH 256

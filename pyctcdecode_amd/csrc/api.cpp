@@ -263,6 +263,7 @@ struct ctcdec_stream {
   uint64_t emit_cap = 0;  // emission nodes per stream
   std::vector<StreamState> mirror;
   std::vector<int64_t> frames;  // frames pushed so far
+  int64_t pushes = 0;           // chunks pushed since the streams' last start (each may close a word: one more chain entry)
   std::vector<ctcdec_lm_state> start_states;  // n * K, or empty: the models' defaults
   // the caller's beams of the last ctcdec_stream_import: roots (BR_IMPORT) of the chains decoded since
   bool has_import = false;
@@ -843,10 +844,14 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   int n_best = p->n_best > 0 ? std::min(p->n_best, B) : B;
   // emission lists: at most one entry per frame plus the import root and the closing entry
   unsigned long long tok_cap = (unsigned long long)n_best * (unsigned long long)(R + 2 * (int64_t)n_utts);
-  if (rs) {  // a resident stream's lists reach back to its start (one entry per emission node at most)
-    unsigned long long hist = 0;
-    for (int32_t u = 0; u < n_utts; ++u) hist += rs->mirror[(size_t)u].emit_next;
-    tok_cap = want_result ? (unsigned long long)n_best * (hist + (unsigned long long)(R + 2 * (int64_t)n_utts)) : 1ull;
+  if (rs) {
+    // A resident stream's lists reach back to its start, but a beam's chain holds at most one entry per frame pushed so
+    // far, one per chunk (a word closed by force_next_word) and its root -- NOT the stream's whole emission arena (every
+    // beam's nodes: ten minutes of audio on 64 streams would ask for gigabytes here; round-3 advisor finding).
+    unsigned long long depth = 0;
+    for (int32_t u = 0; u < n_utts; ++u)
+      depth += (unsigned long long)(rs->frames[(size_t)u] + utt_frames[u] + rs->pushes + 3);
+    tok_cap = want_result ? (unsigned long long)n_best * depth : 1ull;
   }
   // streaming: carried-over beams of every stream
   const ImportBeam* d_imports = nullptr;
@@ -869,15 +874,21 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       if (grown.ensure((size_t)n_utts * cap * sizeof(EmitNode), &err)) return fail(CTCDEC_ERR_DEVICE, err);
       for (int32_t u = 0; u < n_utts && rs->emit.p; ++u) {
         const size_t used = (size_t)rs->mirror[(size_t)u].emit_next * sizeof(EmitNode);
-        if (used && be::d2d((char*)grown.p + (size_t)u * cap * sizeof(EmitNode), (const char*)rs->emit.p + (size_t)u * rs->emit_cap * sizeof(EmitNode), used, &err))
+        if (used && be::d2d((char*)grown.p + (size_t)u * cap * sizeof(EmitNode), (const char*)rs->emit.p + (size_t)u * rs->emit_cap * sizeof(EmitNode), used, &err)) {
+          grown.drop();  // (the stream keeps its old arena)
           return fail(CTCDEC_ERR_DEVICE, err);
+        }
+      }
+      // the new offsets first: a failure here leaves the stream on its old arena with its old stride
+      std::vector<uint64_t> eo((size_t)n_utts + 1);
+      for (int32_t u = 0; u <= n_utts; ++u) eo[(size_t)u] = (uint64_t)u * cap;
+      if (upload(rs->eoff, eo, &err)) {
+        grown.drop();
+        return fail(CTCDEC_ERR_DEVICE, err);
       }
       rs->emit.drop();
       rs->emit = grown;
       rs->emit_cap = cap;
-      std::vector<uint64_t> eo((size_t)n_utts + 1);
-      for (int32_t u = 0; u <= n_utts; ++u) eo[(size_t)u] = (uint64_t)u * cap;
-      if (upload(rs->eoff, eo, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
   } else if (stream) {
     const int64_t n_imp_total = stream->beam_off[n_utts];
@@ -1155,6 +1166,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   if (rs) {  // the streams have moved on, whatever the chunk's outcome: refresh the mirrors first
     if (be::d2h(rs->mirror.data(), rs->sstate.p, (size_t)n_utts * sizeof(StreamState), &err)) return fail(CTCDEC_ERR_DEVICE, err);
     for (int32_t u = 0; u < n_utts; ++u) rs->frames[(size_t)u] += utt_frames[u];
+    rs->pushes += 1;
     if (stream->eos) {  // decoder.py:681-728 with is_end: the next chunk starts a new utterance
       for (auto& m : rs->mirror) {
         m.n_carry = 0;
@@ -1164,6 +1176,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       if (be::h2d(rs->sstate.p, rs->mirror.data(), (size_t)n_utts * sizeof(StreamState), &err)) return fail(CTCDEC_ERR_DEVICE, err);
       rs->has_import = false;
       std::fill(rs->frames.begin(), rs->frames.end(), 0);
+      rs->pushes = 0;
     }
   }
   for (int32_t u = 0; u < n_utts; ++u)

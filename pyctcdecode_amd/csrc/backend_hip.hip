@@ -249,13 +249,17 @@ __global__ __launch_bounds__(256) void utt_sniff_exact(PruneArgs a) {
 }
 
 // per-wave LDS work area of the prune kernels
+constexpr int NP_LEAVES = 64;  // leaves (<= 128 elements each) of numpy's pairwise sum a wave handles: rows up to ~3600 labels
 struct PruneLds {
   double* asc_lp;
   uint16_t *asc_id, *order, *tabA, *tabR, *scratch;
+  double* np_sum;     // [NP_LEAVES + 16] leaf sums, then the combining stack (float64 rows: np_order_exp_sum)
+  uint16_t* np_tab;   // [2 * NP_LEAVES + 48] leaf offsets, leaf lengths, two 16-entry stacks, the leaf count
 };
+constexpr size_t NP_LDS_BYTES = (NP_LEAVES + 16) * 8 + (((2 * NP_LEAVES + 48) * 2 + 15) & ~(size_t)15);
 __host__ __device__ inline size_t prune_lds_bytes(size_t ms, size_t cap) {
   return (((ms + 1) * 8 + 15) & ~(size_t)15) + (((ms + 2) * 2 * 2 + 15) & ~(size_t)15) +
-         ((cap * 2 * 3 + 15) & ~(size_t)15);
+         ((cap * 2 * 3 + 15) & ~(size_t)15) + NP_LDS_BYTES;
 }
 __device__ __forceinline__ PruneLds prune_lds(char* smem, int wave, uint32_t ms, uint32_t cap) {
   char* base = smem + prune_lds_bytes(ms, cap) * wave;
@@ -266,6 +270,8 @@ __device__ __forceinline__ PruneLds prune_lds(char* smem, int wave, uint32_t ms,
   w.tabA = (uint16_t*)((char*)w.asc_id + (((size_t)(ms + 2) * 2 * 2 + 15) & ~(size_t)15));
   w.tabR = w.tabA + cap;
   w.scratch = w.tabR + cap;
+  w.np_sum = (double*)(base + prune_lds_bytes(ms, cap) - NP_LDS_BYTES);
+  w.np_tab = (uint16_t*)(w.np_sum + NP_LEAVES + 16);
   return w;
 }
 
@@ -471,6 +477,122 @@ __device__ __forceinline__ double to_logp(double xv, bool is_prob, double mx, do
   return y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
 }
 
+// float64 rows: sum_v exp(x[v] - m) in the order numpy's np.sum adds a contiguous float64 row (pairwise: np_sum.h), by one
+// wave. The reference's log-softmax (decoder.py:180-197) is x - max - log(np.sum(np.exp(x - max))): with the normaliser
+// summed in this order a frame's log-probabilities are the reference's own bit for bit wherever exp / log round like
+// numpy's, and with them the order inside runs of equal scores (tests/test_order_stability.py). Leaves of the recursion
+// (<= 128 elements: eight strided accumulators, then the leftovers) go to groups of eight lanes, eight leaves at a time;
+// lane 0 lists them first and combines their sums last, both by walking the recursion with a small stack in LDS.
+// Returns false for rows of more than NP_LEAVES leaves (the caller then sums in lane order: same value to ~1 ulp).
+__device__ __forceinline__ bool np_order_exp_sum(const double* x, int V, double m, int lane, const PruneLds& w, double* out) {
+  uint16_t* leaf_off = w.np_tab;
+  uint16_t* leaf_len = w.np_tab + NP_LEAVES;
+  uint16_t* stk_n = w.np_tab + 2 * NP_LEAVES;
+  uint16_t* stk_s = stk_n + 16;
+  uint16_t* n_leaf = stk_s + 16;
+  if (lane == 0) {  // the leaves, left to right
+    int sp = 0, k = 0;
+    stk_s[0] = 0;
+    stk_n[0] = (uint16_t)V;  // (V <= 65535: label ids are 16 bits wide)
+    sp = 1;
+    while (sp > 0 && k <= NP_LEAVES) {
+      --sp;
+      const int off = stk_s[sp], n = stk_n[sp];
+      if (n <= 128) {
+        if (k < NP_LEAVES) {
+          leaf_off[k] = (uint16_t)off;
+          leaf_len[k] = (uint16_t)n;
+        }
+        ++k;
+      } else if (sp + 2 <= 16) {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        stk_s[sp] = (uint16_t)(off + n2);  // right half below the left one: the left is listed first
+        stk_n[sp] = (uint16_t)(n - n2);
+        stk_s[sp + 1] = (uint16_t)off;
+        stk_n[sp + 1] = (uint16_t)n2;
+        sp += 2;
+      } else {
+        k = NP_LEAVES + 1;
+      }
+    }
+    *n_leaf = (uint16_t)k;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nl = *n_leaf;
+  if (nl > NP_LEAVES) return false;
+  const int g = lane >> 3, j = lane & 7;
+  for (int base = 0; base < nl; base += 8) {
+    const int k = base + g;
+    const bool mine = k < nl;
+    const int off = mine ? leaf_off[k] : 0, n = mine ? leaf_len[k] : 0;
+    double res = 0.0;
+    if (n < 8) {
+      for (int i = 0; i < n; ++i) res = res + exp(x[off + i] - m);
+    } else {
+      double r = exp(x[off + j] - m);
+      const int body = n - (n % 8);
+      for (int i = 8; i < body; i += 8) r = r + exp(x[off + i + j] - m);
+      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): additions commute, so an xor butterfly inside the group is that very tree
+      r = r + __shfl_xor(r, 1, 64);
+      r = r + __shfl_xor(r, 2, 64);
+      r = r + __shfl_xor(r, 4, 64);
+      res = r;
+      for (int i = body; i < n; ++i) res = res + exp(x[off + i] - m);
+    }
+    if (mine && j == 0) w.np_sum[k] = res;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {  // pairwise(a, n2) + pairwise(a + n2, n - n2), all the way up
+    double* acc = w.np_sum + NP_LEAVES;
+    uint16_t* stk_st = stk_s;
+    int sp = 1, k = 0;
+    stk_n[0] = (uint16_t)V;
+    stk_st[0] = 0;
+    double ret = 0.0;
+    while (sp > 0) {
+      const int n = stk_n[sp - 1], st = stk_st[sp - 1];
+      if (n <= 128) {
+        ret = w.np_sum[k++];
+        --sp;
+        continue;
+      }
+      int n2 = n / 2;
+      n2 -= n2 % 8;
+      if (st == 0) {
+        stk_st[sp - 1] = 1;
+        stk_n[sp] = (uint16_t)n2;
+        stk_st[sp] = 0;
+        ++sp;
+      } else if (st == 1) {
+        acc[sp - 1] = ret;
+        stk_st[sp - 1] = 2;
+        stk_n[sp] = (uint16_t)(n - n2);
+        stk_st[sp] = 0;
+        ++sp;
+      } else {
+        ret = acc[sp - 1] + ret;
+        --sp;
+      }
+    }
+    w.np_sum[0] = ret;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  *out = w.np_sum[0];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return true;
+}
+template <typename T>
+__device__ __forceinline__ bool np_order_exp_sum_t(const T*, int, double, int, const PruneLds&, double*) { return false; }
+template <>
+__device__ __forceinline__ bool np_order_exp_sum_t<double>(const double* x, int V, double m, int lane, const PruneLds& w, double* out) {
+  return np_order_exp_sum(x, V, m, lane, w, out);
+}
+
 // Generic frame-prune: one wave per frame row, any V / dtype; the row is swept three times (max and
 // row sum, sum of exponentials, selection) and stays in L1/L2 between sweeps.
 // pass 0: every utterance is treated as logits (the overwhelmingly common case) and the row sums for the
@@ -496,8 +618,10 @@ __device__ __forceinline__ void prune_row_generic(const PruneArgs& a, int64_t ro
     if (lane == 0) a.row_sum[row] = rs;
     if (!isfinite(m)) m = 0.0;  // decoder.py:186-189
     double s = 0.0;
-    for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
-    s = wave_sum(s);
+    if (!np_order_exp_sum_t<T>(x, V, m, lane, w, &s)) {  // (float64 rows: numpy's own summation order)
+      for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
+      s = wave_sum(s);
+    }
     mx = m;
     lse = log(s);
   }

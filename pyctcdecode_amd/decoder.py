@@ -103,6 +103,15 @@ NULL_FRAMES: Frames = (-1, -1)
 EMPTY_START_BEAM = Beam("", "", "", None, [], NULL_FRAMES, 0.0)
 
 
+def _same_lm_state(a: Any, b: Any) -> bool:
+    """Equality of two language-model states by value (one model's, or one per model of a MultiLanguageModel)."""
+    if type(a) is not type(b):
+        return False
+    if hasattr(a, "states"):
+        return len(a.states) == len(b.states) and all(_same_lm_state(x, y) for x, y in zip(a.states, b.states))
+    return getattr(a, "state", a) == getattr(b, "state", b)
+
+
 def _is_device_tensor(x: Any) -> bool:
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
@@ -438,7 +447,10 @@ class _DeviceStreams:
 
 class _ResidentBeams(list):
     """The LMBeams of one stream after a chunk, still on the device: an ordinary list that fills itself the first time it
-    is looked at. Handed back unchanged to partial_decode_beams(_batch) it is never filled at all."""
+    is looked at. Handed back unchanged to partial_decode_beams(_batch) it is never filled at all.
+    Caveat: code that reads a list through the C API without calling a method (PySequence_Fast / PyList_GET_SIZE on a
+    subclass: the C json encoder, some extension modules) sees the unfilled storage -- pass list(beams) to such code.
+    Pickling and copying go through __reduce__ and yield a plain, filled list."""
 
     def __init__(self, streams: _DeviceStreams, index: int, gen: int):
         super().__init__()
@@ -462,6 +474,11 @@ class _ResidentBeams(list):
 
     def _current(self) -> bool:
         return not self._edited and self._gen == self._streams.gen
+
+    def __reduce__(self):
+        # pickle / copy / multiprocessing: as the plain list of its beams (the device handle stays behind)
+        self._fill()
+        return (list, (list(list.__iter__(self)),))
 
     def _fill(self) -> None:
         if self._filled:
@@ -996,8 +1013,9 @@ class BeamSearchDecoderCTC:
                 all(isinstance(b, _ResidentBeams) and b._streams is first._streams and b._index == u and b._current()
                     for u, b in enumerate(beams_list))):
             streams = first._streams  # handed back unchanged: nothing to import
-        elif all(len(b) == 1 and b[0] == EMPTY_START_BEAM for b in beams_list):
-            streams = _DeviceStreams(self, n)  # the reference's starting state
+        elif (all(len(b) == 1 and b[0] == EMPTY_START_BEAM for b in beams_list) and
+              all(self._memo_starts_at_default(m) for m in cached_lm_scores_list)):
+            streams = _DeviceStreams(self, n)  # the reference's starting state: the model's own start state, nothing scored
         else:
             # built or edited by the caller (or fed to another call in between): the host resolves their strings
             streams = _DeviceStreams(self, n)
@@ -1011,6 +1029,11 @@ class BeamSearchDecoderCTC:
         first_frames = (C.c_int32 * n)(*[int(p) for p in processed_frames_list])
         want = bool(is_end) or not lazy_ok
         res = C.c_void_p()
+        if not 0 < params.beam_width <= 256:
+            # (refused by the library before anything runs: the lists of the previous chunk must stay readable)
+            self._lib.check(self._lib.dll.ctcdec_stream_push(
+                streams.handle, ptrs, frames, batch.dtype, int(batch.is_device), C.byref(params), first_frames,
+                int(bool(force_next_word)), int(bool(is_end)), int(want), C.byref(res)))
         streams.retire_lists()
         self._lib.check(self._lib.dll.ctcdec_stream_push(
             streams.handle, ptrs, frames, batch.dtype, int(batch.is_device), C.byref(params), first_frames,
@@ -1024,6 +1047,23 @@ class BeamSearchDecoderCTC:
             if res:
                 self._lib.dll.ctcdec_result_free(res)
         return streams.lazy_lists()
+
+    def _memo_starts_at_default(self, memo: Dict[Any, Any]) -> bool:
+        """Is the memo's entry for the empty text what get_starting_state() puts there -- (0, 0, the model's start state)?
+        The reference scores a stream's first word from THAT entry's state (decoder.py:387-396): a caller that seeds it with
+        the last_lm_state of a previous segment must not be decoded from the beginning of a sentence (such streams take the
+        import path, which reads the entry)."""
+        lm = self._language_model
+        if lm is None:
+            return True
+        entry = memo.get(("", False)) if hasattr(memo, "get") else None
+        if entry is None:
+            return True
+        try:
+            lm_hw, raw, state = entry
+        except (TypeError, ValueError):
+            return False
+        return lm_hw == 0.0 and raw == 0.0 and _same_lm_state(state, lm.get_start_state())
 
     def partial_decode_beams(
         self,

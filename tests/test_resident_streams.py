@@ -213,6 +213,51 @@ def test_plain_lists_on_request(sim_library, monkeypatch):  # noqa: F811
     assert first[0].text is not None and second[0].text == dec.decode_beams(x)[0].text
 
 
+def test_stream_seeded_with_the_lm_state_of_a_previous_segment(sim_library, both_beam_kernels):  # noqa: F811
+    """A caller that starts a stream from get_starting_state() but puts the last_lm_state of an earlier segment into the
+    memo's entry for the empty text (what decode_beams(lm_start_state=...) does, decoder.py:640-651) must be decoded from
+    THAT state, not from the beginning of a sentence (round-3 advisor finding: the starting-state fast path ignored it)."""
+    labels = synth.LIBRI_LABELS
+    dec = _build()(labels, LM.path)
+    x1 = synth.d_words(2, 3, 60, labels, False, LM.words, LM.sentences, 28, boost=6.0).astype(np.float64)
+    x2 = synth.d_words(2, 4, 60, labels, False, LM.words, LM.sentences, 28, boost=6.0).astype(np.float64)
+    state = dec.decode_beams(x1)[0].last_lm_state
+    want = dec.decode_beams(x2, lm_start_state=state)
+    cold = dec.decode_beams(x2)
+    assert [w.lm_score for w in want] != [c.lm_score for c in cold]  # (the seed matters on this input)
+    beams, c1, c2 = dec.get_starting_state()
+    c1[("", False)] = (0.0, 0.0, state)
+    got = dec.partial_decode_beams(x2, c1, c2, beams, 0, is_end=True)
+    assert [g.text for g in got] == [w.text for w in want]
+    assert all(abs(g.lm_score - w.lm_score) < 1e-9 and abs(g.logit_score - w.logit_score) < 1e-9 for g, w in zip(got, want))
+    # ... and an untouched starting state still takes the resident fast path
+    beams, c1, c2 = dec.get_starting_state()
+    assert dec._memo_starts_at_default(c1)
+    got = dec.partial_decode_beams(x2, c1, c2, beams, 0, is_end=True)
+    assert [g.text for g in got] == [c.text for c in cold]
+
+
+def test_lazy_lists_pickle_as_plain_lists_and_survive_a_refused_push(sim_library):  # noqa: F811
+    import copy
+    import pickle
+
+    from pyctcdecode_amd.decoder import _ResidentBeams
+
+    labels = synth.LIBRI_LABELS
+    dec = _build()(labels, LM.path)
+    x = synth.d_words(2, 6, 60, labels, False, LM.words, LM.sentences, 28, boost=6.0)
+    beams, c1, c2 = dec.get_starting_state()
+    lazy = dec.partial_decode_beams(x[:30], c1, c2, beams, 0)
+    assert isinstance(lazy, _ResidentBeams) and not lazy._filled
+    back = pickle.loads(pickle.dumps(lazy))
+    assert type(back) is list and len(back) > 0 and back == list(lazy) and copy.copy(lazy) == back
+    # a push the library refuses before anything runs leaves the previous chunk's (unread) lists readable
+    lazy2 = dec.partial_decode_beams(x[30:45], c1, c2, lazy, 30)
+    with pytest.raises(Exception):
+        dec.partial_decode_beams(x[45:], c1, c2, lazy2, 45, beam_width=300)
+    assert len(lazy2) > 0 and lazy2[0].text is not None
+
+
 def test_multi_lm_streams_are_resident_too(sim_library):  # noqa: F811
     """Two language models (the workgroup kernel): the states of model 1.. ride along on the device."""
     from tests import test_multi_lm as M
