@@ -157,5 +157,5 @@ def test_hip_base_score_and_decode_against_hand_derived_answers(both_beam_kernel
     from pyctcdecode_amd import _binding as B
     from pyctcdecode_amd import build_ctcdecoder
 
-    _check_native(B.lib())
+    _check_native(B.get_library())
     _check_decodes(build_ctcdecoder, lambda x: torch.from_numpy(x).cuda())
