@@ -227,6 +227,59 @@ struct WaveDecoder {
   CTC_HD const DeviceTables& tab() const { return ctx.tables(); }
   CTC_HD const DecodeParams& prm() const { return ctx.params(); }
 
+  // ---- text nodes -------------------------------------------------------------------------------
+  // One node per completed-words prefix (the reference's memo entry, decoder.py:387-396): the raw LM score sum, the
+  // hot-word count, the LM state and the ring of the last n_hist word hashes. This kernel keeps them in its own compact
+  // layout in the utterance's node arena: with at most three context words (models up to order 4: ORD = 4) a node is 64
+  // bytes -- four 16-byte chunks to read and four to write per completed word; longer contexts take 96 of a 128-byte slot.
+  //   CTX = 3:  {raw_lm, hw_cnt, ring_cnt | len << 8} {w0, w1, w2, b0} {b1, b2, ring0} {ring1, ring2}
+  //   CTX = 5:  {raw_lm, hw_cnt, ring_cnt | len << 8} {w0..w3} {w4, b0, b1, b2} {b3, b4, ring0} {ring1, ring2} {ring3, ring4}
+  static constexpr int CTX = (ORD - 1 < 3) ? 3 : (ORD - 1 > MAX_CTX ? MAX_CTX : (ORD - 1 <= 3 ? 3 : MAX_CTX));
+  static constexpr int NODE_BYTES = CTX <= 3 ? 64 : 128;
+  struct Node {
+    double raw;
+    uint32_t hw_cnt, ring_cnt;
+    LmState st;
+    uint64_t ring[MAX_CTX];
+  };
+  CTC_HD u32x4a* node_ptr(uint32_t idx) const { return (u32x4a*)((char*)io.text_nodes + (size_t)idx * (size_t)NODE_BYTES); }
+  CTC_HD void node_load(uint32_t idx, Node& n) const {
+    const u32x4a* p = node_ptr(idx);
+    const u32x4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+    n.raw = bits_f64(q_lo(c0));
+    n.hw_cnt = c0[2];
+    n.ring_cnt = c0[3] & 0xFFu;
+    n.st.len = (int32_t)(c0[3] >> 8);
+    if (CTX <= 3) {
+      n.st.words[0] = c1[0]; n.st.words[1] = c1[1]; n.st.words[2] = c1[2]; n.st.words[3] = 0; n.st.words[4] = 0;
+      n.st.backoff[0] = bits_f32(c1[3]); n.st.backoff[1] = bits_f32(c2[0]); n.st.backoff[2] = bits_f32(c2[1]);
+      n.st.backoff[3] = 0.f; n.st.backoff[4] = 0.f;
+      n.ring[0] = q_hi(c2); n.ring[1] = q_lo(c3); n.ring[2] = q_hi(c3); n.ring[3] = 0; n.ring[4] = 0;
+    } else {
+      const u32x4 c4 = p[4], c5 = p[5];
+      n.st.words[0] = c1[0]; n.st.words[1] = c1[1]; n.st.words[2] = c1[2]; n.st.words[3] = c1[3]; n.st.words[4] = c2[0];
+      n.st.backoff[0] = bits_f32(c2[1]); n.st.backoff[1] = bits_f32(c2[2]); n.st.backoff[2] = bits_f32(c2[3]);
+      n.st.backoff[3] = bits_f32(c3[0]); n.st.backoff[4] = bits_f32(c3[1]);
+      n.ring[0] = q_hi(c3); n.ring[1] = q_lo(c4); n.ring[2] = q_hi(c4); n.ring[3] = q_lo(c5); n.ring[4] = q_hi(c5);
+    }
+  }
+  CTC_HD void node_store(uint32_t idx, const Node& n) const {
+    u32x4a* p = node_ptr(idx);
+    const uint64_t rb = f64_bits(n.raw);
+    p[0] = mk4((uint32_t)rb, (uint32_t)(rb >> 32), n.hw_cnt, (n.ring_cnt & 0xFFu) | ((uint32_t)n.st.len << 8));
+    if (CTX <= 3) {
+      p[1] = mk4(n.st.words[0], n.st.words[1], n.st.words[2], f32_bits(n.st.backoff[0]));
+      p[2] = mk4(f32_bits(n.st.backoff[1]), f32_bits(n.st.backoff[2]), (uint32_t)n.ring[0], (uint32_t)(n.ring[0] >> 32));
+      p[3] = mk4q(n.ring[1], n.ring[2]);
+    } else {
+      p[1] = mk4(n.st.words[0], n.st.words[1], n.st.words[2], n.st.words[3]);
+      p[2] = mk4(n.st.words[4], f32_bits(n.st.backoff[0]), f32_bits(n.st.backoff[1]), f32_bits(n.st.backoff[2]));
+      p[3] = mk4(f32_bits(n.st.backoff[3]), f32_bits(n.st.backoff[4]), (uint32_t)n.ring[0], (uint32_t)(n.ring[0] >> 32));
+      p[4] = mk4q(n.ring[1], n.ring[2]);
+      p[5] = mk4q(n.ring[3], n.ring[4]);
+    }
+  }
+
   template <int PHASE>
   CTC_HD void tick() {
     if (io.prof && lane == 0) {
@@ -358,54 +411,32 @@ CTC_UNROLL
       const u32x4 k2 = L.hC[i];
       const uint32_t wid = k2[3], m2 = k1[3];
       const u32x4 k0 = L.hA[i];
-      const uint64_t text = q_lo(k0), part_h = q_hi(k0);
-      // TextNode as 16-byte chunks: 0 text_h, raw_lm | 2 hw_cnt, ring_cnt, state.len, words[0] | 3 words[1..4]
-      // | 4 backoff[0..3] | 5 backoff[4], pad, ring[0] | 6 ring[1], ring[2] | 7 ring[3], ring[4]
-      const TextNode& sn = io.text_nodes[k2[2]];
-      const u32x4a* src = (const u32x4a*)&sn;
-      double raw = sn.raw_lm;
-      const u32x4 c2 = src[2], c3 = src[3], c4 = src[4], c5 = src[5], c6 = src[6];
-      const uint64_t ring3 = sn.ring[3];
-      LmState in, out;
-      in.len = (int32_t)c2[2];
-      in.words[0] = c2[3];
-      in.words[1] = c3[0];
-      in.words[2] = c3[1];
-      in.words[3] = c3[2];
-      in.words[4] = c3[3];
-      in.backoff[0] = bits_f32(c4[0]);
-      in.backoff[1] = bits_f32(c4[1]);
-      in.backoff[2] = bits_f32(c4[2]);
-      in.backoff[3] = bits_f32(c4[3]);
-      in.backoff[4] = bits_f32(c5[0]);
-      out = in;
+      const uint64_t part_h = q_hi(k0);
+      Node sn;
+      node_load(k2[2], sn);
+      double raw = sn.raw;
+      LmState out = sn.st;
       if (T_.has_lm) {
-        const float base = lm_base_score<ORD>(T_, in, wid, &out);
+        const float base = lm_base_score<ORD>(T_, sn.st, wid, &out);
         raw = raw + lm_word_score(T_, P_, base, m2, 0.0, false);
       }
-      const uint32_t cnt = c2[0] + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
+      const uint32_t cnt = sn.hw_cnt + ((m2 & M2_HOT_COMPLETE) ? 1u : 0u);
       const double lmhw = raw + P_.hot_weight * (double)cnt;
-      const uint32_t rc0 = c2[1];
+      const uint32_t rc0 = sn.ring_cnt;
       const uint32_t rc = rc0 + 1 > T_.n_hist ? T_.n_hist : rc0 + 1;
-      // history ring, newest first: the closed word, then the source node's (its fifth entry always drops out)
-      const uint64_t old0 = pack64(c5[2], c5[3]), old1 = q_lo(c6), old2 = q_hi(c6), old3 = ring3;
-      uint64_t ring[MAX_CTX];
-      ring[0] = part_h;
-      ring[1] = 1u < rc ? old0 : 0ull;
-      ring[2] = 2u < rc ? old1 : 0ull;
-      ring[3] = 3u < rc ? old2 : 0ull;
-      ring[4] = 4u < rc ? old3 : 0ull;
-      const uint64_t hh = wave_hist_fold(ring, rc);
-      const uint64_t th = text_push(text, part_h);
-      u32x4a* dst = (u32x4a*)&io.text_nodes[idx];
-      dst[0] = mk4q(th, f64_bits(raw));
-      dst[1] = mk4q(f64_bits(lmhw), hh);
-      dst[2] = mk4(cnt, rc, (uint32_t)out.len, out.words[0]);
-      dst[3] = mk4(out.words[1], out.words[2], out.words[3], out.words[4]);
-      dst[4] = mk4(f32_bits(out.backoff[0]), f32_bits(out.backoff[1]), f32_bits(out.backoff[2]), f32_bits(out.backoff[3]));
-      dst[5] = mk4(f32_bits(out.backoff[4]), 0u, (uint32_t)ring[0], (uint32_t)(ring[0] >> 32));
-      dst[6] = mk4q(ring[1], ring[2]);
-      dst[7] = mk4q(ring[3], ring[4]);
+      // history ring, newest first: the closed word, then the source node's (its last entry drops out when the ring is full)
+      Node nn;
+      nn.raw = raw;
+      nn.hw_cnt = cnt;
+      nn.ring_cnt = rc;
+      nn.st = out;
+      nn.ring[0] = part_h;
+      nn.ring[1] = 1u < rc ? sn.ring[0] : 0ull;
+      nn.ring[2] = 2u < rc ? sn.ring[1] : 0ull;
+      nn.ring[3] = 3u < rc ? sn.ring[2] : 0ull;
+      nn.ring[4] = 4u < rc ? sn.ring[3] : 0ull;
+      const uint64_t hh = wave_hist_fold(nn.ring, rc);
+      node_store(idx, nn);
       ColdRec& cr = cold_cur()[i];
       cr.c_lmhw = lmhw;
       cr.c_hist_h = hh;
@@ -859,9 +890,9 @@ CTC_UNROLL
     if (T_.has_lm) {  // (uniform)
       const bool on_trie = T_.has_trie && (pf_flags & PF_UNI_PREFIX);
       s = P_.unk * (on_trie ? 0.0 : 1.0);
-      if (plen > 6) s = s * pl / 6.0;  // (the two fp64 divisions stay behind branches: ~15 instructions each)
+      s = plen > 6 ? div_by_6(s * pl) : s;
     }
-    if (hot_min_len > 0) s = P_.hot_weight * pl / (double)hot_min_len;
+    if (hot_min_len > 0) s = P_.hot_weight * pl / (double)hot_min_len;  // (a real division: behind a branch, ~30 instructions)
     return s;
   }
 
@@ -1518,15 +1549,11 @@ CTC_UNROLL
     par = 0;
     N = 1;
     if (lane == 0) {
-      TextNode root;
-      root.text_h = 0;
-      root.raw_lm = 0.0;
-      root.lm_hw = 0.0;
+      Node root;
+      root.raw = 0.0;
       root.hw_cnt = 0;
       root.ring_cnt = 0;
       for (int k = 0; k < MAX_CTX; ++k) root.ring[k] = 0;
-      root.hist_h = wave_hist_fold(root.ring, 0);
-      root.pad0 = 0;
       LmState st;
       st.len = 0;
       for (int k = 0; k < MAX_CTX; ++k) {
@@ -1534,15 +1561,17 @@ CTC_UNROLL
         st.backoff[k] = 0.f;
       }
       if (io.start_state && io.start_state->len >= 0) st = *io.start_state;
-      root.state = st;
-      io.text_nodes[0] = root;
+      if (st.len > CTX) st.len = CTX;  // (a state of a model of this order never holds more)
+      root.st = st;
+      node_store(0, root);
+      const uint64_t root_hist = wave_hist_fold(root.ring, 0);
       EmitNode er;
       er.parent = 0;
       er.tok_branch = 0;
       er.wstart = -1;
       er.wend = -1;
       io.emit_nodes[0] = er;
-      write_beam(0, 0, 0, 0.0, NO_CHAR, EMPTY_PARTIAL_M2, 0.0, 0.0, root.hist_h, 0, 0, 0, -1, -1, 0);
+      write_beam(0, 0, 0, 0.0, NO_CHAR, EMPTY_PARTIAL_M2, 0.0, 0.0, root_hist, 0, 0, 0, -1, -1, 0);
     }
     if (io.imports && io.n_import > 0) import_beams();
     ctx.mem_sync();
@@ -1560,24 +1589,21 @@ CTC_UNROLL
     for (int i = lane; i < n; i += 64) {
       const ImportBeam& m = io.imports[i];
       const uint32_t node = 1u + (uint32_t)i;  // node 0 is the empty text
-      TextNode& tn = io.text_nodes[node];
-      tn.text_h = m.text_h;
-      tn.raw_lm = m.raw_lm;
+      Node tn;
+      tn.raw = m.raw_lm;
       const double lmhw = m.raw_lm + P_.hot_weight * (double)m.hw_cnt;
-      tn.lm_hw = lmhw;
       const uint64_t hh = wave_hist_fold(m.ring, m.ring_cnt);
 CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) tn.ring[k] = m.ring[k];
-      tn.hist_h = hh;
       tn.hw_cnt = m.hw_cnt;
       tn.ring_cnt = m.ring_cnt;
-      tn.pad0 = 0;
-      tn.state.len = m.state.len;
+      tn.st.len = m.state.len > CTX ? CTX : m.state.len;
 CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) {
-        tn.state.words[k] = m.state.words[k];
-        tn.state.backoff[k] = m.state.backoff[k];
+        tn.st.words[k] = m.state.words[k];
+        tn.st.backoff[k] = m.state.backoff[k];
       }
+      node_store(node, tn);
       uint32_t enode = m.enode, depth = m.depth;
       if (host_built) {
         EmitNode en;
@@ -1676,16 +1702,11 @@ CTC_UNROLL
         const uint32_t pl = d1[2] >> 16;
         double lmhw;
         if (eos) {
-          const TextNode& src = io.text_nodes[d2[2]];
+          Node src;
+          node_load(d2[2], src);
           const uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
           if (tab().has_lm) {
-            LmState st, end;
-            st.len = src.state.len;
-CTC_UNROLL
-            for (int k = 0; k < MAX_CTX; ++k) {
-              st.words[k] = src.state.words[k];
-              st.backoff[k] = src.state.backoff[k];
-            }
+            LmState st = src.st, end;
             const uint32_t wid = pl > 0 ? d2[3] : 0u;
             const uint32_t wfl = pl > 0 ? m2 : 0u;
             const float base_s = lm_base_score<ORD>(tab(), st, wid, &end);
@@ -1694,7 +1715,7 @@ CTC_UNROLL
               LmState tmp;
               end_score = (double)lm_base_score<ORD>(tab(), end, tab().eos_id, &tmp);
             }
-            const double raw = src.raw_lm + lm_word_score(tab(), prm(), base_s, wfl, end_score, true);
+            const double raw = src.raw + lm_word_score(tab(), prm(), base_s, wfl, end_score, true);
             lmhw = raw + prm().hot_weight * (double)cnt;
           } else {
             lmhw = prm().hot_weight * (double)cnt;
@@ -1800,8 +1821,9 @@ CTC_UNROLL
       ob.pstart = fold ? -1 : cr.pstart;
       ob.pend = fold ? -1 : cr.pend;
       // the text's memo entry: raw LM sum and the state after its last word
-      const TextNode& node = io.text_nodes[closes ? cr.cnode : d2[2]];
-      ob.raw_lm = node.raw_lm;
+      Node node;
+      node_load(closes ? cr.cnode : d2[2], node);
+      ob.raw_lm = node.raw;
       if (!tab().has_lm) {
         ob.state.len = -1;
 CTC_UNROLL
@@ -1812,22 +1834,13 @@ CTC_UNROLL
       } else if (eos) {
         // last_lm_state: state after the last word, before </s> (language_model.py:357); an empty
         // last word is still scored as a word (decoder.py:387-395)
-        const TextNode& src = io.text_nodes[d2[2]];
-        LmState st;
-        st.len = src.state.len;
-CTC_UNROLL
-        for (int k = 0; k < MAX_CTX; ++k) {
-          st.words[k] = src.state.words[k];
-          st.backoff[k] = src.state.backoff[k];
-        }
-        lm_base_score<ORD>(tab(), st, pl > 0 ? d2[3] : 0u, &ob.state);
+        Node src;
+        node_load(d2[2], src);
+        LmState st = src.st, after;
+        lm_base_score<ORD>(tab(), st, pl > 0 ? d2[3] : 0u, &after);
+        ob.state = after;
       } else {
-        ob.state.len = node.state.len;
-CTC_UNROLL
-        for (int k = 0; k < MAX_CTX; ++k) {
-          ob.state.words[k] = node.state.words[k];
-          ob.state.backoff[k] = node.state.backoff[k];
-        }
+        ob.state = node.st;
       }
       if (tok_ok) {
         uint32_t pos = o + len[j];
@@ -1894,11 +1907,12 @@ CTC_UNROLL
         enode = e;
         depth += 1;
       }
-      const TextNode& node = io.text_nodes[closes ? cr.cnode : d2[2]];
+      Node node;
+      node_load(closes ? cr.cnode : d2[2], node);
       ImportBeam& m = io.carry_out[r];
       m.logit_score = lg;
-      m.raw_lm = node.raw_lm;
-      m.text_h = node.text_h;
+      m.raw_lm = node.raw;
+      m.text_h = closes ? text_push(q_lo(d0), q_hi(d0)) : q_lo(d0);  // (the text of the node: its hash is the beam's)
       m.part_h = fold ? 0ull : q_hi(d0);
 CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) m.ring[k] = node.ring[k];
@@ -1910,12 +1924,7 @@ CTC_UNROLL
       m.word_id = fold ? 0u : d2[3];
       m.pstart = fold ? -1 : cr.pstart;
       m.pend = fold ? -1 : cr.pend;
-      m.state.len = node.state.len;
-CTC_UNROLL
-      for (int k = 0; k < MAX_CTX; ++k) {
-        m.state.words[k] = node.state.words[k];
-        m.state.backoff[k] = node.state.backoff[k];
-      }
+      m.state = node.st;
       m.enode = enode;
       m.depth = depth;
       m.resident = 1u;

@@ -122,8 +122,9 @@ struct WaveGpuCtx {
 
 // Four waves per SIMD: 128 registers per lane (the allocator is told so: left alone it takes what it likes and halves the
 // residency) and, by wave_lds_bytes, at most 10 KB of LDS at beam_width <= 100 -- sixteen utterances per CU.
+// (beam_width 101 .. 128: 12.7 KB of LDS allow twelve waves per CU, three per SIMD: 168 registers)
 template <int BW, int ORD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void beam_wave(BeamArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BW <= 100 ? 4 : 3, BW <= 100 ? 4 : 3))) void beam_wave(BeamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   WaveLds view;

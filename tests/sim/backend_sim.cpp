@@ -185,8 +185,8 @@ static void fill_io(const BeamArgs& a, int u, UttIO& io) {
 }
 
 // one wavefront per utterance (beam_wave.h) on 64 cooperative fibers
-template <int BW>
-static void run_wave(const BeamArgs& a) {
+template <int BW, int ORD>
+static void run_wave_ord(const BeamArgs& a) {
   const size_t bytes = wave_lds_bytes<BW>();
   std::vector<char> lds(bytes + 64);
   char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);
@@ -200,10 +200,15 @@ static void run_wave(const BeamArgs& a) {
     wavesim::Wave wave;
     wave.run([&](int lane) {
       wavesim::SimWaveCtx ctx{lane, &wave, &a.tables, &a.params};
-      WaveDecoder<wavesim::SimWaveCtx, BW> dec(ctx, view, io);
+      WaveDecoder<wavesim::SimWaveCtx, BW, ORD> dec(ctx, view, io);
       dec.run();
     });
   }
+}
+template <int BW>
+static void run_wave(const BeamArgs& a) {  // (the instantiations of the HIP launcher: n-gram orders up to 4, or all)
+  if (!a.tables.has_lm || a.tables.lm_order <= 4) run_wave_ord<BW, 4>(a);
+  else run_wave_ord<BW, MAX_CTX + 1>(a);
 }
 
 static int g_last_kernel = 0;
