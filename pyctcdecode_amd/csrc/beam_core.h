@@ -336,7 +336,15 @@ CTC_HD double log_1_2(double x) {  // log x, 1 <= x <= 2 (the classic s = f / (2
   const bool big = x > 1.4142135623730951;
   const double m = big ? x * 0.5 : x, dk = big ? 1.0 : 0.0;
   const double f = m - 1.0;
-  const double s = f / (2.0 + f);
+  // s = f / (2 + f) without the division (~30 instructions): a single-precision reciprocal of the denominator (2 .. 2.42)
+  // refined by three Newton steps in double precision (24 -> 48 -> 96 bits), all explicit fma's -- the same bits on the
+  // device and in the simulator. s is within an ulp or two of the quotient; the series only needs it to about 2^-50.
+  const double den = 2.0 + f;
+  double r = (double)(1.0f / (float)den);
+  r = fma(fma(-den, r, 1.0), r, r);
+  r = fma(fma(-den, r, 1.0), r, r);
+  r = fma(fma(-den, r, 1.0), r, r);
+  const double s = f * r;
   const double z = s * s, w = z * z;
   const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
   const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),

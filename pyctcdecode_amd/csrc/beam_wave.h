@@ -744,6 +744,7 @@ CTC_UNROLL
       c.wd = *(closing_word ? &cr->c_lmhw : &cr->pscore);
       if (P_.prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
     }
+    // (a real finaliser: the hashes of one-character strings differ in their low bits only, and the match tag drops seven bits)
     c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
     c.lg = bits_f64(q_lo(k1)) + bits_f64(pack64(sv[2], sv[3]));
   }
@@ -959,8 +960,8 @@ CTC_UNROLL
     // (history, partial, last_char) folded to 64 bits (decoder.py:250-254): equality of the folds stands in
     // for equality of the triple (its members are 61/64-bit string hashes already)
     uint64_t hk = 0;
-    if (P_.prune_history) hk = fin64(c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40));
-    const u32x4 e0 = mk4q(score_sort_key(score), hk);
+    if (P_.prune_history) hk = c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40);  // (compared for equality only)
+    const u32x4 e0 = mk4q(~my_key, hk);  // (score_sort_key(score) == ~asc_key(score); lanes that push are representatives)
     const uint32_t blank = (c.mw >> 16) & TK_BLANK;
     const uint32_t arrival = c.ls * (uint32_t)N + c.bi;
     const uint32_t donor = imax | (c.lid << 8) | (blank ? (1u << 29) : 0u) | (dbr << 30);

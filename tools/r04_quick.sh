@@ -15,7 +15,7 @@ python - <<'PY'
 import json
 for t in ("sq1","sq2"):
     try:
-        d=json.load(open("gpurun_out/r04q/%s.json"%t))["kernels"]
+        d=json.load(open("gpurun_out/r04q/%s.json"%t))
     except Exception as e:
         print(t,"missing",e); continue
     for k,v in d.items():
