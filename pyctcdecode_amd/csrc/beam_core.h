@@ -311,54 +311,92 @@ CTC_HD double lse_bits_f64(uint64_t u) {
   c.u = u;
   return c.d;
 }
-CTC_HD double exp_m37_0(double d) {  // e^d, -37 <= d <= 0
-  const double kf = rint(d * 1.4426950408889634074);
-  double r = fma(-kf, 6.93147180369123816490e-01, d);
-  r = fma(-kf, 1.90821492927058770002e-10, r);  // |r| <= ln2 / 2
-  // e^r = 1 + r + r^2 q(r), Taylor to r^13 (truncation 4e-18)
-  double q = 1.0 / 6227020800.0;
-  q = fma(q, r, 1.0 / 479001600.0);
-  q = fma(q, r, 1.0 / 39916800.0);
-  q = fma(q, r, 1.0 / 3628800.0);
-  q = fma(q, r, 1.0 / 362880.0);
-  q = fma(q, r, 1.0 / 40320.0);
-  q = fma(q, r, 1.0 / 5040.0);
-  q = fma(q, r, 1.0 / 720.0);
-  q = fma(q, r, 1.0 / 120.0);
-  q = fma(q, r, 1.0 / 24.0);
-  q = fma(q, r, 1.0 / 6.0);
-  q = fma(q, r, 0.5);
-  const double p = fma(r * r, q, r) + 1.0;
-  const int64_t k = (int64_t)kf;  // >= -54: the scale is a normal number
-  return p * lse_bits_f64((uint64_t)(k + 1023) << 52);
+// The 24 double-precision constants of the two series. On the device they are READ (scalar loads from constant memory
+// behind an opaque copy of the table's address) instead of written into the code: an fp64 literal costs two v_mov per use
+// -- forty of the ~110 instructions of a merge -- and a scalar-register pair read by the fma costs none.
+struct LseTab {
+  double log2e, ln2_hi, ln2_lo, e13, e12, e11, e10, e9, e8, e7, e6, e5, e4, e3, e2;  // exp: 1/k!
+  double sqrt2, l6, l4, l2, l7, l5, l3, l1;                                           // log: Sun's Lg1 .. Lg7
+  double r0, r1, r2;  // 1 / x on [2, 1 + sqrt 2] to ~1e-3: r0 + (x - 2.2) (r1 + (x - 2.2) r2), the seed of three Newton steps
+};
+#define CTC_LSE_TAB_INIT                                                                                                    \
+  {1.4426950408889634074, 6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.0 / 6227020800.0, 1.0 / 479001600.0,      \
+   1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0,      \
+   1.0 / 6.0, 0.5, 1.4142135623730951, 1.531383769920937332e-01, 2.222219843214978396e-01, 3.999999999940941908e-01,         \
+   1.479819860511658591e-01, 1.818357216161805012e-01, 2.857142874366239149e-01, 6.666666666666735130e-01,                  \
+   1.0 / 2.2, -1.0 / (2.2 * 2.2), 1.0 / (2.2 * 2.2 * 2.2)}
+// a * b + c with c a CONSTANT of that table: the three-operand v_fma_f64 reads it straight from its scalar registers (left
+// to itself the compiler picks the two-operand v_fmac_f64, whose addend has to sit in the destination: two v_mov first)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CTC_SIM)
+__device__ __forceinline__ double fma_c(double a, double b, double c) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "s"(c));
+  return o;
 }
-CTC_HD double log_1_2(double x) {  // log x, 1 <= x <= 2 (the classic s = f / (2 + f) series, Sun's coefficients)
-  const bool big = x > 1.4142135623730951;
+#else
+inline double fma_c(double a, double b, double c) { return fma(a, b, c); }
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CTC_SIM)
+static __device__ __constant__ const LseTab CTC_LSE_TAB = CTC_LSE_TAB_INIT;
+__device__ __forceinline__ const LseTab& lse_tab() {
+  typedef const LseTab __attribute__((address_space(4))) * P4;
+  P4 p = (P4)&CTC_LSE_TAB;
+  asm volatile("" : "+s"(p));
+  return *(const LseTab*)p;
+}
+#else
+static const LseTab CTC_LSE_TAB = CTC_LSE_TAB_INIT;
+inline const LseTab& lse_tab() { return CTC_LSE_TAB; }
+#endif
+
+CTC_HD double exp_m37_0(const LseTab& C, double d) {  // e^d, -37 <= d <= 0
+  const double kf = rint(d * C.log2e);
+  double r = fma(-kf, C.ln2_hi, d);
+  r = fma(-kf, C.ln2_lo, r);  // |r| <= ln2 / 2
+  // e^r = 1 + r + r^2 q(r), Taylor to r^13 (truncation 4e-18)
+  double q = C.e13;
+  q = fma_c(q, r, C.e12);
+  q = fma_c(q, r, C.e11);
+  q = fma_c(q, r, C.e10);
+  q = fma_c(q, r, C.e9);
+  q = fma_c(q, r, C.e8);
+  q = fma_c(q, r, C.e7);
+  q = fma_c(q, r, C.e6);
+  q = fma_c(q, r, C.e5);
+  q = fma_c(q, r, C.e4);
+  q = fma_c(q, r, C.e3);
+  q = fma_c(q, r, C.e2);
+  const double p = fma(r * r, q, r) + 1.0;
+  const int32_t k = (int32_t)kf;  // -54 .. 0: the scale is a normal number (a 32-bit conversion: one instruction)
+  return p * lse_bits_f64((uint64_t)(uint32_t)(k + 1023) << 52);
+}
+CTC_HD double log_1_2(const LseTab& C, double x) {  // log x, 1 <= x <= 2 (the classic s = f / (2 + f) series, Sun's coefficients)
+  const bool big = x > C.sqrt2;
   const double m = big ? x * 0.5 : x, dk = big ? 1.0 : 0.0;
   const double f = m - 1.0;
-  // s = f / (2 + f) without the division (~30 instructions): a single-precision reciprocal of the denominator (2 .. 2.42)
-  // refined by three Newton steps in double precision (24 -> 48 -> 96 bits), all explicit fma's -- the same bits on the
-  // device and in the simulator. s is within an ulp or two of the quotient; the series only needs it to about 2^-50.
-  const double den = 2.0 + f;
-  double r = (double)(1.0f / (float)den);
+  // s = f / (2 + f) without the division (~30 instructions): a quadratic for the reciprocal of the denominator (2 .. 2.42,
+  // ~1e-3) refined by three Newton steps (1e-6, 1e-12, 1e-24), all explicit fma's -- the same bits on the device and in the
+  // simulator. s is within an ulp or two of the quotient; the series only needs it to about 2^-50.
+  const double den = 2.0 + f, dx = f - 0.2;  // (den - 2.2)
+  double r = fma_c(dx, fma_c(dx, C.r2, C.r1), C.r0);
   r = fma(fma(-den, r, 1.0), r, r);
   r = fma(fma(-den, r, 1.0), r, r);
   r = fma(fma(-den, r, 1.0), r, r);
   const double s = f * r;
   const double z = s * s, w = z * z;
-  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
-                            6.666666666666735130e-01);
+  const double t1 = w * fma_c(w, fma_c(w, C.l6, C.l4), C.l2);
+  const double t2 = z * fma_c(w, fma_c(w, fma_c(w, C.l7, C.l5), C.l3), C.l1);
   const double R = t2 + t1;
   const double hfsq = 0.5 * f * f;
-  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+  return dk * C.ln2_hi - ((hfsq - (s * (hfsq + R) + dk * C.ln2_lo)) - f);
 }
 CTC_HD double lse2(double a, double b) {
   const bool ge = a >= b;
   const double hi = ge ? a : b, lo = ge ? b : a;
   const double d = lo - hi;
   if (d < -37.0) return hi;  // 1 + e^d == 1
-  return hi + log_1_2(1.0 + exp_m37_0(d));  // (a NaN falls through and stays a NaN)
+  const LseTab& C = lse_tab();
+  return hi + log_1_2(C, 1.0 + exp_m37_0(C, d));  // (a NaN falls through and stays a NaN)
 }
 
 CTC_HD uint64_t hist_hash(const uint64_t* ring, uint32_t cnt) {

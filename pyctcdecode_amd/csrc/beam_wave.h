@@ -110,6 +110,16 @@ constexpr uint32_t M2_COMP = 64u;
 constexpr int WAVE_LAB = 16;        // survivors are staged in LDS (ids, modes, label constants) 16 at a time
 constexpr int WAVE_SURV_CAP = 480;  // survivors per frame this kernel handles: arrival = s * N + beam has to fit 16 bits
 
+// 65536 / n + 1 and max(1, 64 / n) for the n <= 64 live beams of a candidate pass: looked up (one scalar load), not divided
+// (an integer division is ~35 instructions of float reciprocal and fix-up on this hardware)
+struct WaveDivTab {
+  uint32_t rcp[65];
+  uint32_t per[65];
+};
+static constexpr WaveDivTab WAVE_DIV = {
+    {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097, 3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1025},
+    {64, 64, 32, 21, 16, 12, 10, 9, 8, 7, 6, 5, 5, 4, 4, 4, 4, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}};
+
 template <int BW>
 struct WaveShape {
   static constexpr int SLB = (BW + 63) / 64;  // beam slots per lane (lane = beam phases)
@@ -189,7 +199,9 @@ constexpr int W_PROF_LOAD = 0, W_PROF_COMP = 1, W_PROF_GEN = 2, W_PROF_MATCH = 3
               W_PROF_ST_BUILD = 18, W_PROF_N = 19;
 
 // ORD: the highest n-gram order compiled in (4 covers the usual models; 6 everything the tables can hold)
-template <class Ctx, int BW, int ORD = MAX_CTX + 1>
+// PROF: the phase timers of ctcdec_profile_phases are compiled in (a diagnostics launch; the ~35 timer sites of a frame
+//       cost three instructions each even when they do nothing)
+template <class Ctx, int BW, int ORD = MAX_CTX + 1, bool PROF = false>
 struct WaveDecoder {
   typedef WaveShape<BW> S;
   static constexpr int SLB = S::SLB;
@@ -282,7 +294,7 @@ struct WaveDecoder {
 
   template <int PHASE>
   CTC_HD void tick() {
-    if (io.prof && lane == 0) {
+    if (PROF && io.prof && lane == 0) {
       unsigned long long now = ctx.clock();
       io.prof[PHASE] += now - t_last;
       t_last = now;
@@ -1008,7 +1020,7 @@ CTC_UNROLL
   CTC_HD void pass1(uint32_t base, uint32_t l0, uint32_t l1) {
     const uint32_t Nn = (uint32_t)N;
     const uint32_t Q = (l1 - l0) * Nn;
-    const uint32_t rcpN = Nn ? 65536u / Nn + 1u : 0u;  // v / N == (v * rcpN) >> 16 for v * N < 65536
+    const uint32_t rcpN = WAVE_DIV.rcp[Nn <= 64u ? Nn : 0u];  // v / N == (v * rcpN) >> 16 for v * N < 65536 (N <= 64 here)
     const uint32_t v = (uint32_t)lane;
     const bool closes_any = closing_labels(l0, l1);
     clear_table();
@@ -1331,8 +1343,7 @@ CTC_UNROLL
       const uint32_t nb = ns - base < (uint32_t)WAVE_LAB ? ns - base : (uint32_t)WAVE_LAB;
       if (N <= 64) {
         // passes of whole labels (<= 64 candidates)
-        uint32_t per = 64u / (uint32_t)(N > 0 ? N : 1);
-        if (per == 0) per = 1;
+        const uint32_t per = WAVE_DIV.per[N > 0 ? N : 0];  // whole labels per pass: max(1, 64 / N)
         for (uint32_t l0 = 0; l0 < nb; l0 += per) pass1(base, l0, l0 + per < nb ? l0 + per : nb);
       } else if (SLB > 1) {
         for (uint32_t l = 0; l < nb; ++l) pass_big(base, l);
@@ -1935,7 +1946,7 @@ CTC_UNROLL
 
   CTC_HD void run() {
     init();
-    if (io.prof && lane == 0) t_last = ctx.clock();
+    if (PROF && io.prof && lane == 0) t_last = ctx.clock();
     prefetch(0);
     {
       TokRegs tr;

@@ -123,7 +123,7 @@ struct WaveGpuCtx {
 // Four waves per SIMD: 128 registers per lane (the allocator is told so: left alone it takes what it likes and halves the
 // residency) and, by wave_lds_bytes, at most 10 KB of LDS at beam_width <= 100 -- sixteen utterances per CU.
 // (beam_width 101 .. 128: 12.7 KB of LDS allow twelve waves per CU, three per SIMD: 168 registers)
-template <int BW, int ORD>
+template <int BW, int ORD, bool PROF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BW <= 100 ? 4 : 3, BW <= 100 ? 4 : 3))) void beam_wave(BeamArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -165,17 +165,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BW <= 100 ? 
     io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * 0 : nullptr;
   }
   WaveGpuCtx ctx{(int)threadIdx.x, (KernArgs)__builtin_amdgcn_kernarg_segment_ptr()};
-  WaveDecoder<WaveGpuCtx, BW, ORD> dec(ctx, view, io);
+  WaveDecoder<WaveGpuCtx, BW, ORD, PROF> dec(ctx, view, io);
   dec.run();
 }
 
 
+template <int BW, int ORD, bool PROF>
+static int launch_wave_p(const BeamArgs& a, hipStream_t stream, std::string* err) {
+  const size_t lds = wave_lds_bytes<BW>();
+  HIP_TRY_W(hipFuncSetAttribute((const void*)beam_wave<BW, ORD, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((beam_wave<BW, ORD, PROF>), dim3((unsigned)a.n_utts), dim3(64), lds, stream, a);
+  return 0;
+}
 template <int BW, int ORD>
 static int launch_wave_t(const BeamArgs& a, hipStream_t stream, std::string* err) {
-  const size_t lds = wave_lds_bytes<BW>();
-  HIP_TRY_W(hipFuncSetAttribute((const void*)beam_wave<BW, ORD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((beam_wave<BW, ORD>), dim3((unsigned)a.n_utts), dim3(64), lds, stream, a);
-  return 0;
+  // (phase timers: their own instantiation, launched only while ctcdec_profile_phases is on)
+  return a.prof ? launch_wave_p<BW, ORD, true>(a, stream, err) : launch_wave_p<BW, ORD, false>(a, stream, err);
 }
 template <int BW>
 static int launch_wave_bw(const BeamArgs& a, hipStream_t stream, std::string* err) {
