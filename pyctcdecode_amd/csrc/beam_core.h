@@ -208,7 +208,9 @@ struct ColdRec {  // 64 B
   uint32_t enode;          // end of the beam's emission chain
   int32_t pstart, pend;    // partial_frames of the open word
   uint32_t depth;          // emission nodes on the beam's chain
-  uint32_t pad[3];
+  uint32_t tnode;          // text node of the beam's completed words
+  uint32_t wid;            // word id of the open word in the LM vocabulary (0: none / not a word)
+  uint32_t pad;
 };
 // ... and what only the table build needs of a pooled candidate: one line per push, per utterance and frame
 struct PoolPay {  // 32 B

@@ -8,7 +8,7 @@
 // wavefronts per SIMD: at beam_width 100 a wave owns 9 920 bytes of LDS and is compiled for 128 registers, so
 // sixteen utterances are resident per CU and a batch of 4096 utterances is one round on the 256 CUs.
 //   * LDS holds only what the candidate passes read per (label, beam): three 16-byte columns per beam
-//     ({text hash, partial hash} {logit, last label | length, table view} {lm + hot-word score, text node, word id}),
+//     ({text hash, partial hash} {logit, last label | length, table view} {lm + hot-word score, hash of text (+) open word}),
 //     column-wise so that consecutive lanes read consecutive 16-byte words;
 //   * everything else of a beam -- the scores of its pending word completion, its history hashes, its emission
 //     chain, the frames of the open word -- is a 64-byte record in global memory (ColdRec, two buffers used
@@ -102,7 +102,8 @@ CTC_HD uint64_t fin64(uint64_t x) {
 
 // ---- layout ------------------------------------------------------------------------------------------------
 // A live beam, LDS part: three columns of 16-byte words
-//   A: text_h, part_h          B: logit, meta1, meta2          C: lm_hw, text_node, word_id
+//   A: text_h, part_h          B: logit, meta1, meta2          C: lm_hw, c_text_h (the text with the open word closed: valid
+//                                                                    with M2_COMP; the merge key of a candidate that closes it)
 // meta1 = last label | code points of the open word << 16; meta2 = prefix-table / hot-word view of the open word, plus
 // M2_COMP: the completion of the open word (text (+) word: its TextNode, scores and history hash) exists in the beam's
 // ColdRec. The rest of the beam is its ColdRec in global memory (beam_core.h).
@@ -420,12 +421,13 @@ CTC_UNROLL
         status |= ST_TEXT_OVERFLOW;  // (made wave-wide at the end of the frame)
         idx = io.text_cap - 1;
       }
-      const u32x4 k2 = L.hC[i];
-      const uint32_t wid = k2[3], m2 = k1[3];
+      ColdRec& cr = cold_cur()[i];
+      const u32x4 w3 = ((const u32x4a*)&cr)[3];  // {depth, text node, word id}
+      const uint32_t wid = w3[2], m2 = k1[3];
       const u32x4 k0 = L.hA[i];
       const uint64_t part_h = q_hi(k0);
       Node sn;
-      node_load(k2[2], sn);
+      node_load(w3[1], sn);
       double raw = sn.raw;
       LmState out = sn.st;
       if (T_.has_lm) {
@@ -449,7 +451,7 @@ CTC_UNROLL
       nn.ring[4] = 4u < rc ? sn.ring[3] : 0ull;
       const uint64_t hh = wave_hist_fold(nn.ring, rc);
       node_store(idx, nn);
-      ColdRec& cr = cold_cur()[i];
+      L.c64[i * 2 + 1] = text_push(q_lo(k0), part_h);  // the completed text's hash: merge key of the candidates that close the word
       cr.c_lmhw = lmhw;
       cr.c_hist_h = hh;
       cr.cnode = idx;
@@ -676,14 +678,15 @@ CTC_UNROLL
     uint32_t pp_wid, pp_fl, ph_min, ph_cmp;
     double lg;
     double wd;    // of the candidate's beam (ColdRec): the pending completion's lm + hot-word score when the label closes the
-    uint64_t wh;  // open word, else the open word's partial score; and the history hash that goes with the branch
+    uint64_t wh;  // open word, else the open word's partial score; and the history hash that goes with the branch;
+    uint32_t cwid;  // ... and the open word's id (what a blank / repeat keeps)
   };
 
   // branch, merge key and summed logit of candidate (label l of the staged block = survivor s, beam i);
   // FULL: also the first probe of the prefix / hot-word table of an appended partial word and the request for the two
-  // words of the beam's ColdRec its score will need. closes_any (uniform): some label of the pass closes open words.
+  // words of the beam's ColdRec its score will need.
   template <bool FULL>
-  CTC_HD void gen(Cand& c, bool valid, uint32_t l, uint32_t s, uint32_t i, bool closes_any) {
+  CTC_HD void gen(Cand& c, bool valid, uint32_t l, uint32_t s, uint32_t i) {
     const DeviceTables& T_ = tab();
     const DecodeParams& P_ = prm();
     // Straight-line: a lane without a candidate computes on label 0 / beam 0 (its fields are only looked at behind
@@ -718,11 +721,8 @@ CTC_UNROLL
     const bool app = b == BR_APPEND;
     const bool closing_word = closes && pl > 0;
     // merge key parts: the text (the completed one when the open word closes) and the new partial word
-    uint64_t kt = q_lo(k0);
-    if (closes_any) {
-      const uint64_t cth = text_push(q_lo(k0), q_hi(k0));
-      kt = closing_word ? cth : kt;
-    }
+    // (the completed text's hash sits in the beam's column C since its completion was made: completions_now)
+    const uint64_t kt = closing_word ? L.c64[ii * 2 + 1] : q_lo(k0);
     const uint64_t p_app = str_concat(q_hi(k0), q_hi(la), q_lo(la));  // pow_raw, h_raw
     uint64_t p = q_hi(k0);
     p = app ? p_app : p;
@@ -735,6 +735,7 @@ CTC_UNROLL
     c.pp_wid = c.pp_fl = c.ph_min = c.ph_cmp = 0;
     c.wd = 0.0;
     c.wh = 0;
+    c.cwid = 0;
     if (FULL) {  // first probe of the prefix / hot-word table of an appended partial word
       const bool probe = valid && app && p != 0;
       c.tslot = (uint32_t)table_slot(p);
@@ -755,6 +756,7 @@ CTC_UNROLL
       const ColdRec* cr = cold_cur() + ii;
       c.wd = *(closing_word ? &cr->c_lmhw : &cr->pscore);
       if (P_.prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
+      c.cwid = cr->wid;
     }
     // (a real finaliser: the hashes of one-character strings differ in their low bits only, and the match tag drops seven bits)
     c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
@@ -941,9 +943,7 @@ CTC_UNROLL
     const uint32_t i = rep ? c.bi : 0u, ll = rep ? c.ll : 0u;
     const uint32_t b = c.br;
     const u32x4 lb = L.lab[ll * 4 + 2], lc = L.lab[ll * 4 + 3];
-    const u32x4 k2 = L.hC[i];
-    const uint32_t st_wid = k2[3];
-    const double own_lmhw = bits_f64(q_lo(k2));
+    const double own_lmhw = bits_f64(L.c64[i * 2]);
     const bool is0 = b == 0, isB = b == BR_BOUNDARY, isA = b == BR_APPEND;  // else: space
     // boundary: a new word starts with the clean label (or, for a bare boundary mark, nothing yet)
     const uint32_t len_clean = lb[3];
@@ -958,7 +958,7 @@ CTC_UNROLL
                          ((t.hon && t.hcomp) ? M2_HOT_COMPLETE : 0u) | (a_hmin << 8);
     const uint32_t q_pl = is0 ? c.pl0 : (isB ? len_clean : (isA ? c.pl0 + c.len_raw : 0u));
     const uint32_t q_m2 = is0 ? (c.m2_0 & ~M2_COMP) : (isB ? m2B : (isA ? m2A : EMPTY_PARTIAL_M2));
-    const uint32_t q_wid = is0 ? st_wid : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t.on ? t.nw : 0u) : 0u));
+    const uint32_t q_wid = is0 ? c.cwid : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t.on ? t.nw : 0u) : 0u));
     const double ps_new = partial_score_sel(T_, P_, isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
     const double q_ps = is0 ? c.wd : ((bw || isA) ? ps_new : 0.0);  // (blank / repeat: the open word's score as it is)
     const double lmhw = (!is0 && !isA && c.pl0 > 0) ? c.wd : own_lmhw;  // boundary / space close the open word
@@ -1004,17 +1004,6 @@ CTC_UNROLL
 #endif
   }
 
-  // does some label in [l0, l1) of the staged block close open words (boundary / space modes)? (uniform)
-  CTC_HD bool closing_labels(uint32_t l0, uint32_t l1) {
-    const uint32_t l = l0 + (uint32_t)lane;
-    bool cl = false;
-    if (l < l1) {
-      const uint32_t mode = L.lab[l * 4][1] & 0xFFu;
-      cl = mode == MODE_ALL_B || mode == MODE_FIRST_B || mode == MODE_C;
-    }
-    return ctx.ballot(cl) != 0ull;
-  }
-
   // One pass: the candidates of the labels [l0, l1) of the staged block (survivors base + l), N <= 64 beams,
   // candidate v = lane
   CTC_HD void pass1(uint32_t base, uint32_t l0, uint32_t l1) {
@@ -1022,12 +1011,11 @@ CTC_UNROLL
     const uint32_t Q = (l1 - l0) * Nn;
     const uint32_t rcpN = WAVE_DIV.rcp[Nn <= 64u ? Nn : 0u];  // v / N == (v * rcpN) >> 16 for v * N < 65536 (N <= 64 here)
     const uint32_t v = (uint32_t)lane;
-    const bool closes_any = closing_labels(l0, l1);
     clear_table();
     const uint32_t sl = (v * rcpN) >> 16;
     const uint32_t l = l0 + sl;
     Cand c;
-    gen<true>(c, v < Q, l, base + l, v - sl * Nn, closes_any);
+    gen<true>(c, v < Q, l, base + l, v - sl * Nn);
     ctx.wsync();
     tick<W_PROF_GEN>();
     uint32_t rep;
@@ -1088,7 +1076,6 @@ CTC_UNROLL
     const uint32_t Nn = (uint32_t)N;
     const u32x4 sv = L.lab[l * 4];
     const double lp = bits_f64(pack64(sv[2], sv[3]));
-    const bool closes_any = closing_labels(l, l + 1u);
     bool valid[2];
     uint64_t ck[2];
     double lg[2];
@@ -1098,7 +1085,7 @@ CTC_UNROLL
     for (int h = 0; h < 2; ++h) {
       const uint32_t v = (uint32_t)(h * 64 + lane);
       Cand c;
-      gen<false>(c, v < Nn, l, base + l, v, closes_any);
+      gen<false>(c, v < Nn, l, base + l, v);
       valid[h] = c.valid;
       ck[h] = c.ck;
       lg[h] = c.lg;
@@ -1145,7 +1132,7 @@ CTC_UNROLL
     for (int h = 0; h < 2; ++h) {
       const uint32_t v = (uint32_t)(h * 64 + lane);
       Cand c;
-      gen<true>(c, v < Nn, l, base + l, v, closes_any);
+      gen<true>(c, v < Nn, l, base + l, v);
       c.is_rep = is_rep[h];
       c.lg = lg[h];
       const uint32_t di = is_rep[h] ? imax[h] : 0u;
@@ -1277,8 +1264,8 @@ CTC_UNROLL
 #ifdef CTC_WAVE_TRACE
     if (lane < N) {
       const u32x4 t0 = L.hA[lane], t1 = L.hB[lane], t2 = L.hC[lane];
-      printf("TB f=%d N=%d i=%d text=%llx part=%llx logit=%.6f meta1=%x m2=%x tn=%u wid=%u\n", frame, N, lane, (unsigned long long)q_lo(t0),
-             (unsigned long long)q_hi(t0), bits_f64(q_lo(t1)), t1[2], t1[3], t2[2], t2[3]);
+      printf("TB f=%d N=%d i=%d text=%llx part=%llx logit=%.6f meta1=%x m2=%x ctext=%llx\n", frame, N, lane, (unsigned long long)q_lo(t0),
+             (unsigned long long)q_hi(t0), bits_f64(q_lo(t1)), t1[2], t1[3], (unsigned long long)q_hi(t2));
     }
 #endif
     // this frame's survivors (block 0: ids / log-probs in the prefetch registers, label constants already in LDS),
@@ -1409,15 +1396,15 @@ CTC_UNROLL
     const u32x4a* pay = (const u32x4a*)&io.pay[((uint32_t)a2 >> 16) & 0xFFFFu];
     const u32x4 e1 = pay[0], e2 = pay[1];  // {summed logit, new partial hash} {plen, word id, table view}
     const u32x4a* crp = (const u32x4a*)&cold_cur()[i];
-    const u32x4 w0 = crp[0], w1 = crp[1], w2 = crp[2];
-    uint32_t depth = cold_cur()[i].depth;
+    const u32x4 w0 = crp[0], w1 = crp[1], w2 = crp[2], w3 = crp[3];  // (w3: depth, text node, word id)
+    uint32_t depth = w3[0];
     const u32x4 k0 = L.hA[i], k1 = L.hB[i], k2 = L.hC[i];
     const uint32_t pl = k1[2] >> 16;
     uint64_t th = q_lo(k0), hh = q_lo(w1);
     const uint64_t ph = q_hi(e1);  // the new partial word's hash (unchanged for a blank / repeat)
-    uint64_t lmhw = q_lo(k2);
+    uint64_t lmhw = q_lo(k2), cth = q_hi(k2);
     uint64_t clm = q_lo(w0), chh = q_hi(w1);
-    uint32_t tnode = k2[2], cnode = w2[0], enode = w2[1];
+    uint32_t tnode = w3[1], cnode = w2[0], enode = w2[1];
     int32_t pst = (int32_t)w2[2], pen = (int32_t)w2[3];
     uint32_t m2 = e2[2] & ~M2_COMP;
     const uint32_t wid = e2[1];
@@ -1429,7 +1416,7 @@ CTC_UNROLL
       const int32_t wst = pst, wen = pen;
       if (b == BR_BOUNDARY || b == BR_SPACE) {
         if (pl > 0) {  // the open word is completed (decoder.py:483-495, 501-515)
-          th = text_push(q_lo(k0), q_hi(k0));
+          th = cth;
           hh = chh;
           lmhw = clm;
           tnode = cnode;
@@ -1448,6 +1435,7 @@ CTC_UNROLL
       cnode = 0;
       clm = 0;
       chh = 0;
+      cth = 0;
       if (e >= io.emit_cap) {
         status |= ST_EMIT_OVERFLOW;
         e = io.emit_cap - 1;
@@ -1462,10 +1450,10 @@ CTC_UNROLL
     nr[0] = mk4q(clm, f64_bits(ps));
     nr[1] = mk4q(hh, chh);
     nr[2] = mk4(cnode, enode, (uint32_t)pst, (uint32_t)pen);
-    nr[3] = mk4(depth, 0u, 0u, 0u);
+    nr[3] = mk4(depth, tnode, wid, 0u);
     o.o0 = mk4q(th, ph);
     o.o1 = mk4(e1[0], e1[1], c | (npl << 16), m2);
-    o.o2 = mk4((uint32_t)lmhw, (uint32_t)(lmhw >> 32), tnode, wid);
+    o.o2 = mk4q(lmhw, cth);
   }
   CTC_HD void put_rec(uint32_t d, const Rec& o) {
     L.hA[d] = o.o0;
@@ -1538,7 +1526,7 @@ CTC_UNROLL
     const uint64_t lgb = f64_bits(logit), lmb = f64_bits(lm_hw);
     L.hA[i] = mk4q(text_h, part_h);
     L.hB[i] = mk4((uint32_t)lgb, (uint32_t)(lgb >> 32), meta1, meta2 & ~M2_COMP);
-    L.hC[i] = mk4((uint32_t)lmb, (uint32_t)(lmb >> 32), text_node, word_id);
+    L.hC[i] = mk4((uint32_t)lmb, (uint32_t)(lmb >> 32), 0u, 0u);
     ColdRec cr;
     cr.c_lmhw = 0.0;
     cr.pscore = pscore;
@@ -1549,7 +1537,9 @@ CTC_UNROLL
     cr.pstart = pstart;
     cr.pend = pend;
     cr.depth = depth;
-    cr.pad[0] = cr.pad[1] = cr.pad[2] = 0;
+    cr.tnode = text_node;
+    cr.wid = word_id;
+    cr.pad = 0;
     cold_cur()[i] = cr;
   }
 
@@ -1668,7 +1658,7 @@ CTC_UNROLL
       if (valid[j]) {
         const u32x4 k0 = L.hA[v], k1 = L.hB[v];
         const uint32_t pl = k1[2] >> 16;
-        const uint64_t kt = pl > 0 ? text_push(q_lo(k0), q_hi(k0)) : q_lo(k0);
+        const uint64_t kt = (fold && pl > 0) ? L.c64[v * 2 + 1] : q_lo(k0);  // (folding: every open word has its completion now)
         ck[j] = fin64(kt ^ 0x165667B19E3779F9ull);
         lg[j] = bits_f64(q_lo(k1));
       }
@@ -1714,12 +1704,13 @@ CTC_UNROLL
         const uint32_t pl = d1[2] >> 16;
         double lmhw;
         if (eos) {
+          const ColdRec dcr = cold_cur()[d];
           Node src;
-          node_load(d2[2], src);
+          node_load(dcr.tnode, src);
           const uint32_t cnt = src.hw_cnt + ((pl > 0 && (m2 & M2_HOT_COMPLETE)) ? 1u : 0u);
           if (tab().has_lm) {
             LmState st = src.st, end;
-            const uint32_t wid = pl > 0 ? d2[3] : 0u;
+            const uint32_t wid = pl > 0 ? dcr.wid : 0u;
             const uint32_t wfl = pl > 0 ? m2 : 0u;
             const float base_s = lm_base_score<ORD>(tab(), st, wid, &end);
             double end_score = 0.0;
@@ -1834,7 +1825,7 @@ CTC_UNROLL
       ob.pend = fold ? -1 : cr.pend;
       // the text's memo entry: raw LM sum and the state after its last word
       Node node;
-      node_load(closes ? cr.cnode : d2[2], node);
+      node_load(closes ? cr.cnode : cr.tnode, node);
       ob.raw_lm = node.raw;
       if (!tab().has_lm) {
         ob.state.len = -1;
@@ -1847,9 +1838,9 @@ CTC_UNROLL
         // last_lm_state: state after the last word, before </s> (language_model.py:357); an empty
         // last word is still scored as a word (decoder.py:387-395)
         Node src;
-        node_load(d2[2], src);
+        node_load(cr.tnode, src);
         LmState st = src.st, after;
-        lm_base_score<ORD>(tab(), st, pl > 0 ? d2[3] : 0u, &after);
+        lm_base_score<ORD>(tab(), st, pl > 0 ? cr.wid : 0u, &after);
         ob.state = after;
       } else {
         ob.state = node.st;
@@ -1920,11 +1911,11 @@ CTC_UNROLL
         depth += 1;
       }
       Node node;
-      node_load(closes ? cr.cnode : d2[2], node);
+      node_load(closes ? cr.cnode : cr.tnode, node);
       ImportBeam& m = io.carry_out[r];
       m.logit_score = lg;
       m.raw_lm = node.raw;
-      m.text_h = closes ? text_push(q_lo(d0), q_hi(d0)) : q_lo(d0);  // (the text of the node: its hash is the beam's)
+      m.text_h = closes ? q_hi(d2) : q_lo(d0);  // (the text of the node: its hash is the beam's, or its completion's)
       m.part_h = fold ? 0ull : q_hi(d0);
 CTC_UNROLL
       for (int k = 0; k < MAX_CTX; ++k) m.ring[k] = node.ring[k];
@@ -1933,7 +1924,7 @@ CTC_UNROLL
       m.plen = fold ? 0u : pl;
       m.last_char = fold ? NO_CHAR : (meta1 & 0xFFFFu);
       m.m2 = fold ? EMPTY_PARTIAL_M2 : (d1[3] & ~M2_COMP);
-      m.word_id = fold ? 0u : d2[3];
+      m.word_id = fold ? 0u : cr.wid;
       m.pstart = fold ? -1 : cr.pstart;
       m.pend = fold ? -1 : cr.pend;
       m.state = node.st;
