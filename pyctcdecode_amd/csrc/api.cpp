@@ -1086,8 +1086,11 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     pa.row_base = 0;
     pa.slow_rows = (uint32_t*)dec->w_slow.p;
     pa.rows_aligned16 = 1;
-    for (const void* q : ptrs)
+    pa.rows_aligned4 = 1;
+    for (const void* q : ptrs) {
       if (((uintptr_t)q & 15u) != 0) pa.rows_aligned16 = 0;
+      if (((uintptr_t)q & 3u) != 0) pa.rows_aligned4 = 0;
+    }
     ba.surv_cnt = (const uint32_t*)dec->w_scnt.p;
     ba.surv_id = (const uint16_t*)dec->w_sid.p;
     ba.surv_lp = (const double*)dec->w_slp.p;
@@ -1446,6 +1449,7 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   pa.pass = 0;
   pa.slow_rows = (uint32_t*)dec->w_slow.p;
   pa.rows_aligned16 = (((uintptr_t)ptrs[0]) & 15u) == 0 ? 1 : 0;
+  pa.rows_aligned4 = (((uintptr_t)ptrs[0]) & 3u) == 0 ? 1 : 0;
   if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   uint32_t flags[4] = {0, 0, 0, 0};
   if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);

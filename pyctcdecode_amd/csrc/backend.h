@@ -60,6 +60,7 @@ struct PruneArgs {
                          // [3]: device-side counter of slow_rows
   int32_t pass;          // 0: all utterances as logits + row sums + sniff; 1: redo the probability-like ones
   int32_t rows_aligned16; // every utterance base pointer is 16-byte aligned
+  int32_t rows_aligned4;  // ... 4-byte aligned (float32 rows read one label at a time)
   int64_t row_base;      // first row of this launch (utt_row0 and the row-indexed arrays are absolute); n_rows rows follow
   uint32_t* slow_rows;   // [n_rows] scratch, or nullptr: rows (relative to row_base) the 64-rows-per-wave kernel hands to the
                          // per-row one; their count is kept in overflow[3]

@@ -1041,7 +1041,10 @@ __device__ __forceinline__ float pf_widen(uint32_t h16) {
   return DT == 2 ? __half2float(__ushort_as_half((unsigned short)h16)) : __uint_as_float(h16 << 16);
 }
 
-template <int NC, int DT>
+// AL: rows start on 16-byte boundaries and hold a multiple of four (16-bit: eight) labels: 16-byte loads. !AL (float32 only):
+// any label count and any 4-byte-aligned rows -- each lane fetches its four consecutive labels one by one (the common
+// "1024 BPE pieces + blank = 1025 labels" shape); labels past the row's end read as -inf.
+template <int NC, int DT, bool AL = true>
 __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -1056,9 +1059,10 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   constexpr int NL = WIDE ? NC : NC / 2;         // 16-byte loads per lane and row
   constexpr int PER = WIDE ? 4 : 8;              // labels per load
   static_assert(WIDE || NC % 2 == 0, "16-bit rows: two float4 groups per load");
+  static_assert(AL || WIDE, "element-wise loads: float32 rows only");
   typedef typename PfRaw<DT>::type Raw;
   const int V = a.n_labels;
-  const int n4 = V / PER;                        // loads per row
+  const int n4 = AL ? V / PER : (V + 3) / 4;     // loads (groups of four labels) per row
   const float tminf = (float)a.token_min_logp;
   // label id of element e of group k in this lane; is group k inside the row?
   auto id_of = [&](int k, int e) { return WIDE ? (k * 64 + lane) * 4 + e : ((k >> 1) * 64 + lane) * 8 + (k & 1) * 4 + e; };
@@ -1079,7 +1083,16 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i4 = k * 64 + lane;
-      if constexpr (WIDE) {
+      if constexpr (!AL) {
+        const float* xf = (const float*)x4;
+        const int e0 = i4 * 4;
+        float4 v;
+        v.x = e0 < V ? xf[e0] : -INFINITY;
+        v.y = e0 + 1 < V ? xf[e0 + 1] : -INFINITY;
+        v.z = e0 + 2 < V ? xf[e0 + 2] : -INFINITY;
+        v.w = e0 + 3 < V ? xf[e0 + 3] : -INFINITY;
+        r[k] = v;
+      } else if constexpr (WIDE) {
         r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       } else {
         const uint32_t ninf = DT == 2 ? 0xFC00FC00u : 0xFF80FF80u;  // -inf twice
@@ -1114,7 +1127,14 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     float mf = -INFINITY, rsf;
 #pragma unroll
     for (int k = 0; k < NC; ++k) mf = max3_raw(max3_raw(mf, r[k].x, r[k].y), r[k].z, r[k].w);
-    if (n4 == NL * 64) {  // (see prune_row_f32x4 on this sum)
+    if (!AL) {  // (labels past the end of the row hold -inf for the maximum: nothing for the sum)
+      rsf = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        const int e0 = (k * 64 + lane) * 4;
+        rsf += ((e0 < V ? r[k].x : 0.f) + (e0 + 1 < V ? r[k].y : 0.f)) + ((e0 + 2 < V ? r[k].z : 0.f) + (e0 + 3 < V ? r[k].w : 0.f));
+      }
+    } else if (n4 == NL * 64) {  // (see prune_row_f32x4 on this sum)
       f32x2 rs2 = (f32x2)(0.f);
 #pragma unroll
       for (int k = 0; k < NC; ++k) rs2 += (f32x2){r[k].x, r[k].y} + (f32x2){r[k].z, r[k].w};
@@ -1252,8 +1272,8 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
         for (uint32_t k = 0; k <= r.mask; ++k) {
           const uint16_t v = tab.get(r.base + k);
           if (v != SMALL_SET_EMPTY) {
-            const uint32_t pay = v >> 10;
-            out_id[pos] = (uint16_t)(v & 1023u);
+            const uint32_t pay = v >> SMALL_SET_ID_BITS;
+            out_id[pos] = (uint16_t)(v & SMALL_SET_ID_MASK);
             out_lp[pos] = pay == SMALL_SET_ARGMAX ? best : to_logp((double)xs[pay * PF_ROWS], false, md, lse);
             ++pos;
           }
@@ -1287,6 +1307,10 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     }
     dim3 grid((unsigned)((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES)), block(PRUNE_WAVES * 64);
     const bool vec4 = a.dtype == 0 && (a.n_labels % 4) == 0 && a.n_labels <= 1024 && a.rows_aligned16;
+    // float32 rows of up to 2046 labels take the 64-rows-per-wave kernel whatever their count and alignment (16-byte loads
+    // when both allow them)
+    const bool f32_fast = a.dtype == 0 && a.n_labels <= (int)SMALL_SET_MAX_ID && a.rows_aligned4;
+    const bool f32_al = (a.n_labels % 4) == 0 && a.rows_aligned16;
 #define CTC_LAUNCH_PRUNE(KERN)                                                                                 \
   do {                                                                                                         \
     HIP_TRY(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
@@ -1296,24 +1320,43 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     const char* pk = getenv("CTCDEC_PRUNE_KERNEL");  // "row": one wave per row for every row (diagnostics)
     const bool rows_ok = a.pass == 0 && a.slow_rows && a.max_surv < a.n_labels && a.n_rows < (1ll << 32) &&
                          !(ex && ex[0] == 'f') && !(pk && pk[0] == 'r');
-    const bool rows64 = vec4 && rows_ok;
+    const bool rows64 = f32_fast && rows_ok;
     // 16-bit rows of a multiple of eight labels (16-byte loads of eight): the same kernel, widened on the fly
     const bool rows64h = (a.dtype == 2 || a.dtype == 3) && (a.n_labels % 8) == 0 && a.n_labels <= 1024 && a.rows_aligned16 && rows_ok;
     const dim3 fgrid((unsigned)((a.n_rows + PF_ROWS - 1) / PF_ROWS)), fblock(64);
     const unsigned rest = (unsigned)std::min<int64_t>((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES, 2048);
     if (rows64) {
-      const int nc = (a.n_labels / 4 + 63) / 64;
-#define CTC_LAUNCH_FAST(NCV)                                                                                              \
+      const int nc = ((a.n_labels + 3) / 4 + 63) / 64;  // groups of four labels per lane: 1 .. 8
+      // rows the fast kernel hands over: the per-row float4 kernel where it applies (<= 1024 aligned labels), else the generic one
+#define CTC_LAUNCH_FAST(NCV, ALV)                                                                                         \
   do {                                                                                                                    \
-    hipLaunchKernelGGL((frame_prune_fast<NCV, 0>), fgrid, fblock, PF_LDS, g_stream, a);                                   \
-    HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_f32x4_listed<NCV>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                (int)lds));                                                                               \
-    hipLaunchKernelGGL((frame_prune_f32x4_listed<NCV>), dim3(rest), block, lds, g_stream, a, cap);                         \
+    hipLaunchKernelGGL((frame_prune_fast<NCV, 0, ALV>), fgrid, fblock, PF_LDS, g_stream, a);                              \
+    if (ALV && NCV <= 4) {                                                                                                \
+      HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_f32x4_listed<(NCV <= 4 ? NCV : 4)>,                            \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+      hipLaunchKernelGGL((frame_prune_f32x4_listed<(NCV <= 4 ? NCV : 4)>), dim3(rest), block, lds, g_stream, a, cap);     \
+    } else {                                                                                                              \
+      HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_listed<float>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                  (int)lds));                                                                             \
+      hipLaunchKernelGGL((frame_prune_listed<float>), dim3(rest), block, lds, g_stream, a, cap);                          \
+    }                                                                                                                     \
   } while (0)
-      if (nc <= 1) CTC_LAUNCH_FAST(1);
-      else if (nc == 2) CTC_LAUNCH_FAST(2);
-      else if (nc == 3) CTC_LAUNCH_FAST(3);
-      else CTC_LAUNCH_FAST(4);
+#define CTC_LAUNCH_FAST_NC(NCV)            \
+  do {                                     \
+    if (f32_al) CTC_LAUNCH_FAST(NCV, true); \
+    else CTC_LAUNCH_FAST(NCV, false);      \
+  } while (0)
+      switch (nc) {
+        case 1: CTC_LAUNCH_FAST_NC(1); break;
+        case 2: CTC_LAUNCH_FAST_NC(2); break;
+        case 3: CTC_LAUNCH_FAST_NC(3); break;
+        case 4: CTC_LAUNCH_FAST_NC(4); break;
+        case 5: CTC_LAUNCH_FAST_NC(5); break;
+        case 6: CTC_LAUNCH_FAST_NC(6); break;
+        case 7: CTC_LAUNCH_FAST_NC(7); break;
+        default: CTC_LAUNCH_FAST_NC(8); break;
+      }
+#undef CTC_LAUNCH_FAST_NC
 #undef CTC_LAUNCH_FAST
     } else if (rows64h) {
       const int nl = (a.n_labels / 8 + 63) / 64;  // 16-byte loads per lane: 1 (up to 512 labels) or 2

@@ -1,4 +1,4 @@
-// set_order_small.h -- set_order.h for at most SMALL_SET_MAX_KEYS ascending ids below 1024, in 48 table slots.
+// set_order_small.h -- set_order.h for at most SMALL_SET_MAX_KEYS ascending ids below 2047, in 48 table slots.
 //
 // The same CPython 3.10 algorithm (Objects/setobject.c, restated in set_order.h: cpython_set_order), with every table
 // size it can reach for so few keys written out, so that one frame's tables fit 96 bytes and a wavefront can order 64
@@ -10,7 +10,7 @@
 //     keys take 32 slots again: the table itself;
 //   * before the argmax is added the copy is resized when (used + 1) * 5 >= mask * 3: only for 4 keys in 8 slots
 //     (-> 16 slots); adding the argmax never triggers another growth.
-// A slot holds  id | payload << 10  (payload < 32: the caller's index of that id), SMALL_SET_EMPTY when free; only the
+// A slot holds  id | payload << 11  (id < 2047, payload < 32: the caller's index of that id), SMALL_SET_EMPTY when free; only the
 // id takes part in hashing and comparison.
 // `Tab` is anything with  uint16_t get(uint32_t slot)  and  void put(uint32_t slot, uint16_t v)  over 48 slots:
 // X = slots [0, 16), Y = slots [16, 48).
@@ -26,6 +26,9 @@ constexpr uint32_t SMALL_SET_MAX_KEYS = 15;
 constexpr uint32_t SMALL_SET_SLOTS = 48;
 constexpr uint16_t SMALL_SET_EMPTY = 0xFFFFu;
 constexpr uint32_t SMALL_SET_ARGMAX = 31;  // payload of an argmax that is not among the ids
+constexpr uint32_t SMALL_SET_ID_BITS = 11;  // ids < 2047 (id 2047 with the argmax payload would read as SMALL_SET_EMPTY)
+constexpr uint32_t SMALL_SET_ID_MASK = (1u << SMALL_SET_ID_BITS) - 1u;
+constexpr uint32_t SMALL_SET_MAX_ID = SMALL_SET_ID_MASK - 1u;
 
 struct SmallSet {
   uint32_t base, mask, used;
@@ -39,7 +42,7 @@ CTC_HD void small_set_clear(Tab& tab, uint32_t base, uint32_t size) {
 // set_insert_clean: the key is known to be absent and no slot was ever deleted
 template <class Tab>
 CTC_HD void small_set_insert_clean(Tab& tab, const SmallSet& s, uint16_t entry) {
-  const uint32_t key = entry & 1023u, mask = s.mask;
+  const uint32_t key = entry & SMALL_SET_ID_MASK, mask = s.mask;
   uint32_t perturb = key, i = key & mask;
   for (;;) {
     if (tab.get(s.base + i) == SMALL_SET_EMPTY) {
@@ -61,7 +64,7 @@ CTC_HD void small_set_insert_clean(Tab& tab, const SmallSet& s, uint16_t entry) 
 // set_add_entry without its resize (the callers know when one is due): false when the id is already a member
 template <class Tab>
 CTC_HD bool small_set_add(Tab& tab, const SmallSet& s, uint16_t entry) {
-  const uint32_t key = entry & 1023u, mask = s.mask;
+  const uint32_t key = entry & SMALL_SET_ID_MASK, mask = s.mask;
   uint32_t perturb = key, i = key & mask;
   for (;;) {
     uint32_t probes = (i + 9 <= mask) ? 9u : 0u;
@@ -72,7 +75,7 @@ CTC_HD bool small_set_add(Tab& tab, const SmallSet& s, uint16_t entry) {
         tab.put(s.base + e, entry);
         return true;
       }
-      if ((cur & 1023u) == key) return false;
+      if ((cur & SMALL_SET_ID_MASK) == key) return false;
       ++e;
       if (probes == 0) break;
       --probes;
@@ -103,7 +106,7 @@ CTC_HD SmallSet small_set_order(Tab& tab, uint32_t n, IdAt id_at, uint32_t argma
   SmallSet s{0, 7, 0};
   small_set_clear(tab, 0, 8);
   for (uint32_t k = 0; k < n; ++k) {
-    small_set_add(tab, s, (uint16_t)(id_at(k) | (k << 10)));
+    small_set_add(tab, s, (uint16_t)(id_at(k) | (k << SMALL_SET_ID_BITS)));
     s.used += 1;
     if (s.used * 5 >= s.mask * 3) {  // 8 slots, 5th key (32 slots: not before the 19th)
       SmallSet grown;
@@ -121,7 +124,7 @@ CTC_HD SmallSet small_set_order(Tab& tab, uint32_t n, IdAt id_at, uint32_t argma
     small_set_rebuild(tab, s, grown, 16, 16);
     s = grown;
   }
-  if (small_set_add(tab, s, (uint16_t)(argmax | (SMALL_SET_ARGMAX << 10)))) s.used += 1;
+  if (small_set_add(tab, s, (uint16_t)(argmax | (SMALL_SET_ARGMAX << SMALL_SET_ID_BITS)))) s.used += 1;
   return s;
 }
 

@@ -18,13 +18,13 @@ TOL = 1e-9  # absolute (tests/golden_util.check_beams); the device's fp64 scores
 
 
 def _tol(x):
-    """Bounds for a decode of logits `x` against the oracle run on their exact float64 upcast: float32 rows of a
-    multiple of four labels (<= 1024; 16-bit rows: of eight) take the packed float32 exponential unless CTCDEC_PRUNE_EXP=f64 -- 1e-4 absolute,
-    order exact outside runs closer than 4e-5 (the north star's float32 bound); everything else is fp64: 1e-9."""
+    """Bounds for a decode of logits `x` against the oracle run on their exact float64 upcast: float32 rows (up to 2046
+    labels; 16-bit rows: a multiple of eight up to 1024) take the packed float32 exponential unless CTCDEC_PRUNE_EXP=f64 --
+    1e-4 absolute, order exact outside runs closer than 4e-5 (the north star's float32 bound); everything else is fp64: 1e-9."""
     dt = str(getattr(x, "dtype", "")).replace("torch.", "")
     V = int(x.shape[-1])
     pk = os.environ.get("CTCDEC_PRUNE_EXP", "pk")[0] != "f"
-    f32_path = dt == "float32" and V % 4 == 0 and V <= 1024 and pk
+    f32_path = dt == "float32" and V <= 2046 and pk
     # (float16 / bfloat16 rows of a multiple of eight labels: the 64-rows-per-wave kernel widens them and runs the same
     # float32 exponentials; the reference itself computes such rows in float16)
     h_path = dt in ("float16", "bfloat16") and V % 8 == 0 and V <= 1024 and pk
@@ -103,6 +103,30 @@ def test_hip_vs_oracle_bpe1024_lm_hotwords(lm, bpe):
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="bpe%d" % u, **_tol(x))
     texts = dec.decode_batch(None, xs, hotwords=hot)
     assert texts == [g[0].text for g in got]
+
+
+def test_hip_vs_oracle_bpe1025_pieces_plus_blank(lm):
+    """The common real shape "1024 BPE pieces + the CTC blank" = 1025 labels: no multiple of four, rows that are only
+    4-byte aligned -- the 64-rows-per-wave prune kernel with element-wise loads (round 4), against the oracle."""
+    import torch
+
+    from oracle.ctc_oracle import build_oracle
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
+
+    pieces = synth.make_bpe_vocab(lm.words, size=1024)
+    dec = build_ctcdecoder(pieces, lm.path)
+    alpha = Alphabet.build_alphabet(pieces)
+    assert len(alpha.labels) == 1025
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
+    hot = lm.hotwords(6, 2)
+    xs = [synth.d_words(4, u, 90, pieces, True, lm.words, lm.sentences, len(pieces), boost=6.0) for u in range(3)]
+    xs.append(synth.d_flat(4, 9, 40, 1025))
+    got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], hotwords=hot, prune_history=True)
+    for u, x in enumerate(xs):
+        exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="bpe1025_%d" % u, **_tol(x))
+    assert dec.decode_batch(None, xs, hotwords=hot) == [g[0].text for g in got]
 
 
 def test_hip_ragged_batch_and_edge_cases(lm):
@@ -458,7 +482,12 @@ def test_hip_rows64_prune_kernel_shapes(monkeypatch):
     for V, T, scale, tmin in [(1024, 1, 2.0, -5.0), (1024, 63, 2.0, -5.0), (1024, 64, 3.0, -4.0), (1024, 65, 2.0, -5.0),
                               (1024, 200, 1.3, -5.5), (1020, 130, 2.0, -5.0), (772, 70, 2.0, -5.0), (512, 129, 2.0, -4.5),
                               (260, 67, 2.0, -4.0), (256, 64, 1.5, -4.0), (32, 500, 1.0, -3.0), (64, 100, 0.7, -3.9),
-                              (8, 77, 1.0, -1.5), (4, 5, 1.0, -1.0)]:
+                              (8, 77, 1.0, -1.5), (4, 5, 1.0, -1.0),
+                              # round 4: label counts that are no multiple of four (each lane fetches its labels one by one:
+                              # "1024 pieces + blank") and more than 1024 labels (five to eight groups of four per lane)
+                              (1025, 130, 2.0, -5.0), (1027, 70, 2.0, -5.0), (1021, 64, 2.0, -5.0), (29, 200, 1.0, -3.0),
+                              (30, 65, 1.0, -3.0), (31, 64, 1.2, -3.0), (5, 66, 1.0, -1.5), (1280, 65, 2.0, -5.0),
+                              (1540, 64, 2.0, -5.5), (2044, 66, 2.0, -5.5), (2046, 64, 2.2, -6.0), (2045, 67, 2.0, -5.5)]:
         dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
         x = (rng.standard_normal((T, V)) * scale).astype(np.float32)
         if T >= 64:

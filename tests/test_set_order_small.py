@@ -29,8 +29,8 @@ extern "C" int small_order_(const uint16_t* ids, int n, int argmax, uint16_t* ou
   for (uint32_t k = 0; k <= r.mask; ++k) {
     const uint16_t v = t.get(r.base + k);
     if (v != ctc::SMALL_SET_EMPTY) {
-      out[m] = v & 1023u;
-      pay[m] = v >> 10;
+      out[m] = v & ctc::SMALL_SET_ID_MASK;
+      pay[m] = v >> ctc::SMALL_SET_ID_BITS;
       ++m;
     }
   }
@@ -76,10 +76,10 @@ def test_small_tables_give_the_order_of_a_real_set(lib):
     n_cases = 0
     for n in range(0, 16):
         for rep in range(400):
-            hi = [1024, 1024, 64, 40, 300][rep % 5]  # dense id ranges collide in the 8-slot table
+            hi = [1024, 2047, 64, 40, 300][rep % 5]  # dense id ranges collide in the 8-slot table; ids go up to 2046
             ids = sorted(int(v) for v in rng.choice(hi, size=min(n, hi), replace=False))
             inside = n > 0 and rep % 3 != 0
-            amax = int(rng.choice(ids)) if inside else int(rng.integers(0, 1024))
+            amax = int(rng.choice(ids)) if inside else int(rng.integers(0, hi))
             got, pay = _small(lib, ids, amax)
             real = [int(k) for k in (set(ids) | {amax})]  # decoder.py:445-447
             assert got == real, (ids, amax)
@@ -97,6 +97,6 @@ def test_small_tables_on_runs_of_neighbouring_ids(lib):
             if start + n > 1024:
                 continue
             ids = list(range(start, start + n))
-            for amax in (0, start, start + n - 1 if n else 3, (start + 8) % 1024, (start + 32) % 1024, 1023):
+            for amax in (0, start, start + n - 1 if n else 3, (start + 8) % 1024, (start + 32) % 1024, 1023, 2046):
                 got, _ = _small(lib, ids, amax)
                 assert got == [int(k) for k in (set(ids) | {amax})], (ids, amax)
