@@ -948,6 +948,7 @@ constexpr int PF_ROWS = 64;
 constexpr int PF_CAND = 16;
 constexpr size_t PF_LDS_IDS = (size_t)PF_ROWS * PF_CAND * 2;
 constexpr size_t PF_LDS_X = (size_t)PF_ROWS * PF_CAND * 4;
+constexpr int PF_MAX_LABELS = 2048;  // 64 lanes x 8 groups of four labels
 constexpr size_t PF_LDS = PF_LDS_IDS + PF_LDS_X + (size_t)PF_ROWS * SMALL_SET_SLOTS * 2;  // 12 KiB: 13 waves per CU
 
 // exp(d), d <= 0, two at a time, as exp_nonpos_f32x2 with the rounding and the scaling done by the 1.5 * 2^23 trick
@@ -1307,9 +1308,10 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     }
     dim3 grid((unsigned)((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES)), block(PRUNE_WAVES * 64);
     const bool vec4 = a.dtype == 0 && (a.n_labels % 4) == 0 && a.n_labels <= 1024 && a.rows_aligned16;
-    // float32 rows of up to 2046 labels take the 64-rows-per-wave kernel whatever their count and alignment (16-byte loads
-    // when both allow them)
-    const bool f32_fast = a.dtype == 0 && a.n_labels <= (int)SMALL_SET_MAX_ID && a.rows_aligned4;
+    // float32 rows of up to 2048 labels (8 groups of four per lane) take the 64-rows-per-wave kernel whatever their count
+    // and alignment (16-byte loads when both allow them)
+    static_assert(PF_MAX_LABELS - 1 <= (int)SMALL_SET_MAX_ID, "label ids must fit the small set tables");
+    const bool f32_fast = a.dtype == 0 && a.n_labels <= PF_MAX_LABELS && a.rows_aligned4;
     const bool f32_al = (a.n_labels % 4) == 0 && a.rows_aligned16;
 #define CTC_LAUNCH_PRUNE(KERN)                                                                                 \
   do {                                                                                                         \
@@ -1477,7 +1479,14 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     HIP_TRY(hipGetLastError());
     g_last_kernel = 1;
   } else if (a.n_utts > 0) {
-    LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
+    // Eight waves per utterance instead of four when every CU holds at most one utterance (the LDS of a workgroup allows
+    // two per CU, the registers 2 x 256 threads or 1 x 512): measured on MI355X, 256 utterances x T=1000 -- BASELINE config 2
+    // (~2 500 candidates per frame) 84.2 -> 70.4 ms, the headline workload (a few dozen candidates) 12.1 -> 11.8 ms.
+    // That variant also takes its candidates in chunks of 1024 (it has the CU's LDS to itself). CTCDEC_GROUP_THREADS=256|512
+    // forces one.
+    const char* gt = getenv("CTCDEC_GROUP_THREADS");
+    const bool wide = a.tables.n_lms <= 1 && (gt ? gt[0] == '5' : a.n_utts <= g_cus);
+    LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv, group_cand(beam_bucket(a.params.beam_width), wide));
     size_t lds = lds_bytes(shape);
     if (lds > 160 * 1024) {
       if (err) *err = "beam table does not fit LDS (" + std::to_string(lds) + " bytes)";
@@ -1486,12 +1495,6 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     // Threads per utterance: four waves (measured on MI355X, 512 utterances, beam 100: 256 threads 13.0 ms,
     // 128 threads 15.2 ms, 64 threads 19.7 ms for this kernel).
     int rc;
-    // Eight waves per utterance instead of four when every CU holds at most one utterance (the LDS of a workgroup allows
-    // two per CU, the registers 2 x 256 threads or 1 x 512): measured on MI355X, 256 utterances x T=1000 -- BASELINE config 2
-    // (~2 500 candidates per frame) 84.2 -> 70.4 ms, the headline workload (a few dozen candidates) 12.1 -> 11.8 ms.
-    // CTCDEC_GROUP_THREADS=256|512 forces one.
-    const char* gt = getenv("CTCDEC_GROUP_THREADS");
-    const bool wide = gt ? gt[0] == '5' : a.n_utts <= g_cus;
     rc = launch_group(a, shape, lds, a.tables.n_lms > 1 ? 2 : (wide ? 1 : 0), g_stream, err);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());

@@ -75,13 +75,19 @@ CTC_HD size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 CTC_HD int beam_bucket(int beam_width) {  // beam-table capacities the kernel is instantiated for
   return beam_width <= 32 ? 32 : beam_width <= 64 ? 64 : beam_width <= 128 ? 128 : 256;
 }
-constexpr int CAND_CHUNK = 512;  // candidates merged per pass (>= 2 * largest beam bucket)
-CTC_HD LdsShape make_shape(int beam_width, int max_surv) {
+constexpr int CAND_CHUNK = 512;  // candidates merged per pass (>= 2 * largest beam bucket, >= 512: the pool's 1024-bucket histogram
+                                 // lives in the 2 * cand slots of the merge table)
+constexpr int CAND_CHUNK_WIDE = 1024;  // ... when a workgroup has a CU's LDS to itself (beam_decode<*, 512>: at most one
+                                       // utterance per CU). A frame of ~2 500 candidates (BASELINE configs[1]) takes 3 chunks and
+                                       // one pool compaction instead of 5 and 4.
+// candidates per chunk of the workgroup kernel's variants (host and device agree through this one rule)
+CTC_HD int group_cand(int bw_bucket, bool wide) { return wide && bw_bucket <= 128 ? CAND_CHUNK_WIDE : CAND_CHUNK; }
+CTC_HD LdsShape make_shape(int beam_width, int max_surv, int cand = CAND_CHUNK) {
   LdsShape s;
   s.bw = beam_bucket(beam_width);
-  s.cand = CAND_CHUNK;
-  s.pool = CAND_CHUNK + s.bw;  // one chunk of fresh candidates + the best beam_width kept so far
-  s.sortn = 1024;              // >= pool for every bucket (pool <= 768)
+  s.cand = cand;
+  s.pool = cand + s.bw;  // one chunk of fresh candidates + the best beam_width kept so far
+  s.sortn = 2 * cand;    // a power of two >= pool for every bucket (bw <= 256 <= cand)
   s.surv = (max_surv + 3) & ~3;
   return s;
 }
@@ -922,15 +928,22 @@ CTC_UNROLL
     uint32_t mask = (uint32_t)(2 * shape.cand - 1);
     uint64_t kt = L.ck_text[q], kp = L.ck_part[q];
     uint32_t g = q / group;
-    uint32_t slot = key_slot_hash(kt, kp, g) & mask;
+    // a slot holds  q + 1 (12 bits: cand <= 2048)  |  the hash's upper 20 bits: a candidate that finds the slot taken
+    // compares those first and reads the other's keys (two more dependent LDS round trips of the probe chain, which the
+    // slowest lane of the wave dictates) only when they agree
+    const uint32_t hsh = key_slot_hash(kt, kp, g);
+    uint32_t slot = hsh & mask;
+    const uint32_t mine = (q + 1) | (hsh & 0xFFFFF000u);
     for (;;) {
-      uint32_t old = ctx.atomic_cas(&L.table[slot], 0u, q + 1);
+      uint32_t old = ctx.atomic_cas(&L.table[slot], 0u, mine);
       if (old == 0) {
         if (my_slot) *my_slot = slot;
         return q;
       }
-      uint32_t r = old - 1;
-      if (L.ck_text[r] == kt && L.ck_part[r] == kp && r / group == g) return r;
+      if (((old ^ mine) & 0xFFFFF000u) == 0) {
+        const uint32_t r = (old & 0xFFFu) - 1;
+        if (L.ck_text[r] == kt && L.ck_part[r] == kp && r / group == g) return r;
+      }
       slot = (slot + 1) & mask;
     }
   }
@@ -1043,28 +1056,41 @@ CTC_UNROLL
       }
       for (uint32_t e = ctx.tid; e < n; e += ctx.nt) ctx.atomic_add(&L.table[bucket_of(e)], 1u);
       ctx.sync();
-      // 64 partial sums of 16 buckets each, then the boundary bucket
+      // 64 partial sums of 16 buckets each, then the boundary bucket. (Every loop below reads from addresses that do not
+      // depend on what it has read: unrolled, the LDS reads of a step are in flight together -- a thread that walks them
+      // one by one pays a round trip each, and these are the only threads at work.)
       for (uint32_t t = ctx.tid; t < 64u; t += ctx.nt) {
         uint32_t c = 0;
+#pragma unroll
         for (uint32_t k = 0; k < 16u; ++k) c += L.table[t * 16u + k];
         L.part[t] = c;
       }
       ctx.sync();
       for (uint32_t t = ctx.tid; t < 64u; t += ctx.nt) {
         uint32_t before = 0;
-        for (uint32_t k = 0; k < t; ++k) before += L.part[k];
+#pragma unroll
+        for (uint32_t k = 0; k < 64u; ++k) {
+          const uint32_t v = L.part[k];
+          before += k < t ? v : 0u;
+        }
         const uint32_t mine = L.part[t];
         if (before < want && want <= before + mine) {  // the want-th entry lies in my 16 buckets
-          uint32_t cum = before;
+          uint32_t h[16];
+#pragma unroll
+          for (uint32_t k = 0; k < 16u; ++k) h[k] = L.table[t * 16u + k];
+          uint32_t cum = before, bk = 0, bcum = 0;
+          bool found = false;
+#pragma unroll
           for (uint32_t k = 0; k < 16u; ++k) {
-            const uint32_t h = L.table[t * 16u + k];
-            if (cum + h >= want) {
-              L.scal[12] = t * 16u + k;
-              L.scal[13] = cum;
-              break;
+            if (!found && cum + h[k] >= want) {
+              found = true;
+              bk = k;
+              bcum = cum;
             }
-            cum += h;
+            cum += h[k];
           }
+          L.scal[12] = t * 16u + bk;
+          L.scal[13] = bcum;
         }
       }
       ctx.sync();
@@ -1090,16 +1116,45 @@ CTC_UNROLL
       }
       ctx.sync();
       for (uint32_t k = ctx.tid; k < 1024u; k += ctx.nt) L.table[k] = 0;  // hand the table back zeroed
-      // rank the `want` chosen entries among themselves
+      // rank the `want` chosen entries among themselves. Their keys are first copied side by side behind the sort
+      // buffer's entries (sortn - pool >= cand - bw >= want slots are free there), then the want x want comparisons are
+      // spread over all threads, four to a row, the partial counts summed where the list was.
+      LPtr<uint64_t> ca0, ca1;
+      ca0.p = L.s_k0.p + shape.pool;
+      ca1.p = L.s_k1.p + shape.pool;
       for (uint32_t i = ctx.tid; i < want; i += ctx.nt) {
         const uint32_t e = slist[i];
-        const uint64_t a0 = L.s_k0[e], a1 = L.s_k1[e];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < want; ++j) {
-          const uint32_t e2 = slist[j];
-          const uint64_t b0 = L.s_k0[e2], b1 = L.s_k1[e2];
-          rank += ((b0 < a0) || (b0 == a0 && b1 < a1)) ? 1u : 0u;
+        ca0[i] = L.s_k0[e];
+        ca1[i] = L.s_k1[e];
+        slist[i] = 0;  // (the list has served: from here on, the rank of entry i)
+      }
+      ctx.sync();
+      {
+        const uint32_t G = ctx.nt >= 4 ? 4u : 1u;  // threads per row
+        const uint32_t g = (uint32_t)ctx.tid % G, rows = (uint32_t)ctx.nt / G;
+        for (uint32_t i = (uint32_t)ctx.tid / G; i < want; i += rows) {
+          const uint64_t a0 = ca0[i], a1 = ca1[i];
+          uint32_t rank = 0;
+          uint32_t j = g;
+          for (; j + 3u * G < want; j += 4u * G) {  // four independent pairs of LDS reads in flight per step
+            const uint64_t b0 = ca0[j], b1 = ca0[j + G], b2 = ca0[j + 2u * G], b3 = ca0[j + 3u * G];
+            const uint64_t c0 = ca1[j], c1 = ca1[j + G], c2 = ca1[j + 2u * G], c3 = ca1[j + 3u * G];
+            rank += ((b0 < a0) || (b0 == a0 && c0 < a1)) ? 1u : 0u;
+            rank += ((b1 < a0) || (b1 == a0 && c1 < a1)) ? 1u : 0u;
+            rank += ((b2 < a0) || (b2 == a0 && c2 < a1)) ? 1u : 0u;
+            rank += ((b3 < a0) || (b3 == a0 && c3 < a1)) ? 1u : 0u;
+          }
+          for (; j < want; j += G) {
+            const uint64_t b0 = ca0[j], c0 = ca1[j];
+            rank += ((b0 < a0) || (b0 == a0 && c0 < a1)) ? 1u : 0u;
+          }
+          if (rank) ctx.atomic_add(&slist[i], rank);
         }
+      }
+      ctx.sync();
+      for (uint32_t i = ctx.tid; i < want; i += ctx.nt) {
+        const uint64_t a1 = ca1[i];
+        const uint32_t rank = slist[i];
         const uint32_t idx = (uint32_t)(a1 & 0xFFFFFFFFull);
         L.sel[rank] = idx;
         L.keep[rank] = 1u;

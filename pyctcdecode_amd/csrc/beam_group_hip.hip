@@ -82,9 +82,10 @@ __global__ __launch_bounds__(NT, NT > 256 ? 1 : 2) void beam_decode(BeamArgs a, 
   // compile-time layout: every LDS array sits at a constant offset (ds_* immediate offsets)
   LdsShape shape;
   shape.bw = BW;
-  shape.cand = CAND_CHUNK;
-  shape.pool = CAND_CHUNK + BW;
-  shape.sortn = 1024;
+  constexpr int CAND = BW <= 128 && NT > 256 ? CAND_CHUNK_WIDE : CAND_CHUNK;  // = group_cand(BW, NT > 256)
+  shape.cand = CAND;
+  shape.pool = CAND + BW;
+  shape.sortn = 2 * CAND;
   shape.surv = surv_cap;
   LdsView view;
   lds_carve(view, (lds_bytes_t)smem, shape);

@@ -1,4 +1,4 @@
-// set_order_small.h -- set_order.h for at most SMALL_SET_MAX_KEYS ascending ids below 2047, in 48 table slots.
+// set_order_small.h -- set_order.h for at most SMALL_SET_MAX_KEYS ascending ids below 4095, in 48 table slots.
 //
 // The same CPython 3.10 algorithm (Objects/setobject.c, restated in set_order.h: cpython_set_order), with every table
 // size it can reach for so few keys written out, so that one frame's tables fit 96 bytes and a wavefront can order 64
@@ -10,7 +10,7 @@
 //     keys take 32 slots again: the table itself;
 //   * before the argmax is added the copy is resized when (used + 1) * 5 >= mask * 3: only for 4 keys in 8 slots
 //     (-> 16 slots); adding the argmax never triggers another growth.
-// A slot holds  id | payload << 11  (id < 2047, payload < 32: the caller's index of that id), SMALL_SET_EMPTY when free; only the
+// A slot holds  id | payload << 12  (id < 4095, payload < 16: the caller's index of that id), SMALL_SET_EMPTY when free; only the
 // id takes part in hashing and comparison.
 // `Tab` is anything with  uint16_t get(uint32_t slot)  and  void put(uint32_t slot, uint16_t v)  over 48 slots:
 // X = slots [0, 16), Y = slots [16, 48).
@@ -25,10 +25,11 @@ namespace ctc {
 constexpr uint32_t SMALL_SET_MAX_KEYS = 15;
 constexpr uint32_t SMALL_SET_SLOTS = 48;
 constexpr uint16_t SMALL_SET_EMPTY = 0xFFFFu;
-constexpr uint32_t SMALL_SET_ARGMAX = 31;  // payload of an argmax that is not among the ids
-constexpr uint32_t SMALL_SET_ID_BITS = 11;  // ids < 2047 (id 2047 with the argmax payload would read as SMALL_SET_EMPTY)
+constexpr uint32_t SMALL_SET_ARGMAX = 15;  // payload of an argmax that is not among the ids (indices stop at 14)
+constexpr uint32_t SMALL_SET_ID_BITS = 12;  // ids < 4095 (id 4095 with the argmax payload would read as SMALL_SET_EMPTY)
 constexpr uint32_t SMALL_SET_ID_MASK = (1u << SMALL_SET_ID_BITS) - 1u;
 constexpr uint32_t SMALL_SET_MAX_ID = SMALL_SET_ID_MASK - 1u;
+static_assert(SMALL_SET_MAX_KEYS <= SMALL_SET_ARGMAX, "an index must not read as the argmax marker");
 
 struct SmallSet {
   uint32_t base, mask, used;

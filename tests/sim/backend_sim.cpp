@@ -255,7 +255,14 @@ static int launch_beam_kernels(const BeamArgs& a, std::string*) {
     return 0;
   }
   if (a.n_utts > 0) g_last_kernel = 2;
-  LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv);
+  // CTCDEC_SIM_CAND=512|1024|2048: the candidate chunk of the workgroup kernel (the device build takes 1024 for its
+  // 512-thread variant, 512 otherwise -- beam_core.h: group_cand)
+  int cand = CAND_CHUNK;
+  if (const char* e = getenv("CTCDEC_SIM_CAND")) {
+    const int v = atoi(e);
+    if (v == 512 || v == 1024 || v == 2048) cand = v;
+  }
+  LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv, cand);
   size_t bytes = lds_bytes(shape);
   std::vector<char> lds(bytes + 64);
   char* base = (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15);

@@ -76,7 +76,7 @@ def test_small_tables_give_the_order_of_a_real_set(lib):
     n_cases = 0
     for n in range(0, 16):
         for rep in range(400):
-            hi = [1024, 2047, 64, 40, 300][rep % 5]  # dense id ranges collide in the 8-slot table; ids go up to 2046
+            hi = [1024, 4095, 64, 40, 300, 2048][rep % 6]  # dense id ranges collide in the 8-slot table; ids go up to 4094
             ids = sorted(int(v) for v in rng.choice(hi, size=min(n, hi), replace=False))
             inside = n > 0 and rep % 3 != 0
             amax = int(rng.choice(ids)) if inside else int(rng.integers(0, hi))
@@ -84,8 +84,8 @@ def test_small_tables_give_the_order_of_a_real_set(lib):
             real = [int(k) for k in (set(ids) | {amax})]  # decoder.py:445-447
             assert got == real, (ids, amax)
             assert got == _big(lib, ids, amax)
-            for g, p in zip(got, pay):  # payloads: the index of the id, 31 for an argmax from outside
-                assert (p == 31 and g == amax and amax not in ids) or ids[p] == g
+            for g, p in zip(got, pay):  # payloads: the index of the id, 15 for an argmax from outside
+                assert (p == 15 and g == amax and amax not in ids) or ids[p] == g
             n_cases += 1
     assert n_cases == 16 * 400
 
@@ -97,6 +97,6 @@ def test_small_tables_on_runs_of_neighbouring_ids(lib):
             if start + n > 1024:
                 continue
             ids = list(range(start, start + n))
-            for amax in (0, start, start + n - 1 if n else 3, (start + 8) % 1024, (start + 32) % 1024, 1023, 2046):
+            for amax in (0, start, start + n - 1 if n else 3, (start + 8) % 1024, (start + 32) % 1024, 1023, 2047, 4094):
                 got, _ = _small(lib, ids, amax)
                 assert got == [int(k) for k in (set(ids) | {amax})], (ids, amax)

@@ -44,6 +44,20 @@ def test_flat_libri_beam100_chunks(seed, sim_library):  # noqa: F811
     _compare(synth.LIBRI_LABELS, None, x, dkw={"prune_history": bool(seed % 2)}, what="flat%d" % seed)
 
 
+@pytest.mark.parametrize("cand", [1024, 2048])
+@pytest.mark.parametrize("seed", range(3))
+def test_flat_libri_beam100_wide_candidate_chunks(seed, cand, sim_library, monkeypatch):  # noqa: F811
+    """The 512-thread variant of the workgroup kernel takes its candidates in chunks of 1024 (beam_core.h: group_cand): a
+    frame of ~2 500 candidates then runs through three chunks and one pool compaction (2048: two chunks)."""
+    monkeypatch.setenv("CTCDEC_BEAM_KERNEL", "group")
+    monkeypatch.setenv("CTCDEC_SIM_CAND", str(cand))
+    x = synth.d_flat(2, 20 + seed, 40, 29).astype(np.float64)
+    _compare(synth.LIBRI_LABELS, None, x, dkw={"prune_history": bool(seed % 2)}, what="flatwide%d_%d" % (cand, seed))
+    x = synth.d_flat(3, 30 + seed, 30, 29).astype(np.float64)
+    _compare(synth.LIBRI_LABELS, LM.path, x, dkw={"prune_history": bool(seed % 2), "beam_width": 128},
+             what="flatwidelm%d_%d" % (cand, seed))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_flat_libri_lm(seed, sim_library):  # noqa: F811
     x = synth.d_flat(3, seed, 30, 29).astype(np.float64)
