@@ -64,6 +64,7 @@ struct Surv {  // one surviving label of the current frame
 struct LdsShape {
   int bw;    // beam capacity (beam_width rounded up to 8)
   int cand;  // candidates per chunk
+  int tab;   // merge-table slots (a power of two >= 2 * cand)
   int pool;  // pool capacity
   int sortn; // sort-buffer entries (power of two >= pool)
   int surv;  // survivors per frame capacity
@@ -82,10 +83,14 @@ constexpr int CAND_CHUNK_WIDE = 1024;  // ... when a workgroup has a CU's LDS to
                                        // one pool compaction instead of 5 and 4.
 // candidates per chunk of the workgroup kernel's variants (host and device agree through this one rule)
 CTC_HD int group_cand(int bw_bucket, bool wide) { return wide && bw_bucket <= 128 ? CAND_CHUNK_WIDE : CAND_CHUNK; }
+// ... and the slots of their merge table: a quarter full at most where LDS is plentiful (linear probing: the longest probe
+// chain among a wave's 64 lanes sets the pace), half full otherwise
+CTC_HD int group_tab(int cand) { return cand > CAND_CHUNK ? 4 * cand : 2 * cand; }
 CTC_HD LdsShape make_shape(int beam_width, int max_surv, int cand = CAND_CHUNK) {
   LdsShape s;
   s.bw = beam_bucket(beam_width);
   s.cand = cand;
+  s.tab = group_tab(cand);
   s.pool = cand + s.bw;  // one chunk of fresh candidates + the best beam_width kept so far
   s.sortn = 2 * cand;    // a power of two >= pool for every bucket (bw <= 256 <= cand)
   s.surv = (max_surv + 3) & ~3;
@@ -99,7 +104,7 @@ struct LdsView {
   LPtr<uint64_t> ck_text, ck_part;
   LPtr<double> c_logit;
   LPtr<uint32_t> crep, rmin, rmax, rcnt;
-  LPtr<uint32_t> table;  // 2*cand slots, stores q+1
+  LPtr<uint32_t> table;  // shape.tab slots, stores q+1 | hash bits
   // pool of merged, scored candidates of the current frame
   LPtr<double> p_score, p_logit;
   LPtr<uint32_t> p_arr, p_don;
@@ -182,7 +187,7 @@ CTC_HD size_t lds_carve(LdsView& o, lds_bytes_t base, const LdsShape& s) {
   o.rmin = lds_take<uint32_t>(p, 4 * s.cand);
   o.rmax = lds_take<uint32_t>(p, 4 * s.cand);
   o.rcnt = lds_take<uint32_t>(p, 4 * s.cand);
-  o.table = lds_take<uint32_t>(p, 4 * 2 * s.cand);
+  o.table = lds_take<uint32_t>(p, 4 * s.tab);
   lds_bytes_t q = shared0;
   o.s_k0 = lds_take<uint64_t>(q, 8 * s.sortn);
   o.s_k1 = lds_take<uint64_t>(q, 8 * s.sortn);
@@ -919,13 +924,13 @@ CTC_UNROLL
   }
 
   CTC_HD void clear_table() {
-    for (int k = ctx.tid; k < 2 * shape.cand; k += ctx.nt) L.table[k] = 0;
+    for (int k = ctx.tid; k < shape.tab; k += ctx.nt) L.table[k] = 0;
   }
 
   // insert candidate q (keys already in ck_*); candidates of one label occupy `group` consecutive
   // indices and only merge with each other (the key contains last_char). Returns the representative.
   CTC_HD uint32_t table_insert(uint32_t q, uint32_t group, uint32_t* my_slot = nullptr) {
-    uint32_t mask = (uint32_t)(2 * shape.cand - 1);
+    uint32_t mask = (uint32_t)(shape.tab - 1);
     uint64_t kt = L.ck_text[q], kp = L.ck_part[q];
     uint32_t g = q / group;
     // a slot holds  q + 1 (12 bits: cand <= 2048)  |  the hash's upper 20 bits: a candidate that finds the slot taken
@@ -951,15 +956,16 @@ CTC_UNROLL
   // Select the pool entries with score >= thr, ordered by (score desc, arrival asc); L.sel[r] = pool
   // index of rank r for r < min(count, beam_width). Returns the count (may exceed beam_width).
   // Entries are first compacted (typically ~25 of ~100 survive the threshold); small sets are ranked by
-  // counting (one LDS sweep, no barriers), large ones by a bitonic network.
+  // counting (one LDS sweep, no barriers), large ones by a bucket histogram.
   // (scal[5], the compaction counter, is zero on entry: init() and the end of this function see to it.)
   // with_hist: also leave the history-prune key of rank r in hk_*[r] (decoder.py:250-254).
-  CTC_HD uint32_t sort_pool(uint32_t pool_n, double thr, bool with_hist) {
+  // !ordered: the caller wants the best min(count, beam_width) entries as a set -- a large set's sel[] then comes in any order.
+  CTC_HD uint32_t sort_pool(uint32_t pool_n, double thr, bool with_hist, bool ordered = true) {
     tick<17>();
     for (uint32_t k = ctx.tid; k < pool_n; k += ctx.nt) {
-      double sc = L.p_score[k];
+      const double sc = L.p_score[k];
       if (sc >= thr) {
-        uint32_t pos = ctx.atomic_add(&L.scal[5], 1u);
+        const uint32_t pos = ctx.atomic_add(&L.scal[5], 1u);
         L.s_k0[pos] = score_sort_key(sc);
         L.s_k1[pos] = ((uint64_t)L.p_arr[k] << 32) | k;
         if (with_hist && pos < 256u) {
@@ -1116,6 +1122,12 @@ CTC_UNROLL
       }
       ctx.sync();
       for (uint32_t k = ctx.tid; k < 1024u; k += ctx.nt) L.table[k] = 0;  // hand the table back zeroed
+      if (!ordered) {  // (uniform)
+        for (uint32_t i = ctx.tid; i < want; i += ctx.nt) L.sel[i] = (uint32_t)(L.s_k1[slist[i]] & 0xFFFFFFFFull);
+        ctx.sync();
+        if (ctx.tid == 0) L.scal[5] = 0;
+        return n;
+      }
       // rank the `want` chosen entries among themselves. Their keys are first copied side by side behind the sort
       // buffer's entries (sortn - pool >= cand - bw >= want slots are free there), then the want x want comparisons are
       // spread over all threads, four to a row, the partial counts summed where the list was.
@@ -1178,17 +1190,27 @@ CTC_UNROLL
     tick<6>();
     uint32_t pool_n = L.scal[0];
     double mx = sortable_to_max();
-    uint32_t n = sort_pool(pool_n, mx + prm.beam_prune_logp, false);
+    if (ctx.tid == 0) L.smax[3] = 0;  // (ordered before the atomics below by the barriers inside sort_pool)
+    uint32_t n = sort_pool(pool_n, mx + prm.beam_prune_logp, false, false);
     if (n > (uint32_t)prm.beam_width) n = (uint32_t)prm.beam_width;
-    // gather the survivors through the temp arrays, then rewrite the pool front
-    for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
-      uint32_t idx = L.sel[k];
-      L.g_score[k] = L.p_score[idx];
-      L.g_logit[k] = L.p_logit[idx];
-      L.g_arr[k] = L.p_arr[idx];
-      L.g_don[k] = L.p_don[idx];
-      L.g_wid[k] = L.p_wid[idx];
-      L.g_m2[k] = L.p_m2[idx];
+    // gather the survivors through the temp arrays, then rewrite the pool front; the lowest score kept is the one a later
+    // candidate has to beat
+    for (uint32_t k0 = 0; k0 < n; k0 += (uint32_t)ctx.nt) {  // (uniform trip count: a wave reduction inside)
+      const uint32_t k = k0 + (uint32_t)ctx.tid;
+      uint64_t low = 0;
+      if (k < n) {
+        uint32_t idx = L.sel[k];
+        const double sc = L.p_score[idx];
+        L.g_score[k] = sc;
+        L.g_logit[k] = L.p_logit[idx];
+        L.g_arr[k] = L.p_arr[idx];
+        L.g_don[k] = L.p_don[idx];
+        L.g_wid[k] = L.p_wid[idx];
+        L.g_m2[k] = L.p_m2[idx];
+        low = score_sort_key(sc);  // (grows as the score falls; never 0 for a finite score)
+      }
+      low = ctx.wave_max_u64(low);
+      if (ctx.is_wave_leader() && low != 0) ctx.atomic_max64(&L.smax[3], low);
     }
     ctx.sync();
     for (uint32_t k = ctx.tid; k < n; k += ctx.nt) {
@@ -1203,7 +1225,7 @@ CTC_UNROLL
       L.scal[0] = n;
       // from now on only a candidate that beats the current beam_width-th best can still matter: later
       // candidates arrive later, so an equal score ranks behind the beam_width entries kept here
-      if (n >= (uint32_t)prm.beam_width) L.smax[2] = asc_key(L.g_score[n - 1]);
+      if (n >= (uint32_t)prm.beam_width) L.smax[2] = ~L.smax[3];  // = asc_key(lowest score kept)
     }
     ctx.sync();
     clear_table();  // the gather temp may overlap the (all-zero between chunks) merge table

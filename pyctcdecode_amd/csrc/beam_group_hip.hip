@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NT, NT > 256 ? 1 : 2) void beam_decode(BeamArgs a, 
   shape.bw = BW;
   constexpr int CAND = BW <= 128 && NT > 256 ? CAND_CHUNK_WIDE : CAND_CHUNK;  // = group_cand(BW, NT > 256)
   shape.cand = CAND;
+  shape.tab = CAND > CAND_CHUNK ? 4 * CAND : 2 * CAND;  // = group_tab(CAND)
   shape.pool = CAND + BW;
   shape.sortn = 2 * CAND;
   shape.surv = surv_cap;
