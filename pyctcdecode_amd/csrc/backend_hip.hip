@@ -1214,7 +1214,25 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     }
   };
 
-  {
+  if constexpr (NC <= 4) {
+    // two rows in flight behind the one being worked on (three register buffers in rotation): at 13 waves per CU (LDS) and
+    // 4 KB a row, one row ahead leaves ~50 KB per CU on its way -- short of what ~8 TB/s times the memory latency asks for
+    Raw ra[NL], rb[NL], rc[NL];
+    load_row(row_lo, ra);
+    if (nrows > 1) load_row(row_lo + 1, rb);
+    for (int i = 0; i < nrows; i += 3) {
+      if (i + 2 < nrows) load_row(row_lo + i + 2, rc);
+      phase_a(i, ra);
+      if (i + 1 < nrows) {
+        if (i + 3 < nrows) load_row(row_lo + i + 3, ra);
+        phase_a(i + 1, rb);
+      }
+      if (i + 2 < nrows) {
+        if (i + 4 < nrows) load_row(row_lo + i + 4, rb);
+        phase_a(i + 2, rc);
+      }
+    }
+  } else {
     Raw ra[NL], rb[NL];
     load_row(row_lo, ra);
     for (int i = 0; i < nrows; i += 2) {

@@ -323,12 +323,17 @@ def test_hip_config5_streaming_64_streams(lm, bpe):
 
 def test_hip_half_precision_logits_in_place(lm, bpe):
     """fp16 / bf16 device logits are read in place (exact widening); the result must equal decoding the
-    same values handed over as fp32 (beams exactly, scores to 1e-6)."""
+    same values handed over as fp32 (beams exactly, scores to 1e-6) -- and the oracle's decode of those widened values
+    (the comparison with itself alone would only show that the widening is exact)."""
     import torch
 
+    from oracle.ctc_oracle import build_oracle
     from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd.alphabet import Alphabet
 
     dec = build_ctcdecoder(bpe, lm.path)
+    alpha = Alphabet.build_alphabet(bpe)
+    orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
     x = synth.d_words(4, 21, 300, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0)
     for dt in (torch.float16, torch.bfloat16):
         xh = torch.from_numpy(x).cuda().to(dt)
@@ -342,6 +347,11 @@ def test_hip_half_precision_logits_in_place(lm, bpe):
         for o, q in zip(a, b):
             assert abs(o.logit_score - q.logit_score) <= bound
             assert abs(o.lm_score - q.lm_score) <= bound
+        wide = xh.to(torch.float32).cpu().numpy()
+        with np.errstate(all="ignore"):
+            exp = orc.decode_beams(wide.astype(np.float64), prune_history=True)
+        expd = [{"text": e[0], "frames": [[w, int(f0), int(f1)] for w, (f0, f1) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a], expd, what="half %s" % dt, **_tol(wide))
 
 
 def test_hip_probability_rows_overflowing_the_survivor_bound():

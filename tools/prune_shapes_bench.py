@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from pyctcdecode_amd import build_ctcdecoder  # noqa: E402
 
 n, T = 512, 1000
-for V in (1024, 1025, 1027, 1280, 2044, 2047, 2048, 2052, 29, 32):
+for V in [int(v) for v in sys.argv[1:]] or (1024, 1025, 1027, 1280, 2044, 2047, 2048, 2052, 29, 32):
     dec = build_ctcdecoder([chr(0x4E00 + i) for i in range(V - 1)])
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn((n, T, V), device="cuda", generator=g) * 1.0
