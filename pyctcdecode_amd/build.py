@@ -18,7 +18,7 @@ HIP_FLAGS = {"beam_wave_hip.hip": ["-mllvm", "-disable-machine-licm"],
              # (the workgroup kernel: 238 -> 195 registers, 255 -> 138 scalar registers spilled to vector lanes)
              "beam_group_hip.hip": ["-mllvm", "-disable-machine-licm"]}
 HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "set_order_small.h", "backend.h", "host_tables.h", "np_sum.h",
-           "wave_ops_hip.h"]
+           "wave_ops_hip.h", "text_wave.h"]
 
 
 def hipcc() -> str:

@@ -22,6 +22,7 @@
 #include "set_order.h"
 #include "set_order_small.h"
 #include "np_sum.h"
+#include "text_wave.h"
 #include "wave_ops_hip.h"
 
 namespace ctc {
@@ -1442,21 +1443,54 @@ int launch_group(const BeamArgs& a, const LdsShape& shape, size_t lds, int kind,
 int launch_wave(const BeamArgs& a, hipStream_t stream, std::string* err);
 
 // decode_batch (params.texts_only): the best beam's text of every utterance, assembled on the device. One wave per
-// utterance: lane 0 walks the emission chain leaf to root and writes the UTF-8 bytes backwards into the utterance's
-// scratch area, the wave then copies them to a block of the text pool. A launch of its own, behind the beam kernel: all
-// the chain walks (a few hundred dependent loads each) run side by side instead of one at the tail of every beam wave.
+// utterance walks the emission chain leaf to root through LDS windows and writes the UTF-8 bytes into the utterance's
+// scratch area (text_wave.h), then copies them to a block of the text pool. A launch of its own, behind the beam kernel:
+// all the chain walks run side by side instead of one at the tail of every beam wave.
+struct TextGpuCtx {
+  int lane;
+  __device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+  __device__ __forceinline__ int clz64(uint64_t x) { return __clzll((long long)x); }
+  __device__ __forceinline__ uint32_t wave_excl_sum_u32(uint32_t v) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    return incl - v;
+  }
+  __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  }
+};
+
 __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[TEXT_LDS_BYTES];
   const int u = blockIdx.x;
   const int lane = threadIdx.x;
   if (a.n_out[u] == 0) return;
   OutBeam& ob = a.out[(size_t)u * a.out_stride];
   uint8_t* scratch = a.text_scratch + a.text_soff[u];
   const uint32_t cap = (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]);
-  uint32_t pos = 0, len = 0;
+  TextLds L;
+  text_lds_carve(L, (CTC_LDS char*)smem);
+  TextGpuCtx ctx{lane};
+  const uint32_t pos = wave_text_backwards(ctx, L, a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap,
+                                           (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]));
+  uint32_t len = cap - pos;
   unsigned long long base = 0;
   if (lane == 0) {
-    pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap, (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]));
-    len = cap - pos;
     base = atomicAdd(a.tok_pool_head + 1, (unsigned long long)len);
     if (base + len > a.text_pool_cap) {
       a.status[u] |= ST_TOK_OVERFLOW;
@@ -1467,9 +1501,8 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
     ob.tok_cnt = len;
     ob.pad[0] = (uint32_t)(base >> 32);
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the other lanes read what lane 0 wrote)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (every lane reads bytes other lanes wrote)
   __builtin_amdgcn_wave_barrier();
-  pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
   len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
   const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
   const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));

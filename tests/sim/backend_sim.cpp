@@ -13,6 +13,7 @@
 #include "../../pyctcdecode_amd/csrc/backend.h"
 #include "../../pyctcdecode_amd/csrc/beam_core.h"
 #include "../../pyctcdecode_amd/csrc/beam_wave.h"
+#include "../../pyctcdecode_amd/csrc/text_wave.h"
 #include "wave_fibers.h"
 #include "../../pyctcdecode_amd/csrc/set_order.h"
 #include "../../pyctcdecode_amd/csrc/np_sum.h"
@@ -221,7 +222,31 @@ static void assemble_texts(const BeamArgs& a) {
     OutBeam& ob = a.out[(size_t)u * a.out_stride];
     uint8_t* scratch = a.text_scratch + a.text_soff[u];
     const uint32_t cap = (uint32_t)(a.text_soff[u + 1] - a.text_soff[u]);
-    const uint32_t pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap, (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]));
+    const uint32_t n_nodes = (uint32_t)(a.emit_off[u + 1] - a.emit_off[u]);
+    // the wave's walk (text_wave.h, what the HIP build launches) on 64 fibers ...
+    std::vector<char> lds(TEXT_LDS_BYTES + 16);
+    memset(lds.data(), 0xCD, lds.size());
+    TextLds tl;
+    text_lds_carve(tl, (char*)(((uintptr_t)lds.data() + 15) & ~(uintptr_t)15));
+    uint32_t wave_pos[wavesim::LANES];
+    memset(scratch, 0xEE, cap);
+    wavesim::Wave wave;
+    wave.run([&](int lane) {
+      wavesim::SimWaveCtx ctx{lane, &wave, &a.tables, &a.params};
+      wave_pos[lane] = wave_text_backwards(ctx, tl, a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], scratch, cap, n_nodes);
+    });
+    // ... checked against the one-thread walk (beam_core.h) on every call
+    std::vector<uint8_t> seq(cap ? cap : 1, 0xEE);
+    const uint32_t pos = text_backwards(a.emit_nodes + a.emit_off[u], a.tables, ob.pad[1], seq.data(), cap, n_nodes);
+    for (int l = 0; l < wavesim::LANES; ++l)
+      if (wave_pos[l] != pos) {
+        fprintf(stderr, "sim: wave_text_backwards returns %u in lane %d, text_backwards %u (utterance %d)\n", wave_pos[l], l, pos, u);
+        abort();
+      }
+    if (memcmp(scratch + pos, seq.data() + pos, cap - pos) != 0) {
+      fprintf(stderr, "sim: wave_text_backwards and text_backwards write different bytes (utterance %d)\n", u);
+      abort();
+    }
     uint32_t len = cap - pos;
     unsigned long long base = a.tok_pool_head[1];
     if (base + len > a.text_pool_cap) {
