@@ -1514,11 +1514,12 @@ static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
 int last_beam_kernel() { return g_last_kernel; }
 
 int launch_beam(const BeamArgs& a, std::string* err) {
-  // Two kernels for the same recursion. One workgroup (4 waves) per utterance has the shorter frame
-  // (13.0 vs 14.9 us on the bench input) but only two utterances fit a CU; one wave per utterance keeps four
-  // (beam_width <= 104: five by LDS) resident and needs a quarter of the issue slots per utterance, so it wins as
-  // soon as there are more utterances than the workgroup kernel can hold at once (measured at 2048 utterances:
-  // 31 vs 48 ms). CTCDEC_BEAM_KERNEL=wave|group overrides the
+  // Two kernels for the same recursion. A lone utterance's frame takes about the same time in both (measured in round 4 on
+  // the bench input: 11.3 us on the workgroup kernel's eight waves, 11.4 us on one wave), but a CU holds two workgroups
+  // against sixteen waves and one wave needs an eighth of the issue slots per utterance: the wave kernel wins as soon as
+  // there are more utterances than the workgroup kernel can hold at once (512 utterances: 12.6 ms either way;
+  // 1024: 14.9 vs 24.4 ms; 4096: 19.3 ms). Dense frames are the exception: ~2 500 candidates a frame (BASELINE configs[1],
+  // 256 utterances) take 38 ms on the workgroup kernel and 160 ms on one wave. CTCDEC_BEAM_KERNEL=wave|group overrides the
   // batch-size rule (tests, tuning; `wave` still falls back when the decode is not eligible for it).
   const char* force = getenv("CTCDEC_BEAM_KERNEL");
   const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
@@ -1532,9 +1533,10 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   } else if (a.n_utts > 0) {
     // Eight waves per utterance instead of four when every CU holds at most one utterance (the LDS of a workgroup allows
     // two per CU, the registers 2 x 256 threads or 1 x 512): measured on MI355X, 256 utterances x T=1000 -- BASELINE config 2
-    // (~2 500 candidates per frame) 84.2 -> 70.4 ms, the headline workload (a few dozen candidates) 12.1 -> 11.8 ms.
-    // That variant also takes its candidates in chunks of 1024 (it has the CU's LDS to itself). CTCDEC_GROUP_THREADS=256|512
-    // forces one.
+    // (~2 500 candidates per frame) 84.2 -> 70.4 ms in round 3, the headline workload (a few dozen candidates) 12.1 -> 11.8 ms.
+    // That variant also takes its candidates in chunks of 1024 with a merge table of 4096 slots (it has the CU's LDS to
+    // itself): config 2 in 38 ms (round 4). Otherwise four waves (512 utterances, beam 100: 256 threads 13.0 ms, 128 threads
+    // 15.2 ms, 64 threads 19.7 ms for this kernel). CTCDEC_GROUP_THREADS=256|512 forces one.
     const char* gt = getenv("CTCDEC_GROUP_THREADS");
     const bool wide = a.tables.n_lms <= 1 && (gt ? gt[0] == '5' : a.n_utts <= g_cus);
     LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv, group_cand(beam_bucket(a.params.beam_width), wide));
@@ -1543,8 +1545,6 @@ int launch_beam(const BeamArgs& a, std::string* err) {
       if (err) *err = "beam table does not fit LDS (" + std::to_string(lds) + " bytes)";
       return -1;
     }
-    // Threads per utterance: four waves (measured on MI355X, 512 utterances, beam 100: 256 threads 13.0 ms,
-    // 128 threads 15.2 ms, 64 threads 19.7 ms for this kernel).
     int rc;
     rc = launch_group(a, shape, lds, a.tables.n_lms > 1 ? 2 : (wide ? 1 : 0), g_stream, err);
     if (rc) return rc;
