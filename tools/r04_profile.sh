@@ -32,3 +32,6 @@ grep "phase ticks" $out/phases4096.log
 CTCDEC_BEAM_KERNEL=wave timeout 300 python bench.py --batch 512 --phases $B --steps 3 > $out/phases512.json 2> $out/phases512.log
 grep "phase ticks" $out/phases512.log
 ls -la $out
+# randomised differential cases against the oracle on the HIP build (both beam kernels are drawn by the generator)
+FUZZ_BACKEND=hip timeout 400 python tools/fuzz_sim_vs_oracle.py 300 9201 > $out/fuzz_hip.log 2>&1
+tail -1 $out/fuzz_hip.log
