@@ -37,14 +37,17 @@ def main():
     }
     f, w = load("fetch_4096.json"), load("write_4096.json")
     d = {}
+    wk = {k.split("<")[0]: k for k in w}  # (the two passes are separate runs: match kernels by their plain names)
     for k in f:
         if k.startswith("__amd") or k.startswith("utt_sniff"):
             continue
         name = "frame_prune" if k.startswith("frame_prune_fast") else k.split("<")[0]
         raw = f[k]["FETCH_SIZE"] * KIB
+        wv = w[wk[k.split("<")[0]]]
+        assert wv["dispatches"] == f[k]["dispatches"] and wv["grid"] == f[k]["grid"], (k, wv, f[k])
         d[name] = {"kernel": k, "dispatches": f[k]["dispatches"], "grid": f[k]["grid"], "FETCH_SIZE_KiB_raw": f[k]["FETCH_SIZE"],
-                   "WRITE_SIZE_KiB_raw": w[k]["WRITE_SIZE"], "fetch_bytes_corrected": raw * 2 if name == "frame_prune" else raw,
-                   "write_bytes_raw": w[k]["WRITE_SIZE"] * KIB, "algorithmic_bytes": 4096 * 1000 * 1024 * 4.0}
+                   "WRITE_SIZE_KiB_raw": wv["WRITE_SIZE"], "fetch_bytes_corrected": raw * 2 if name == "frame_prune" else raw,
+                   "write_bytes_raw": wv["WRITE_SIZE"] * KIB, "algorithmic_bytes": 4096 * 1000 * 1024 * 4.0}
     out["batch_4096"] = d
     with open(os.path.join(SRC, "library.sha256")) as fh:
         out["binary_sha16"] = fh.read().split()[0][:16]  # of pyctcdecode_amd/libctcdec.so on the box that measured
@@ -63,7 +66,8 @@ def main():
                  "same with --batch 512 (the per-GPU shard of configs[3] over 8 GPUs; the launcher picks the workgroup kernel when "
                  "utterances <= 2 x CUs)\n" + stats(os.path.join(SRC, "kernel_stats_512.csv")) + "\n")
     for a, b in (("bench.json", "r04_bench.json"), ("bench.log", "r04_bench.log"), ("pytest_gpu.log", "r04_pytest_gpu.log"),
-                 ("phases512.log", "r04_phases_512.log"), ("phases4096.log", "r04_phases_4096.log")):
+                 ("phases512.log", "r04_phases_512.log"), ("phases4096.log", "r04_phases_4096.log"),
+                 ("fuzz_hip.log", "r04_fuzz_hip.log")):
         if os.path.exists(os.path.join(SRC, a)):
             shutil.copy(os.path.join(SRC, a), os.path.join(DST, b))
     print(open(os.path.join(DST, "r04_kernel_stats.txt")).read())
