@@ -15,6 +15,7 @@
 #include "../../pyctcdecode_amd/csrc/beam_wave.h"
 #include "../../pyctcdecode_amd/csrc/text_wave.h"
 #include "wave_fibers.h"
+#include "group_fibers.h"
 #include "../../pyctcdecode_amd/csrc/set_order.h"
 #include "../../pyctcdecode_amd/csrc/np_sum.h"
 
@@ -287,6 +288,16 @@ static int launch_beam_kernels(const BeamArgs& a, std::string*) {
     const int v = atoi(e);
     if (v == 512 || v == 1024 || v == 2048) cand = v;
   }
+  // CTCDEC_SIM_GROUP_THREADS=64|128|256|512: run the workgroup kernel on that many cooperative fibers instead of one
+  // sequential thread (barrier placement and every thread-count-dependent path as on the device; 512 also picks the
+  // device's wide candidate chunk unless CTCDEC_SIM_CAND says otherwise)
+  int group_threads = 0;
+  if (const char* e = getenv("CTCDEC_SIM_GROUP_THREADS")) {
+    const int v = atoi(e);
+    if (v == 64 || v == 128 || v == 256 || v == 512) group_threads = v;
+  }
+  if (group_threads == 512 && !getenv("CTCDEC_SIM_CAND") && a.tables.n_lms <= 1)
+    cand = group_cand(beam_bucket(a.params.beam_width), true);
   LdsShape shape = make_shape(a.params.beam_width, a.params.max_surv, cand);
   size_t bytes = lds_bytes(shape);
   std::vector<char> lds(bytes + 64);
@@ -299,6 +310,20 @@ static int launch_beam_kernels(const BeamArgs& a, std::string*) {
     UttIO io;
     fill_io(a, u, io);
     const uint32_t n_lms = a.tables.n_lms > 1 ? a.tables.n_lms : 1u;
+    if (group_threads > 0) {  // as many fibers as the device launch has threads (group_fibers.h)
+      static thread_local groupsim::Block block;
+      block.run(group_threads, [&](int tid) {
+        groupsim::GroupFiberCtx ctx{tid, group_threads, &block};
+        if (n_lms > 1) {
+          BeamDecoder<groupsim::GroupFiberCtx, true> dec(ctx, view, shape, a.tables, a.params, io);
+          dec.run();
+        } else {
+          BeamDecoder<groupsim::GroupFiberCtx, false> dec(ctx, view, shape, a.tables, a.params, io);
+          dec.run();
+        }
+      });
+      continue;
+    }
     SeqCtx ctx;
     if (n_lms > 1) {
       BeamDecoder<SeqCtx, true> dec(ctx, view, shape, a.tables, a.params, io);
