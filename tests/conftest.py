@@ -1,6 +1,11 @@
 import os
 import sys
 
+# /root/reference is read-only test input: no test process, and no child it starts, may leave bytecode next to its modules
+# (tests/test_reference_suite.py and the oracle's differential checks import them from where they lie)
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

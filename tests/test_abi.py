@@ -60,3 +60,55 @@ def test_product_never_imports_oracle_or_sim():
                 assert "import oracle" not in src and "from oracle" not in src, fn
                 assert "libctcdec_sim" not in src and "backend_sim" not in src.replace(
                     "tests/sim/backend_sim.cpp", ""), fn
+
+
+def _documented_build_commands():
+    """The by-hand build of INTEGRATION.md's "## Build" block: every command line after the `# or by hand` comment."""
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    block = doc[doc.index("## Build"):]
+    block = block[block.index("```bash") + len("```bash"):]
+    block = block[:block.index("```")]
+    lines = [ln.strip() for ln in block.splitlines()]
+    by_hand = lines[[i for i, ln in enumerate(lines) if ln.startswith("# or by hand")][0] + 1:]
+    return [ln for ln in by_hand if ln and not ln.startswith("#")]
+
+
+def test_documented_by_hand_build_links_and_exports_everything(tmp_path):
+    """INTEGRATION.md's by-hand build is run as written (cwd = a scratch directory, sources by absolute path, the library
+    into the scratch directory): it has to name every translation unit and flag pyctcdecode_amd/build.py uses, and what
+    it produces has to export the whole C ABI. (Round 4's text had fallen behind the build: it no longer linked.)"""
+    import shlex
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+
+    cmds = [shlex.split(c) for c in _documented_build_commands()]
+    assert len(cmds) == len(build_mod.SOURCES) + 1, cmds
+    out = str(tmp_path / "libctcdec.so")
+
+    def localise(cmd):
+        cmd = [a if not a.startswith("pyctcdecode_amd/csrc/") else os.path.join(ROOT, a) for a in cmd]
+        cmd = [out if a == "pyctcdecode_amd/libctcdec.so" else a for a in cmd]
+        if cmd[0] == "hipcc":
+            cmd[0] = build_mod.hipcc()
+        return cmd
+
+    compiles, link = [localise(c) for c in cmds[:-1]], localise(cmds[-1])
+    # the documented lines and build.py agree on sources and on the per-file flags
+    for src in build_mod.SOURCES:
+        mine = [c for c in compiles if c[c.index("-c") + 1].endswith("/" + src)]
+        assert len(mine) == 1, src
+        for flag in build_mod.HIP_FLAGS.get(src, []):
+            assert flag in mine[0], (src, flag)
+        if src.endswith(".hip"):
+            assert "--offload-arch=gfx950" in mine[0] and "-O3" in mine[0], mine[0]
+
+    def run(cmd):
+        r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True)
+        assert r.returncode == 0, (" ".join(cmd), r.stderr[-2000:])
+
+    with ThreadPoolExecutor(len(compiles)) as ex:
+        list(ex.map(run, compiles))
+    run(link)
+    lib = B.Library(out)  # raises AttributeError on a missing export
+    assert lib.dll.ctcdec_version().startswith(b"ctcdec")

@@ -5,8 +5,11 @@ is written there) with `pyctcdecode` aliased to `pyctcdecode_amd` and `kenlm.Mod
 Skipped where /root/reference does not exist (the GPU box).
 
 Excluded (each with its reason in EXCLUDED below): tests of the reference's private helpers and private
-attributes, the assertion that a multiprocessing pool was used, and one comparison of floats at 1e-15.
-Every other test of the reference's suite must pass unchanged -- 30 of the 40 do."""
+attributes -- 8 tests. Every other test of the reference's suite must pass -- 32 of the 40 do, among them
+test_decode_beams_batch, which compares OutputBeams with EXACT float equality (-2.853399551509947 /
+0.14660044849005294): the fp64 route sums the log-softmax normaliser in numpy's own order and reproduces them
+bit for bit. The one thing patched in the reference's test module is MockPool.map_has_run (see
+_neutralise_pool_assertion): `pool` is accepted and ignored here, one device launch decodes the batch."""
 import importlib
 import os
 import sys
@@ -32,12 +35,6 @@ EXCLUDED = {
     "TestLanguageModel.test_match_ptn": "private attribute _match_ptn",
     "TestLanguageModel.test_trie": "private attribute _char_trie",
     "TestHotwordScorer.test_fuzz_HotwordScorer": "constructor over the reference's internal regex + pygtrie objects",
-    # asserts that pool.map() was called: here `pool` is accepted and ignored (one device launch decodes the batch)
-    "TestDecoder.test_decode_batch": "asserts the multiprocessing pool was used",
-    # compares OutputBeams with exact float equality (-2.853399551509947 / 0.14660044849005294): those last digits
-    # are numpy's SIMD exp/log rounding; libm / ocml give -2.8533995515099497 / 0.14660044849005027 (3e-15 away).
-    # The same beams are checked to 1e-9 in tests/test_sim_golden.py (toy_lm_default) and on the GPU.
-    "TestDecoder.test_decode_beams_batch": "exact float equality at 1e-15 (+ pool.map assertion)",
 }
 
 
@@ -91,6 +88,7 @@ def _run(module_name):
     saved, added = _alias_modules()
     try:
         mod = importlib.import_module("pyctcdecode.tests." + module_name)
+        _neutralise_pool_assertion(mod)
         suite = unittest.defaultTestLoader.loadTestsFromModule(mod)
         res = unittest.TestResult()
         suite.run(res)
@@ -98,6 +96,22 @@ def _run(module_name):
     finally:
         _restore(saved, added)
         sys.dont_write_bytecode = old
+
+
+def _neutralise_pool_assertion(mod):
+    """The reference's decode_batch tests end with `assertTrue(pool.map_has_run)` (fork pool) / `assertFalse(...)` (spawn
+    pool, which the reference refuses to use, decoder.py:840-855): here a batch is ONE device launch and `pool` is accepted
+    and ignored.  Only that flag is patched -- it reads as what the reference would have set -- so that everything else
+    those tests assert (texts, and the exact floats of test_decode_beams_batch) runs against this package."""
+    pool_cls = getattr(mod, "MockPool", None)
+    spawn_cls = getattr(mod, "SpawnContext", None)
+    if pool_cls is None:
+        return
+
+    def _get(self):
+        return not (spawn_cls is not None and isinstance(self._ctx, spawn_cls))
+
+    pool_cls.map_has_run = property(_get, lambda self, v: None)
 
 
 def _name(test):
