@@ -142,6 +142,7 @@ _PROTOS = {
     "ctcdec_last_error": (C.c_char_p, []),
     "ctcdec_version": (C.c_char_p, []),
 }
+MAX_BEAM_WIDTH = 256  # CTCDEC_MAX_BEAM_WIDTH of include/ctcdec.h (tests/test_abi.py holds the two together)
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 

@@ -28,12 +28,65 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+_VERSIONS = {}
+
+
+def _tool_version(tool: str) -> str:
+    """First lines of `<tool> --version` (cached): part of every object's stamp, so that another compiler rebuilds."""
+    if tool not in _VERSIONS:
+        try:
+            out = subprocess.run([tool, "--version"], capture_output=True, text=True).stdout
+        except OSError:
+            out = "?"
+        _VERSIONS[tool] = " ".join(out.split()[:40])
+    return _VERSIONS[tool]
+
+
+def _compile_cmd(src: str, obj: str):
+    path = os.path.join(SRC, src)
+    if src.endswith(".hip"):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wno-unused-result"]
+        return cmd + HIP_FLAGS.get(src, []) + os.environ.get("CTCDEC_HIPCC_EXTRA", "").split() + ["-c", path, "-o", obj]
+    # pure host C++ (no HIP headers): ARPA parsing, table builders, C ABI
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    return [cxx, "-O2", "-std=c++17", "-fPIC", "-DNDEBUG", "-c", path, "-o", obj]
+
+
+def _stamp(cmd) -> str:
+    """What an object was built with: its full command line and the compiler's version. An object whose stamp differs
+    from what build() would run now is stale whatever its mtime says (changed flags, CTCDEC_HIPCC_EXTRA, CXX, a new ROCm)."""
+    import hashlib
+
+    # (paths relative to the package: the same tree under another root -- the GPU box's scratch copy -- is the same build)
+    line = " ".join(cmd).replace(HERE, "$PKG")
+    return hashlib.sha256((line + "\n" + _tool_version(cmd[0])).encode()).hexdigest()
+
+
+def _stamp_ok(obj: str, cmd) -> bool:
+    try:
+        with open(obj + ".stamp") as f:
+            return f.read().strip() == _stamp(cmd)
+    except OSError:
+        return False
+
+
+def _obj_dir() -> str:
+    return os.path.join(HERE, "csrc", "_obj")
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(SRC, f) for f in SOURCES + HEADERS + ["pytexts.c"]] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    # objects of another command line / compiler (only where objects exist: a tree that shipped just the library is as built)
+    for src in SOURCES:
+        obj = os.path.join(_obj_dir(), src + ".o")
+        if os.path.exists(obj) and not _stamp_ok(obj, _compile_cmd(src, obj)):
+            return True
+    return False
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -41,23 +94,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(PYTEXTS):
             build_pytexts(verbose)
         return OUT
-    obj_dir = os.path.join(HERE, "csrc", "_obj")
+    obj_dir = _obj_dir()
     os.makedirs(obj_dir, exist_ok=True)
-    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
     deps = [os.path.join(SRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
     newest_header = max(os.path.getmtime(d) for d in deps)
     jobs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src + ".o")
         objs.append(obj)
-        path = os.path.join(SRC, src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(path)):
-            continue  # this translation unit is up to date
-        if src.endswith(".hip"):
-            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DNDEBUG", "-Wno-unused-result"]
-            cmd += HIP_FLAGS.get(src, []) + os.environ.get("CTCDEC_HIPCC_EXTRA", "").split() + ["-c", path, "-o", obj]
-        else:  # pure host C++ (no HIP headers): ARPA parsing, table builders, C ABI
-            cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-DNDEBUG", "-c", path, "-o", obj]
+        cmd = _compile_cmd(src, obj)
+        if (not force and os.path.exists(obj) and _stamp_ok(obj, cmd) and
+                os.path.getmtime(obj) >= max(newest_header, os.path.getmtime(os.path.join(SRC, src)))):
+            continue  # this translation unit is up to date: same sources, same command line, same compiler
         jobs.append(cmd)
     from concurrent.futures import ThreadPoolExecutor
 
@@ -65,6 +113,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        with open(cmd[-1] + ".stamp", "w") as f:
+            f.write(_stamp(cmd))
 
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))  # (the translation units compile side by side; an error of any of them is raised here)

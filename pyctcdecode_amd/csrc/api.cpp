@@ -1098,7 +1098,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     // the wave kernel's payload lines (one per candidate a frame can push into its pool)
     ba.pay = nullptr;
     ba.pay_stride = 0;
-    if (wave_eligible(ba.tables, dp)) {
+    if (be::wave_kernel_chosen(ba)) {  // reserved only for launches that will use it (2 GB at the bench size)
       ba.pay_stride = (uint64_t)wave_pay_stride(dp);
       if (dec->w_pay.ensure((size_t)n_utts * (size_t)ba.pay_stride * sizeof(PoolPay), &err)) return fail(CTCDEC_ERR_DEVICE, err);
       ba.pay = (PoolPay*)dec->w_pay.p;

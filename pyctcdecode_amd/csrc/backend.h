@@ -121,6 +121,10 @@ struct BeamArgs {
                                // beams; import_xstates likewise), import_off is not used
 };
 int launch_beam(const BeamArgs& a, std::string* err);
+// Will launch_beam run the wave kernel on these arguments (given payload lines)? THE kernel-selection rule, shared by the
+// launcher and by the caller that reserves the wave kernel's scratch: eligibility, the carried-in beams, the batch-size
+// rule and the CTCDEC_BEAM_KERNEL override. `a.pay` itself is not looked at.
+bool wave_kernel_chosen(const BeamArgs& a);
 
 // stage timing (ms) of the last launch_prune / launch_beam pair, measured on the decode stream
 void last_timing(double* prune_ms, double* beam_ms);

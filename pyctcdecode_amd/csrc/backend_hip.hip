@@ -1513,6 +1513,13 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
 static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
 int last_beam_kernel() { return g_last_kernel; }
 
+bool wave_kernel_chosen(const BeamArgs& a) {
+  const char* force = getenv("CTCDEC_BEAM_KERNEL");
+  const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
+  // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
+  return a.n_utts > 0 && !want_group && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width);
+}
+
 int launch_beam(const BeamArgs& a, std::string* err) {
   // Two kernels for the same recursion. A lone utterance's frame takes about the same time in both (measured in round 4 on
   // the bench input: 11.3 us on the workgroup kernel's eight waves, 11.4 us on one wave), but a CU holds two workgroups
@@ -1521,11 +1528,8 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   // 1024: 14.9 vs 24.4 ms; 4096: 19.3 ms). Dense frames are the exception: ~2 500 candidates a frame (BASELINE configs[1],
   // 256 utterances) take 38 ms on the workgroup kernel and 160 ms on one wave. CTCDEC_BEAM_KERNEL=wave|group overrides the
   // batch-size rule (tests, tuning; `wave` still falls back when the decode is not eligible for it).
-  const char* force = getenv("CTCDEC_BEAM_KERNEL");
-  const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
-  // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
-  const bool wave_ok = wave_eligible(a.tables, a.params) && a.pay && a.max_import <= wave_bucket(a.params.beam_width);
-  if (a.n_utts > 0 && wave_ok && !want_group) {
+  const bool wave = a.pay && wave_kernel_chosen(a);
+  if (wave) {
     const int rc = launch_wave(a, g_stream, err);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());

@@ -1004,6 +1004,12 @@ class BeamSearchDecoderCTC:
             if not isinstance(beams, _ResidentBeams) and len(beams) == 0:
                 raise ValueError("a stream needs at least one beam (use get_starting_state())")
         params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, weight, 0)
+        # refused here, before any stream is opened, imported into or retired: the lists of the previous chunk stay readable
+        # (the library refuses the same values with the same exceptions, api.cpp: decode_impl)
+        if params.beam_width < 1:
+            raise ValueError("beam_width must be >= 1")
+        if params.beam_width > B.MAX_BEAM_WIDTH:
+            raise NotImplementedError("beam_width above the supported maximum of %d" % B.MAX_BEAM_WIDTH)
         lazy_ok = os.environ.get("CTCDEC_RESIDENT_STREAMS", "1") != "0"
         # which device streams do these beams belong to?
         streams: Optional[_DeviceStreams] = None
@@ -1029,11 +1035,6 @@ class BeamSearchDecoderCTC:
         first_frames = (C.c_int32 * n)(*[int(p) for p in processed_frames_list])
         want = bool(is_end) or not lazy_ok
         res = C.c_void_p()
-        if not 0 < params.beam_width <= 256:
-            # (refused by the library before anything runs: the lists of the previous chunk must stay readable)
-            self._lib.check(self._lib.dll.ctcdec_stream_push(
-                streams.handle, ptrs, frames, batch.dtype, int(batch.is_device), C.byref(params), first_frames,
-                int(bool(force_next_word)), int(bool(is_end)), int(want), C.byref(res)))
         streams.retire_lists()
         self._lib.check(self._lib.dll.ctcdec_stream_push(
             streams.handle, ptrs, frames, batch.dtype, int(batch.is_device), C.byref(params), first_frames,

@@ -432,130 +432,6 @@ class LanguageModel(AbstractLanguageModel):
         return cls(NgramModel(parts["kenlm"]), unigrams, **weights)
 
     def reset_params(self, **params: Dict[str, Any]) -> None:
-        """Reset some of the parameters in place."""
-
-
-class LanguageModel(AbstractLanguageModel):
-    """language_model.py:230-360 over an :class:`NgramModel`."""
-
-    def __init__(
-        self,
-        kenlm_model: Any,
-        unigrams: Optional[Collection[str]] = None,
-        alpha: float = DEFAULT_ALPHA,
-        beta: float = DEFAULT_BETA,
-        unk_score_offset: float = DEFAULT_UNK_LOGP_OFFSET,
-        score_boundary: bool = DEFAULT_SCORE_LM_BOUNDARY,
-    ) -> None:
-        if not isinstance(kenlm_model, NgramModel):
-            # a real kenlm.Model (or anything with .path): rebuild our own trie from its file
-            path = getattr(kenlm_model, "path", None)
-            if path is None:
-                raise TypeError("kenlm_model must be an NgramModel or expose a .path")
-            kenlm_model = NgramModel(path.decode("utf-8") if isinstance(path, bytes) else path)
-        # The reference treats kenlm.Model as immutable and builds many LanguageModels with different unigram sets
-        # on one (tests/test_decoder.py:188-280). Here the unigram set is part of the model's tables: the first
-        # LanguageModel configures the model it was given, every further one works on a private copy, so that
-        # earlier LanguageModels (and the decoders sharing their tables) keep their own OOV / partial-word scoring.
-        if kenlm_model._unigrams_owned:
-            kenlm_model = kenlm_model.private_copy()
-        kenlm_model._unigrams_owned = True
-        self._kenlm_model = kenlm_model
-        if unigrams is None:
-            logger.warning("No known unigrams provided, decoding results might be a lot worse.")
-            self._has_trie = False
-            self._given_unigrams = set()
-            self._n_unigrams = kenlm_model.set_unigrams(None)
-        else:
-            if len(unigrams) < 1000:
-                logger.warning(
-                    "Only %s unigrams passed as vocabulary. Is this small or artificial data?", len(unigrams)
-                )
-            self._has_trie = True
-            self._given_unigrams = set(unigrams)
-            self._n_unigrams = kenlm_model.set_unigrams(self._given_unigrams)
-            retained = 1.0 if len(unigrams) == 0 else self._n_unigrams / len(unigrams)
-            if retained < 0.1:
-                logger.warning(
-                    "Only %s%% of unigrams in vocabulary found in kenlm model-- this might mean that your "
-                    "vocabulary and language model are incompatible. Is this intentional?",
-                    round(retained * 100, 1),
-                )
-        self.alpha = alpha
-        self.beta = beta
-        self.unk_score_offset = unk_score_offset
-        self.score_boundary = score_boundary
-
-    # -- serialisation (language_model.py:362-452): a directory with exactly three files --------------
-    JSON_ATTRS = ("alpha", "beta", "unk_score_offset", "score_boundary")
-    _ATTRS_SERIALIZED_FILENAME = "attrs.json"
-    _UNIGRAMS_SERIALIZED_FILENAME = "unigrams.txt"
-
-    @property
-    def _unigram_set(self) -> Set[str]:
-        """Unigrams that survived the filter to the LM vocabulary (language_model.py:95)."""
-        return {w for w in self._given_unigrams if w in self._kenlm_model}
-
-    @property
-    def serializable_attrs(self) -> Dict[str, Any]:
-        attrs = {}
-        for name in LanguageModel.JSON_ATTRS:
-            val = getattr(self, name)
-            if val is None:
-                raise ValueError(f"attribute {name} not found. Cannot serialize")
-            attrs[name] = val
-        return attrs
-
-    def save_to_dir(self, filepath: str, unigram_encoding: Optional[str] = None) -> None:
-        import json
-        import os
-        import shutil
-
-        with open(os.path.join(filepath, self._ATTRS_SERIALIZED_FILENAME), "w") as fi:
-            json.dump(self.serializable_attrs, fi)
-        with open(os.path.join(filepath, self._UNIGRAMS_SERIALIZED_FILENAME), "w", encoding=unigram_encoding) as fi:
-            for unigram in sorted(self._unigram_set):
-                fi.write(unigram + "\n")
-        src = self._kenlm_model.path.decode("utf-8")
-        shutil.copy2(src, os.path.join(filepath, os.path.split(src)[1]))
-
-    @staticmethod
-    def parse_directory_contents(filepath: str) -> Dict[str, str]:
-        import os
-
-        contents = [c for c in os.listdir(filepath) if not c.startswith(".") and not c.startswith("__")]
-        if len(contents) != 3:
-            raise ValueError(f"Found wrong number of files in directory. Expected 3 files, found {contents}")
-        for needed, what in ((LanguageModel._ATTRS_SERIALIZED_FILENAME, "attributes"),
-                             (LanguageModel._UNIGRAMS_SERIALIZED_FILENAME, "unigrams")):
-            if needed not in contents:
-                raise ValueError(f"did not find {what} file in files: {contents}")
-            contents.remove(needed)
-        kenlm_file = contents[0]
-        if os.path.splitext(kenlm_file)[1] not in {".arpa", ".bin", ".binary", NgramModel.FLAT_SUFFIX}:
-            raise ValueError(f"Explected kenlm file to end in `.arpa` or `.bin(ary)`. Found {kenlm_file}")
-        return {
-            "json_attrs": os.path.join(filepath, LanguageModel._ATTRS_SERIALIZED_FILENAME),
-            "unigrams": os.path.join(filepath, LanguageModel._UNIGRAMS_SERIALIZED_FILENAME),
-            "kenlm": os.path.join(filepath, kenlm_file),
-        }
-
-    @classmethod
-    def load_from_dir(cls, filepath: str, unigram_encoding: Optional[str] = None) -> "LanguageModel":
-        import json
-
-        filenames = cls.parse_directory_contents(filepath)
-        with open(filenames["json_attrs"], "r") as fi:
-            json_attrs = json.load(fi)
-        if set(json_attrs.keys()) != set(cls.JSON_ATTRS):
-            raise ValueError(
-                f"Expected json serialized attributes to be {cls.JSON_ATTRS} but found {json_attrs.keys()}"
-            )
-        with open(filenames["unigrams"], "r", encoding=unigram_encoding) as fi:
-            unigrams = fi.read().splitlines()
-        return cls(NgramModel(filenames["kenlm"]), unigrams, **json_attrs)
-
-    def reset_params(self, **params: Dict[str, Any]) -> None:
         """language_model.py:271-301."""
         for name, typ, attr in (
             ("alpha", float, "alpha"),

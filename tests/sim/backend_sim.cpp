@@ -268,10 +268,13 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   if (rc == 0 && a.n_utts > 0 && a.params.texts_only && a.text_scratch) assemble_texts(a);
   return rc;
 }
-static int launch_beam_kernels(const BeamArgs& a, std::string*) {
+bool wave_kernel_chosen(const BeamArgs& a) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend (default here: wave)
   const bool want_group = force && force[0] == 'g';
-  if (a.n_utts > 0 && wave_eligible(a.tables, a.params) && a.pay && a.max_import <= wave_bucket(a.params.beam_width) && !want_group) {
+  return a.n_utts > 0 && !want_group && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width);
+}
+static int launch_beam_kernels(const BeamArgs& a, std::string*) {
+  if (a.pay && wave_kernel_chosen(a)) {
     switch (wave_bucket(a.params.beam_width)) {
       case 64: run_wave<64>(a); break;
       case 100: run_wave<100>(a); break;

@@ -112,3 +112,9 @@ def test_documented_by_hand_build_links_and_exports_everything(tmp_path):
     run(link)
     lib = B.Library(out)  # raises AttributeError on a missing export
     assert lib.dll.ctcdec_version().startswith(b"ctcdec")
+
+
+def test_python_limits_match_the_header():
+    with open(os.path.join(ROOT, "include", "ctcdec.h")) as f:
+        header = f.read()
+    assert int(re.search(r"#define\s+CTCDEC_MAX_BEAM_WIDTH\s+(\d+)", header).group(1)) == B.MAX_BEAM_WIDTH
