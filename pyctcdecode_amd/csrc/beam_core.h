@@ -305,11 +305,12 @@ constexpr int N_PROF = 24;
 // ---------------------------------------------------------------------------------------------
 CTC_HD uint64_t score_sort_key(double s) {
   // ascending key order == descending score order; -0.0 and +0.0 compare equal like in Python
-  if (s == 0.0) s = 0.0;
+  // (s + 0.0 turns -0.0 into +0.0 and leaves every other value alone; the sign then selects "flip all bits" / "flip the
+  // sign bit" through an arithmetic shift: five instructions instead of two compares and four selects)
   union { double d; uint64_t u; } c;
-  c.d = s;
-  uint64_t asc = (c.u >> 63) ? ~c.u : (c.u | (1ull << 63));
-  return ~asc;
+  c.d = s + 0.0;
+  const uint64_t m = (uint64_t)((int64_t)c.u >> 63);
+  return ~(c.u ^ (m | (1ull << 63)));
 }
 
 // decoder.py:170-177: s_hi + math.log(1 + math.exp(s_lo - s_hi)). exp and log are written out here (the same source on

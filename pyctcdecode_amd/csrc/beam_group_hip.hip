@@ -56,10 +56,7 @@ struct GpuCtx {
     return cmp;
   }
   // max over the 64 lanes of the calling wave (all lanes must call it)
-  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-    CTC_DPP_REDUCE(v, 0ull, comb_max_u64);
-    return bcast_lane63(v);
-  }
+  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) { return wave_max_u64_split(v); }
   __device__ __forceinline__ bool is_wave_leader() { return (threadIdx.x & 63) == 0; }
   __device__ __forceinline__ int wave_width() { return 64; }
   __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }

@@ -81,13 +81,15 @@ CTC_HD uint64_t q_hi(u32x4 v) { return pack64(v[2], v[3]); }
 
 CTC_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 
-// History of a text: its last n_hist word hashes (newest first) folded to 64 bits. The words are 61-bit
-// polynomial hashes: xor under distinct rotations keeps equal tuples equal and makes unequal ones collide with
-// probability ~2^-61 (no multiplies: this runs for every completed word).
+// History of a text: its last n_hist word hashes (newest first) folded to 64 bits. The words are packed pairs
+// of 31-bit polynomial hashes: xor under distinct rotations keeps equal tuples equal and makes unequal ones collide with
+// probability ~2^-62 (no multiplies: this runs for every completed word).
+// NH: the ring entries that can be in use (the decoder's context length: 3 for models up to order 4)
+template <int NH = MAX_CTX>
 CTC_HD uint64_t wave_hist_fold(const uint64_t* ring, uint32_t cnt) {
   uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(cnt + 1u);
 CTC_UNROLL
-  for (int k = 0; k < MAX_CTX; ++k)
+  for (int k = 0; k < NH; ++k)
     if ((uint32_t)k < cnt) h ^= rotl64(ring[k], 13 * k + 1);
   return h;
 }
@@ -304,13 +306,11 @@ struct WaveDecoder {
 
   // ---- small helpers -------------------------------------------------------------------------
   CTC_HD static uint64_t asc_key(double s) {
-    if (s == 0.0) s = 0.0;
-    const uint64_t u = f64_bits(s);
-    return (u >> 63) ? ~u : (u | (1ull << 63));
+    const uint64_t u = f64_bits(s + 0.0);  // (-0.0 -> +0.0: they compare equal in Python)
+    return u ^ ((uint64_t)((int64_t)u >> 63) | (1ull << 63));  // negative: every bit flipped; else the sign bit set
   }
   CTC_HD static double key_to_score(uint64_t u) {
-    const uint64_t bits = (u >> 63) ? (u & ~(1ull << 63)) : ~u;
-    return bits_f64(bits);
+    return bits_f64(u ^ (~(uint64_t)((int64_t)u >> 63) | (1ull << 63)));
   }
   CTC_HD uint32_t prefix_cnt(uint64_t m) const { return (uint32_t)ctx.popc64(m & ((1ull << lane) - 1ull)); }
   CTC_HD ColdRec* cold_cur() const { return io.cold + (size_t)par * COLD_STRIDE; }
@@ -449,7 +449,7 @@ CTC_UNROLL
       nn.ring[2] = 2u < rc ? sn.ring[1] : 0ull;
       nn.ring[3] = 3u < rc ? sn.ring[2] : 0ull;
       nn.ring[4] = 4u < rc ? sn.ring[3] : 0ull;
-      const uint64_t hh = wave_hist_fold(nn.ring, rc);
+      const uint64_t hh = wave_hist_fold<CTX>(nn.ring, rc);  // (rc <= n_hist <= CTX)
       node_store(idx, nn);
       L.c64[i * 2 + 1] = text_push(q_lo(k0), part_h);  // the completed text's hash: merge key of the candidates that close the word
       cr.c_lmhw = lmhw;

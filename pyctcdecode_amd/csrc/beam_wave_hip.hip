@@ -76,12 +76,10 @@ struct WaveGpuCtx {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), s);
     return ((uint64_t)hi << 32) | lo;
   }
-  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-    CTC_DPP_REDUCE(v, 0ull, comb_max_u64);
-    return bcast_lane63(v);
-  }
+  __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) { return wave_max_u64_split(v); }
   __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
     // (status bits: rare) any lane with a bit set makes it wave-wide
+    if (__ballot((v & 0xFFu) != 0u) == 0ull) return v;  // nothing raised (every frame but a handful): one ballot, not eight
     uint32_t r = 0;
 #pragma unroll
     for (int b = 0; b < 8; ++b)

@@ -20,44 +20,66 @@ namespace ctc {
 
 // ---------------------------------------------------------------------------------------------
 // String identity.  The reference keys every merge / memo on Python strings
-// (decoder.py:215-216, 250-254, 387, 399).  On device a string is its polynomial hash in the
-// Mersenne field p = 2^61-1 over UTF-8 bytes (+1 so that no byte is zero):
-//     H("") = 0,  H(s.c) = H(s)*BASE + (c+1),  H(s.t) = H(s)*BASE^|t| + H(t)   (all mod p)
-// Two distinct strings of <= L bytes collide with probability <= L/2^61 (random BASE).
+// (decoder.py:215-216, 250-254, 387, 399).  On device a string is a PAIR of polynomial hashes over its UTF-8 bytes
+// (+1 so that no byte is zero) in the Mersenne field p = 2^31-1, with two independent bases, packed into one 64-bit word
+// (low half: base 1, high half: base 2):
+//     H("") = 0,  H(s.c) = H(s)*BASE + (c+1),  H(s.t) = H(s)*BASE^|t| + H(t)   (each half mod p)
+// Two distinct strings of <= L bytes collide with probability <= (L/2^31)^2 (random bases): 2^-52 for 30-byte words.
+// (Rounds 1-4 used ONE polynomial mod 2^61-1: the same strength, but its 61 x 61-bit modular product is seven multiply-class
+// instructions and ~45 vector instructions per appended label on this hardware; two 31 x 31-bit ones are two and ~18.)
 // ---------------------------------------------------------------------------------------------
-constexpr uint64_t M61 = (1ull << 61) - 1;
-constexpr uint64_t STR_BASE = 0x1D2F5C8B3A4E6F71ull & M61;   // byte polynomial base
-constexpr uint64_t TEXT_BASE = 0x0B7E151628AED2A7ull & M61;  // word-sequence polynomial base
+constexpr uint32_t P31 = 0x7FFFFFFFu;
+constexpr uint32_t STR_BASE_1 = 0x3A4E6F71u & P31, STR_BASE_2 = 0x1D2F5C8Bu;  // byte polynomial bases (< p)
+constexpr uint64_t STR_BASE = ((uint64_t)STR_BASE_2 << 32) | STR_BASE_1;      // ... packed like a hash
 
-CTC_HD uint64_t mod61(uint64_t x) {
-  x = (x & M61) + (x >> 61);
-  return x >= M61 ? x - M61 : x;
+// x < 2^32 - 1 -> its canonical residue (x - p wraps to a huge value when x < p: the minimum is x)
+CTC_HD uint32_t mod31(uint32_t x) {
+  const uint32_t y = x - P31;
+  return y < x ? y : x;
 }
-
-CTC_HD uint64_t mulmod61(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  uint64_t hi = __umul64hi(a, b);
-  uint64_t lo = a * b;
-#else
-  unsigned __int128 pr = (unsigned __int128)a * b;
-  uint64_t hi = (uint64_t)(pr >> 64);
-  uint64_t lo = (uint64_t)pr;
-#endif
-  // a,b < 2^61 -> product < 2^122: hi < 2^58
-  uint64_t r = (lo & M61) + ((lo >> 61) | (hi << 3));
-  return mod61(r);
+CTC_HD uint32_t mulmod31(uint32_t a, uint32_t b) {  // a, b < p
+  const uint64_t t = (uint64_t)a * b;               // < 2^62
+  return mod31(((uint32_t)t & P31) + (uint32_t)(t >> 31));
 }
+CTC_HD uint32_t addmod31(uint32_t a, uint32_t b) { return mod31(a + b); }  // a, b < p
 
-CTC_HD uint64_t addmod61(uint64_t a, uint64_t b) { return mod61(a + b); }
-
-// H(s . t) from H(s), BASE^|t|, H(t)
+// H(s . t) from H(s), BASE^|t|, H(t)   (all three packed pairs)
 CTC_HD uint64_t str_concat(uint64_t hs, uint64_t pow_t, uint64_t ht) {
-  return addmod61(mulmod61(hs, pow_t), ht);
+  const uint32_t lo = addmod31(mulmod31((uint32_t)hs, (uint32_t)pow_t), (uint32_t)ht);
+  const uint32_t hi = addmod31(mulmod31((uint32_t)(hs >> 32), (uint32_t)(pow_t >> 32)), (uint32_t)(ht >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// H(s . c) for one byte c
+CTC_HD uint64_t str_push_byte(uint64_t hs, unsigned char c) {
+  const uint64_t one = (uint64_t)c + 1u;
+  return str_concat(hs, STR_BASE, (one << 32) | one);
 }
 
-// text' = text (+) word : position-sensitive polynomial over word hashes (+1: words are non-empty)
+CTC_HD uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+// One step of a 64-bit state (two 32-bit halves) absorbing a 32-bit / 64-bit value: two 32-bit multiply-xorshift rounds, the
+// second half keyed by the first. For a fixed input the step is a bijection of the state (each half is a bijection of itself
+// given the other), so two different histories can only meet by accident (~2^-64). Written in 32-bit halves because that is
+// what the hardware multiplies at full width in one instruction: a 64 x 64 -> 64 multiply is three multiply-class
+// instructions and a 61-bit modular one seven; a step here is two (round 4 spent 74 of a word completion's ~310 vector
+// instructions hashing n-gram keys with 64-bit finalisers and 50 on the text's modular polynomial).
+CTC_HD uint64_t mix_step(uint64_t state, uint32_t x_lo, uint32_t x_hi) {
+  uint32_t a = (uint32_t)state, b = (uint32_t)(state >> 32);
+  a = (a ^ x_lo) * 0x9E3779B1u;
+  a ^= a >> 15;
+  b = ((b + x_hi) ^ a) * 0x85EBCA6Bu;
+  b ^= b >> 13;
+  return ((uint64_t)b << 32) | a;
+}
+
+// text' = text (+) word : a position-sensitive chain over word hashes (the words are polynomial string hashes, 2 x 31 bits;
+// appending the same word to different texts keeps them different, appending different words to one text gives different
+// texts unless the step collides). Only ever compared for equality, and computed by this one function on the host
+// (imported streaming beams, api.cpp) and on the device.
 CTC_HD uint64_t text_push(uint64_t text_h, uint64_t word_h) {
-  return addmod61(mulmod61(text_h, TEXT_BASE), addmod61(word_h, 1));
+  const uint64_t s1 = mix_step(text_h, (uint32_t)word_h, (uint32_t)(word_h >> 32));
+  // (a second absorption of the word, halves swapped: every bit of the word reaches both halves of the state through a multiply)
+  return mix_step(s1, (uint32_t)(word_h >> 32) + 0x7F4A7C15u, (uint32_t)word_h);
 }
 
 CTC_HD uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
@@ -77,15 +99,16 @@ CTC_HD uint32_t key_slot_hash(uint64_t text_h, uint64_t part_h, uint32_t ch) {
 // n-gram key: a chain over the word ids NEWEST FIRST (the scored word, then its context going back), so the
 // keys of all orders of one query share their prefix: key_n = end(push(...push(push(begin, w_n), w_{n-1})..., w_1), n)
 // costs one mix per order instead of one per word per order.  Never 0 (0 marks an empty slot).  The key is a
-// mixed value already: its low bits are the table slot.
+// mixed value already: its low bits are the table slot. (Round 5: the per-word step is mix_step -- two 32-bit multiplies --
+// instead of a splitmix64 finaliser; the host checks every loaded model for colliding keys with an independent hash.)
 CTC_HD uint64_t ngram_key_begin() { return 0x243F6A8885A308D3ull; }
-CTC_HD uint64_t ngram_key_push(uint64_t k, uint32_t id) { return mix64(k ^ (uint64_t)id) + 0x13198A2E03707344ull; }
+CTC_HD uint64_t ngram_key_push(uint64_t k, uint32_t id) { return mix_step(k, id, rotl32(id, 16)); }
 CTC_HD uint64_t ngram_key_end(uint64_t k, uint32_t n) {
   k ^= (uint64_t)n << 56;
   return k == 0 ? 1 : k;
 }
 
-// slot hash of the prefix / hot-word tables (keys are 61-bit polynomial string hashes): fold to 32 bits, one
+// slot hash of the prefix / hot-word tables (keys are polynomial string hashes, 2 x 31 bits): fold to 32 bits, one
 // multiply, one xor-shift so that the low bits used for the slot depend on all of the key
 CTC_HD uint64_t table_slot(uint64_t key) {
   uint32_t x = (uint32_t)key ^ (uint32_t)(key >> 32);

@@ -11,13 +11,13 @@ namespace ctc {
 
 uint64_t hash_bytes(const char* s, size_t n) {
   uint64_t h = 0;
-  for (size_t i = 0; i < n; ++i) h = addmod61(mulmod61(h, STR_BASE), (uint64_t)(unsigned char)s[i] + 1);
+  for (size_t i = 0; i < n; ++i) h = str_push_byte(h, (unsigned char)s[i]);
   return h;
 }
 
 uint64_t pow_base(size_t nbytes) {
-  uint64_t r = 1;
-  for (size_t i = 0; i < nbytes; ++i) r = mulmod61(r, STR_BASE);
+  uint64_t r = (1ull << 32) | 1ull;  // BASE^0 in both halves
+  for (size_t i = 0; i < nbytes; ++i) r = str_concat(r, STR_BASE, 0);
   return r;
 }
 
@@ -110,18 +110,24 @@ static std::string strip(const std::string& s) {
 }
 
 struct RawGram {
-  uint64_t key;
+  uint64_t key, chk;
   float prob, backoff;
 };
 
-static void table_put(std::vector<NgramEntry>& tab, uint64_t mask, uint64_t key, float p, float b) {
+// chk: a second, independent 64-bit hash of the same word-id tuple (kept only while the table is built). Two entries with one
+// key and different check values are two DIFFERENT n-grams whose keys collide: the model is refused rather than scored
+// wrongly (the key is all the device compares). An n-gram listed twice in the file overwrites itself, as before.
+static bool table_put(std::vector<NgramEntry>& tab, std::vector<uint64_t>& chk_tab, uint64_t mask, uint64_t key, uint64_t chk,
+                      float p, float b) {
   uint64_t s = key & mask;
   for (;;) {
     if (tab[s].key == 0 || tab[s].key == key) {
+      if (tab[s].key == key && chk_tab[s] != chk) return false;
       tab[s].key = key;
       tab[s].prob = p;
       tab[s].backoff = b;
-      return;
+      chk_tab[s] = chk;
+      return true;
     }
     s = (s + 1) & mask;
   }
@@ -219,9 +225,13 @@ std::string HostLM::load_arpa(const std::string& path) {
       }
       unigrams[id] = UnigramEntry{prob, backoff};
     } else {
-      uint64_t k = ngram_key_begin();  // newest word first (common.h)
-      for (int j = section - 1; j >= 0; --j) k = ngram_key_push(k, index(toks[j]));
-      raw.push_back(RawGram{ngram_key_end(k, (uint32_t)section), prob, backoff});
+      uint64_t k = ngram_key_begin(), chk = 0x6A09E667F3BCC909ull;  // newest word first (common.h)
+      for (int j = section - 1; j >= 0; --j) {
+        const uint32_t id = index(toks[j]);
+        k = ngram_key_push(k, id);
+        chk = mix64(chk ^ (uint64_t)id) + 0x13198A2E03707344ull;
+      }
+      raw.push_back(RawGram{ngram_key_end(k, (uint32_t)section), chk ^ (uint64_t)section, prob, backoff});
     }
   }
   free(buf);
@@ -237,7 +247,12 @@ std::string HostLM::load_arpa(const std::string& path) {
   std::vector<NgramEntry>& ngram_table = ngr->table;
   ngram_table.assign(size, NgramEntry{0, 0.f, 0.f});
   ngram_mask = size - 1;
-  for (const RawGram& g : raw) table_put(ngram_table, ngram_mask, g.key, g.prob, g.backoff);
+  {
+    std::vector<uint64_t> chk_table(size, 0);
+    for (const RawGram& g : raw)
+      if (!table_put(ngram_table, chk_table, ngram_mask, g.key, g.chk, g.prob, g.backoff))
+        return "two different n-grams of " + path + " hash to one 64-bit key: refusing the model (not scoring it wrongly)";
+  }
   bos_id = index("<s>");
   eos_id = index("</s>");
   in_uniset.assign(words.size(), 0);
@@ -249,7 +264,7 @@ std::string HostLM::load_arpa(const std::string& path) {
 
 // ---- flat model file: "CTCDLM01" | order, n_words, bos, eos (u32) | n_ngrams, table_size, blob_bytes (u64)
 //      | word end offsets u64[n_words] | word bytes | UnigramEntry[n_words] | NgramEntry[table_size] | "CTCDEND1"
-static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '2'};  // 02: n-gram keys newest-first, slot = key & mask
+static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '3'};  // 03: n-gram keys by mix_step (02: splitmix chain), newest-first, slot = key & mask
 static const char kCacheEnd[8] = {'C', 'T', 'C', 'D', 'E', 'N', 'D', '1'};
 
 std::string HostLM::save_cache(const std::string& path) const {
@@ -356,7 +371,7 @@ void HostLM::build_prefix_table() {
     uint64_t h = 0;
     size_t pos = 0;
     for (size_t b : bounds) {
-      for (; pos < b; ++pos) h = addmod61(mulmod61(h, STR_BASE), (uint64_t)(unsigned char)w[pos] + 1);
+      for (; pos < b; ++pos) h = str_push_byte(h, (unsigned char)w[pos]);
       PrefixEntry& e = m[h];
       e.key = h;
       if (in_uniset[id]) e.flags |= PF_UNI_PREFIX;
@@ -422,7 +437,7 @@ void HostMulti::build() {
     uint64_t h = 0;
     size_t pos = 0;
     for (size_t b : bounds) {
-      for (; pos < b; ++pos) h = addmod61(mulmod61(h, STR_BASE), (uint64_t)(unsigned char)w[pos] + 1);
+      for (; pos < b; ++pos) h = str_push_byte(h, (unsigned char)w[pos]);
       PrefixEntry& e = m[h];
       e.key = h;
       e.flags |= pbits;
@@ -480,7 +495,7 @@ void HostHotwords::build(const std::vector<std::string>& uni, const HostAlphabet
     uint64_t h = 0;
     size_t pos = 0;
     for (size_t b : bounds) {
-      for (; pos < b; ++pos) h = addmod61(mulmod61(h, STR_BASE), (uint64_t)(unsigned char)w[pos] + 1);
+      for (; pos < b; ++pos) h = str_push_byte(h, (unsigned char)w[pos]);
       auto it = m.find(h);
       if (it == m.end()) {
         m.emplace(h, HotEntry{h, wl, b == w.size() ? 1u : 0u});

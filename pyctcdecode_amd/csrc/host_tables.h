@@ -14,7 +14,7 @@
 namespace ctc {
 
 uint64_t hash_bytes(const char* s, size_t n);                 // H(s)
-uint64_t pow_base(size_t nbytes);                             // STR_BASE^nbytes mod p
+uint64_t pow_base(size_t nbytes);                             // STR_BASE^nbytes (both halves, packed)
 uint32_t utf8_length(const char* s, size_t n);                // code points
 // byte offsets of every code-point boundary after the first code point, including n
 void utf8_boundaries(const char* s, size_t n, std::vector<size_t>* out);

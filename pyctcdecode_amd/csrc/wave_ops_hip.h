@@ -40,6 +40,33 @@ __device__ __forceinline__ uint64_t comb_max_f64(uint64_t a, uint64_t b) {
   return (uint64_t)__double_as_longlong(fmax(__longlong_as_double((long long)a), __longlong_as_double((long long)b)));
 }
 __device__ __forceinline__ uint64_t comb_max_u64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+// Wave-wide maximum of 32-bit unsigned values: the compiler folds each step into ONE v_max_u32_dpp (lanes a step has no source
+// for read 0, the identity) -- six VALU instructions and a v_readlane.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  int x = (int)v;
+#define CTC_MAX_STEP(CTRL, ROWS, BOUND)                                                              \
+  {                                                                                                  \
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xf, BOUND);          \
+    x = (int)(o > (uint32_t)x ? o : (uint32_t)x);                                                    \
+  }
+  CTC_MAX_STEP(0x111, 0xf, true)
+  CTC_MAX_STEP(0x112, 0xf, true)
+  CTC_MAX_STEP(0x114, 0xf, true)
+  CTC_MAX_STEP(0x118, 0xf, true)
+  CTC_MAX_STEP(0x142, 0xa, false)
+  CTC_MAX_STEP(0x143, 0xc, false)
+#undef CTC_MAX_STEP
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+// Wave-wide maximum of 64-bit unsigned values as two 32-bit ones: the high words, then the low words of the lanes that hold the
+// highest high word (~17 VALU instructions; the 64-bit DPP reduction is six rounds of two moves, a 64-bit compare and two
+// selects plus the moves that fill the lanes without a source: ~45).
+__device__ __forceinline__ uint64_t wave_max_u64_split(uint64_t v) {
+  const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+  const uint32_t mh = wave_max_u32(hi);
+  const uint32_t ml = wave_max_u32(hi == mh ? lo : 0u);
+  return ((uint64_t)mh << 32) | ml;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_min_i32(int v) {
   const int o = __builtin_amdgcn_update_dpp(0x7FFFFFFF, v, CTRL, ROW_MASK, 0xf, false);
