@@ -210,16 +210,18 @@ CTC_HD size_t lds_bytes(const LdsShape& s) {
 
 // wave kernel (beam_wave.h): what the candidate passes do not read per (label, beam) lives outside LDS, two buffers of
 // COLD_STRIDE records per utterance used alternately by the table builds
-struct ColdRec {  // 64 B
+struct ColdRec {  // 64 B = four 16-byte chunks; a candidate reads ONE of the first two (one load): chunk 0 when its label
+                  // closes the beam's open word, chunk 1 otherwise
   double c_lmhw;           // lm + hot-word score of text (+) open word, once that completion exists (M2_COMP)
+  uint64_t c_hist_h;       // hash of the last n_hist words of that completion
   double pscore;           // partial score of the open word
   uint64_t hist_h;         // hash of the text's last n_hist words (decoder.py:250-251)
-  uint64_t c_hist_h;       // ... of the completion
   uint32_t cnode;          // TextNode of the completion
   uint32_t enode;          // end of the beam's emission chain
   int32_t pstart, pend;    // partial_frames of the open word
   uint32_t depth;          // emission nodes on the beam's chain
-  uint32_t tnode;          // text node of the beam's completed words
+  uint32_t tnode;          // text node of the beam's completed words (the wave kernel also keeps it in the beam's LDS column C
+                           // while the open word has no completion)
   uint32_t wid;            // word id of the open word in the LM vocabulary (0: none / not a word)
   uint32_t pad;
 };

@@ -105,7 +105,9 @@ CTC_HD uint64_t fin64(uint64_t x) {
 // ---- layout ------------------------------------------------------------------------------------------------
 // A live beam, LDS part: three columns of 16-byte words
 //   A: text_h, part_h          B: logit, meta1, meta2          C: lm_hw, c_text_h (the text with the open word closed: valid
-//                                                                    with M2_COMP; the merge key of a candidate that closes it)
+//                                                                    with M2_COMP; the merge key of a candidate that closes it;
+//                                                                    WITHOUT M2_COMP its low word is the beam's text node, which
+//                                                                    the completion starts from -- no trip to the ColdRec first)
 // meta1 = last label | code points of the open word << 16; meta2 = prefix-table / hot-word view of the open word, plus
 // M2_COMP: the completion of the open word (text (+) word: its TextNode, scores and history hash) exists in the beam's
 // ColdRec. The rest of the beam is its ColdRec in global memory (beam_core.h).
@@ -241,6 +243,33 @@ struct WaveDecoder {
   // from where the compiler spills them to vector-register lanes and pays a v_readlane per use.
   CTC_HD const DeviceTables& tab() const { return ctx.tables(); }
   CTC_HD const DecodeParams& prm() const { return ctx.params(); }
+  // ... except the dozen that EVERY candidate pass reads (round 5): a scalar load is a ~70-cycle round trip through the scalar
+  // cache that the wave sits out (it issues in order), a pass had ten of them, and a wave's frame is bound by such waits, not
+  // by instruction issue (tools/micro/valu_rates.hip). These are fetched once per launch and held -- in scalar registers, or
+  // spilled to a vector-register lane, where the reload is one v_readlane.
+  struct Hot {
+    const PrefixEntry* prefixes;
+    uint64_t prefix_mask;
+    const HotEntry* hot;
+    uint64_t hot_mask;
+    double prune_logp, hot_weight, unk;
+    uint32_t has_lm, has_trie, prune_history, beam_width;
+  } H;
+  CTC_HD void load_hot() {
+    const DeviceTables& T_ = tab();
+    const DecodeParams& P_ = prm();
+    H.prefixes = T_.prefixes;
+    H.prefix_mask = T_.prefix_mask;
+    H.hot = T_.hot;
+    H.hot_mask = T_.hot_mask;
+    H.prune_logp = P_.beam_prune_logp;
+    H.hot_weight = P_.hot_weight;
+    H.unk = P_.unk;
+    H.has_lm = T_.has_lm ? 1u : 0u;
+    H.has_trie = T_.has_trie ? 1u : 0u;
+    H.prune_history = P_.prune_history ? 1u : 0u;
+    H.beam_width = (uint32_t)P_.beam_width;
+  }
 
   // ---- text nodes -------------------------------------------------------------------------------
   // One node per completed-words prefix (the reference's memo entry, decoder.py:387-396): the raw LM score sum, the
@@ -422,12 +451,13 @@ CTC_UNROLL
         idx = io.text_cap - 1;
       }
       ColdRec& cr = cold_cur()[i];
-      const u32x4 w3 = ((const u32x4a*)&cr)[3];  // {depth, text node, word id}
-      const uint32_t wid = w3[2], m2 = k1[3];
+      // the source node's index sits in the beam's column C (no completion yet: see the layout), so the node and the word id
+      // are fetched side by side: two dependent round trips for a completion (node, n-gram probes) instead of three
+      const uint32_t wid = cr.wid, m2 = k1[3];
       const u32x4 k0 = L.hA[i];
       const uint64_t part_h = q_hi(k0);
       Node sn;
-      node_load(w3[1], sn);
+      node_load(L.c32[i * 4 + 2], sn);
       double raw = sn.raw;
       LmState out = sn.st;
       if (T_.has_lm) {
@@ -452,8 +482,7 @@ CTC_UNROLL
       const uint64_t hh = wave_hist_fold<CTX>(nn.ring, rc);  // (rc <= n_hist <= CTX)
       node_store(idx, nn);
       L.c64[i * 2 + 1] = text_push(q_lo(k0), part_h);  // the completed text's hash: merge key of the candidates that close the word
-      cr.c_lmhw = lmhw;
-      cr.c_hist_h = hh;
+      ((u32x4a*)&cr)[0] = mk4q(f64_bits(lmhw), hh);  // {c_lmhw, c_hist_h}: one store
       cr.cnode = idx;
       L.b32[i * 4 + 3] = m2 | M2_COMP;
     }
@@ -556,7 +585,7 @@ CTC_UNROLL
   CTC_HD uint32_t rank_pool(double thr, bool with_hist) {
     if (pool_n > 64u) filter_pool(thr);  // (heavy frames: usually back to one entry per lane)
     const uint32_t n = pool_n;
-    const uint32_t want = (uint32_t)prm().beam_width;
+    const uint32_t want = H.beam_width;
     const uint64_t thr_key = score_sort_key(thr);
     // pad the list to a multiple of four (n <= P, P % 4 == 0: the slots exist)
     if (lane < 3 && (n & 3u) != 0u && n + (uint32_t)lane < ((n + 3u) & ~3u)) L.pk[n + (uint32_t)lane] = mk4q(~0ull, 0ull);
@@ -585,9 +614,8 @@ CTC_UNROLL
   // later, so an equal score ranks behind the >= beam_width entries kept here. (Many exactly equal scores around the
   // cut: the full ranking decides.)
   CTC_HD void compact_pool() {
-    const DecodeParams& P_ = prm();
-    filter_pool(key_to_score(runmax) + P_.beam_prune_logp);
-    const uint32_t n = pool_n, want = (uint32_t)P_.beam_width;
+    filter_pool(key_to_score(runmax) + H.prune_logp);
+    const uint32_t n = pool_n, want = H.beam_width;
     if (n <= want) {
       tick<W_PROF_COMPACT>();
       return;
@@ -629,10 +657,9 @@ CTC_UNROLL
     tick<W_PROF_COMPACT>();
   }
   CTC_HD void compact_pool_ranked() {
-    const DecodeParams& P_ = prm();
     const double mx = key_to_score(runmax);
-    uint32_t n = rank_pool(mx + P_.beam_prune_logp, false);
-    if (n > (uint32_t)P_.beam_width) n = (uint32_t)P_.beam_width;
+    uint32_t n = rank_pool(mx + H.prune_logp, false);
+    if (n > H.beam_width) n = H.beam_width;
     u32x4 g0[SLB];
     uint64_t g1[SLB];
 CTC_UNROLL
@@ -656,7 +683,7 @@ CTC_UNROLL
       }
     }
     pool_n = n;
-    if (n >= (uint32_t)P_.beam_width) {
+    if (n >= H.beam_width) {
       const uint32_t r = n - 1;
       uint64_t k = 0;
 CTC_UNROLL
@@ -678,17 +705,14 @@ CTC_UNROLL
     uint32_t pp_wid, pp_fl, ph_min, ph_cmp;
     double lg;
     double wd;    // of the candidate's beam (ColdRec): the pending completion's lm + hot-word score when the label closes the
-    uint64_t wh;  // open word, else the open word's partial score; and the history hash that goes with the branch;
-    uint32_t cwid;  // ... and the open word's id (what a blank / repeat keeps)
+    uint64_t wh;  // open word, else the open word's partial score; and the history hash that goes with the branch
   };
 
   // branch, merge key and summed logit of candidate (label l of the staged block = survivor s, beam i);
-  // FULL: also the first probe of the prefix / hot-word table of an appended partial word and the request for the two
-  // words of the beam's ColdRec its score will need.
+  // FULL: also the first probe of the prefix / hot-word table of an appended partial word and the request for the chunk
+  // of the beam's ColdRec its score will need.
   template <bool FULL>
   CTC_HD void gen(Cand& c, bool valid, uint32_t l, uint32_t s, uint32_t i) {
-    const DeviceTables& T_ = tab();
-    const DecodeParams& P_ = prm();
     // Straight-line: a lane without a candidate computes on label 0 / beam 0 (its fields are only looked at behind
     // `valid`), and every branch of the reference's if-ladder (decoder.py:452-534) is a select.
     const uint32_t ll = valid ? l : 0u, ii = valid ? i : 0u;
@@ -735,28 +759,27 @@ CTC_UNROLL
     c.pp_wid = c.pp_fl = c.ph_min = c.ph_cmp = 0;
     c.wd = 0.0;
     c.wh = 0;
-    c.cwid = 0;
     if (FULL) {  // first probe of the prefix / hot-word table of an appended partial word
       const bool probe = valid && app && p != 0;
       c.tslot = (uint32_t)table_slot(p);
-      c.want_p = probe && (k1[3] & PF_ON_TABLE) && T_.prefixes;
-      c.want_h = probe && (k1[3] & M2_HOT_ON) && T_.hot;
+      c.want_p = probe && (k1[3] & PF_ON_TABLE) && H.prefixes;
+      c.want_h = probe && (k1[3] & M2_HOT_ON) && H.hot;
       if (c.want_p) {
-        const PrefixEntry& g = T_.prefixes[c.tslot & T_.prefix_mask];
+        const PrefixEntry& g = H.prefixes[c.tslot & H.prefix_mask];
         c.pp_key = g.key;
         c.pp_wid = g.word_id;
         c.pp_fl = g.flags;
       }
       if (c.want_h) {
-        const HotEntry& g = T_.hot[c.tslot & T_.hot_mask];
+        const HotEntry& g = H.hot[c.tslot & H.hot_mask];
         c.ph_key = g.key;
         c.ph_min = g.min_len;
         c.ph_cmp = g.complete;
       }
-      const ColdRec* cr = cold_cur() + ii;
-      c.wd = *(closing_word ? &cr->c_lmhw : &cr->pscore);
-      if (P_.prune_history) c.wh = *(closing_word ? &cr->c_hist_h : &cr->hist_h);
-      c.cwid = cr->wid;
+      // one 16-byte load: chunk 0 {completion's score, its history hash} or chunk 1 {partial score, the text's history hash}
+      const u32x4 cw = ((const u32x4a*)(cold_cur() + ii))[closing_word ? 0 : 1];
+      c.wd = bits_f64(q_lo(cw));
+      c.wh = q_hi(cw);
     }
     // (a real finaliser: the hashes of one-character strings differ in their low bits only, and the match tag drops seven bits)
     c.ck = fin64(kt ^ rotl64(p, 17) ^ ((uint64_t)(l + 1u) << 56));
@@ -856,19 +879,18 @@ CTC_UNROLL
     uint32_t pf, nw, hmin, hcomp;
   };
   CTC_HD TabView resolve_tables(const Cand& c) {
-    const DeviceTables& T_ = tab();
     TabView t;
     t.on = t.hon = false;
     t.pf = t.nw = t.hmin = t.hcomp = 0;
     if (c.is_rep && c.br == BR_APPEND) {
       const uint64_t key = c.kp;
       if (c.want_p) {
-        uint64_t sp = c.tslot & T_.prefix_mask;
+        uint64_t sp = c.tslot & H.prefix_mask;
         uint64_t ek = c.pp_key;
         uint32_t nw = c.pp_wid, pf = c.pp_fl;
         while (ek != key && ek != 0) {
-          sp = (sp + 1) & T_.prefix_mask;
-          const PrefixEntry& g = T_.prefixes[sp];
+          sp = (sp + 1) & H.prefix_mask;
+          const PrefixEntry& g = H.prefixes[sp];
           ek = g.key;
           nw = g.word_id;
           pf = g.flags;
@@ -878,12 +900,12 @@ CTC_UNROLL
         t.pf = pf;
       }
       if (c.want_h) {
-        uint64_t sh = c.tslot & T_.hot_mask;
+        uint64_t sh = c.tslot & H.hot_mask;
         uint64_t ek = c.ph_key;
         uint32_t hmin = c.ph_min, hcomp = c.ph_cmp;
         while (ek != key && ek != 0) {
-          sh = (sh + 1) & T_.hot_mask;
-          const HotEntry& g = T_.hot[sh];
+          sh = (sh + 1) & H.hot_mask;
+          const HotEntry& g = H.hot[sh];
           ek = g.key;
           hmin = g.min_len;
           hcomp = g.complete;
@@ -898,17 +920,24 @@ CTC_UNROLL
 
   // partial_score (beam_core.h: language_model.py:141-150, 326-336; decoder.py:363-367, 397-409) as selects, for the
   // single-model kernel: same operations in the same order.
-  CTC_HD static double partial_score_sel(const DeviceTables& T_, const DecodeParams& P_, uint32_t pf_flags, uint32_t hot_min_len,
-                                         uint32_t plen) {
+  CTC_HD double partial_score_sel(uint32_t pf_flags, uint32_t hot_min_len, uint32_t plen) const {
     const double pl = (double)plen;
     double s = 0.0;
-    if (T_.has_lm) {  // (uniform)
-      const bool on_trie = T_.has_trie && (pf_flags & PF_UNI_PREFIX);
-      s = P_.unk * (on_trie ? 0.0 : 1.0);
+    if (H.has_lm) {  // (uniform)
+      const bool on_trie = H.has_trie && (pf_flags & PF_UNI_PREFIX);
+      s = H.unk * (on_trie ? 0.0 : 1.0);
       s = plen > 6 ? div_by_6(s * pl) : s;
     }
-    if (hot_min_len > 0) s = P_.hot_weight * pl / (double)hot_min_len;  // (a real division: behind a branch, ~30 instructions)
+    if (hot_min_len > 0) s = H.hot_weight * pl / (double)hot_min_len;  // (a real division: behind a branch, ~30 instructions)
     return s;
+  }
+
+  // total_score (beam_core.h; decoder.py:363-367, 398-409, 420) on the held has_lm flag
+  CTC_HD double total_score_h(double logit, double lm_hw, double ps, uint32_t plen) const {
+    if (!H.has_lm) return logit + lm_hw + ps;
+    double s = lm_hw;
+    if (plen > 0) s = s + ps;
+    return logit + s;
   }
 
   // one pool entry per flagged lane, in lane order; its payload goes to the frame's next free payload line
@@ -935,8 +964,6 @@ CTC_UNROLL
   // score the representatives of a pass (decoder.py:346-424) and push what can still matter into the pool;
   // imax / dbr: the group's donor (last arrival: its beam, its branch)
   CTC_HD void score_push(const Cand& c, const TabView& t, uint32_t imax, uint32_t dbr) {
-    const DeviceTables& T_ = tab();
-    const DecodeParams& P_ = prm();
     // Straight-line (selects, LDS reads at safe indices). Lanes that represent nothing compute on beam 0 / label 0
     // and are masked at the end.
     const bool rep = c.is_rep;
@@ -958,21 +985,23 @@ CTC_UNROLL
                          ((t.hon && t.hcomp) ? M2_HOT_COMPLETE : 0u) | (a_hmin << 8);
     const uint32_t q_pl = is0 ? c.pl0 : (isB ? len_clean : (isA ? c.pl0 + c.len_raw : 0u));
     const uint32_t q_m2 = is0 ? (c.m2_0 & ~M2_COMP) : (isB ? m2B : (isA ? m2A : EMPTY_PARTIAL_M2));
-    const uint32_t q_wid = is0 ? c.cwid : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t.on ? t.nw : 0u) : 0u));
-    const double ps_new = partial_score_sel(T_, P_, isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
+    // (a blank / repeat keeps its beam's open word and with it the word's id: the table build reads it from that beam's ColdRec
+    //  -- bit 31 + the beam -- instead of every candidate lane fetching it here)
+    const uint32_t q_wid = is0 ? (0x80000000u | c.bi) : (isB ? (len_clean > 0 ? lc[2] : 0u) : (isA ? (t.on ? t.nw : 0u) : 0u));
+    const double ps_new = partial_score_sel(isB ? lc[1] : a_pf, isB ? hminB : a_hmin, q_pl);
     const double q_ps = is0 ? c.wd : ((bw || isA) ? ps_new : 0.0);  // (blank / repeat: the open word's score as it is)
     const double lmhw = (!is0 && !isA && c.pl0 > 0) ? c.wd : own_lmhw;  // boundary / space close the open word
-    const double sc = total_score(T_, c.lg, lmhw, q_ps, q_pl);
+    const double sc = total_score_h(c.lg, lmhw, q_ps, q_pl);
     const double score = rep ? sc : 0.0;
     const uint64_t my_key = rep ? asc_key(sc) : 0ull;
     const uint64_t pass_key = ctx.wave_max_u64(my_key);
     if (pass_key > runmax) runmax = pass_key;
-    const double thr = key_to_score(runmax) + P_.beam_prune_logp;
+    const double thr = key_to_score(runmax) + H.prune_logp;
     tick<W_PROF_SCORE>();
     // (history, partial, last_char) folded to 64 bits (decoder.py:250-254): equality of the folds stands in
     // for equality of the triple (its members are 61/64-bit string hashes already)
     uint64_t hk = 0;
-    if (P_.prune_history) hk = c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40);  // (compared for equality only)
+    if (H.prune_history) hk = c.wh ^ rotl64(c.kp, 19) ^ ((uint64_t)(c.lid + 1u) << 40);  // (compared for equality only)
     const u32x4 e0 = mk4q(~my_key, hk);  // (score_sort_key(score) == ~asc_key(score); lanes that push are representatives)
     const uint32_t blank = (c.mw >> 16) & TK_BLANK;
     const uint32_t arrival = c.ls * (uint32_t)N + c.bi;
@@ -1180,11 +1209,11 @@ CTC_UNROLL
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
         nl[j] = lg[j] + p;
-        sc[j] = total_score(T_, nl[j], rest[j], psc[j], pl[j]);
+        sc[j] = total_score_h(nl[j], rest[j], psc[j], pl[j]);
         if (live[j]) L.scr[j * 64 + lane] = sc[j];
       }
       ctx.wsync();
-      const double thr = L.scr[0] + P_.beam_prune_logp;
+      const double thr = L.scr[0] + H.prune_logp;
       bool bad = false;
 CTC_UNROLL
       for (int j = 0; j < SLB; ++j) {
@@ -1341,8 +1370,8 @@ CTC_UNROLL
     TokRegs tr;
     tok_load(tr);
     tick<W_PROF_PFTOK>();
-    const double thr = key_to_score(runmax) + prm().beam_prune_logp;
-    const bool hist = prm().prune_history != 0;
+    const double thr = key_to_score(runmax) + H.prune_logp;
+    const bool hist = H.prune_history != 0;
 #ifdef CTC_WAVE_TRACE
     if ((uint32_t)lane < pool_n) {
       const u32x4 t0 = L.pk[lane];
@@ -1354,7 +1383,7 @@ CTC_UNROLL
 #ifdef CTC_STATS
     if (lane == 0) fprintf(stderr, "ST %d %u %u %u\n", N, ns, pool_n, n);
 #endif
-    if (n > (uint32_t)prm().beam_width) n = (uint32_t)prm().beam_width;
+    if (n > H.beam_width) n = H.beam_width;
     tick<W_PROF_RANK>();
     // nothing passed the threshold: only possible with non-finite scores (NaN rows) or a positive
     // beam_prune_logp; the reference then dies on max([]) (decoder.py:545) -- reported through the status
@@ -1381,8 +1410,6 @@ CTC_UNROLL
   // the columns of one rank (w = its L.sel word, d = its place in the new table); also writes the beam's ColdRec
   // and, for a label that is not a blank / repeat, its emission node. All lanes call.
   CTC_HD void gather(int frame, uint32_t w, bool kept, uint32_t d, Rec& o) {
-    const DeviceTables& T_ = tab();
-    const DecodeParams& P_ = prm();
     o.o0 = o.o1 = o.o2 = mk4(0, 0, 0, 0);
     // the payload is the donor's (the last-arriving duplicate, decoder.py:221-223), its branch included
     uint64_t a2 = 0;
@@ -1400,14 +1427,18 @@ CTC_UNROLL
     uint32_t depth = w3[0];
     const u32x4 k0 = L.hA[i], k1 = L.hB[i], k2 = L.hC[i];
     const uint32_t pl = k1[2] >> 16;
-    uint64_t th = q_lo(k0), hh = q_lo(w1);
+    uint64_t th = q_lo(k0), hh = q_hi(w1);
     const uint64_t ph = q_hi(e1);  // the new partial word's hash (unchanged for a blank / repeat)
     uint64_t lmhw = q_lo(k2), cth = q_hi(k2);
-    uint64_t clm = q_lo(w0), chh = q_hi(w1);
+    uint64_t clm = q_lo(w0), chh = q_hi(w0);
     uint32_t tnode = w3[1], cnode = w2[0], enode = w2[1];
     int32_t pst = (int32_t)w2[2], pen = (int32_t)w2[3];
     uint32_t m2 = e2[2] & ~M2_COMP;
-    const uint32_t wid = e2[1];
+    uint32_t wid = e2[1];
+    if (wid & 0x80000000u) {  // the open word of the beam that kept it (score_push): mostly the donor itself
+      const uint32_t rb = wid & 0xFFu;
+      wid = rb == i ? w3[2] : cold_cur()[rb].wid;
+    }
     const uint32_t npl = e2[0];
     if (b == 0) {
       if (!(don & (1u << 29))) pen = frame + 1;  // a repeated label extends the open word (decoder.py:453-461)
@@ -1435,7 +1466,7 @@ CTC_UNROLL
       cnode = 0;
       clm = 0;
       chh = 0;
-      cth = 0;
+      cth = (uint64_t)tnode;  // (no completion of the new open word yet: column C carries the text node, see the layout)
       if (e >= io.emit_cap) {
         status |= ST_EMIT_OVERFLOW;
         e = io.emit_cap - 1;
@@ -1445,10 +1476,10 @@ CTC_UNROLL
       depth += 1;
     }
     double ps = 0.0;
-    if (npl > 0) ps = partial_score_sel(T_, P_, m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
+    if (npl > 0) ps = partial_score_sel(m2 & PF_PARTIAL_MASK, (m2 & M2_HOT_ON) ? ((m2 >> 8) & 0xFFFFu) : 0u, npl);
     u32x4a* nr = (u32x4a*)&cold_next()[d];
-    nr[0] = mk4q(clm, f64_bits(ps));
-    nr[1] = mk4q(hh, chh);
+    nr[0] = mk4q(clm, chh);
+    nr[1] = mk4q(f64_bits(ps), hh);
     nr[2] = mk4(cnode, enode, (uint32_t)pst, (uint32_t)pen);
     nr[3] = mk4(depth, tnode, wid, 0u);
     o.o0 = mk4q(th, ph);
@@ -1526,7 +1557,7 @@ CTC_UNROLL
     const uint64_t lgb = f64_bits(logit), lmb = f64_bits(lm_hw);
     L.hA[i] = mk4q(text_h, part_h);
     L.hB[i] = mk4((uint32_t)lgb, (uint32_t)(lgb >> 32), meta1, meta2 & ~M2_COMP);
-    L.hC[i] = mk4((uint32_t)lmb, (uint32_t)(lmb >> 32), 0u, 0u);
+    L.hC[i] = mk4((uint32_t)lmb, (uint32_t)(lmb >> 32), text_node, 0u);  // (no completion yet: the text node, see the layout)
     ColdRec cr;
     cr.c_lmhw = 0.0;
     cr.pscore = pscore;
@@ -1936,6 +1967,7 @@ CTC_UNROLL
   }
 
   CTC_HD void run() {
+    load_hot();
     init();
     if (PROF && io.prof && lane == 0) t_last = ctx.clock();
     prefetch(0);

@@ -1,7 +1,8 @@
 """Diagnostics (GPU box): time decode_batch of the bench workload under several switch settings inside ONE process
 (same resident logits, same decoder), so that variants are compared on the same box and the same data.
   python tools/ab_bench.py [--batch 4096] [--steps 3] CONFIG [CONFIG ...]
-CONFIG = comma-separated KEY=VALUE environment switches and/or n=<utterances>, e.g.
+CONFIG = comma-separated KEY=VALUE environment switches and/or n=<utterances>, bw=<beam width>, lib=<path of another build of
+the library: tools/build_variant.py>, e.g.
   "CTCDEC_BEAM_KERNEL=wave,n=4096"  "CTCDEC_BEAM_KERNEL=group,n=512"  "CTCDEC_PRUNE_EXP=pk"
 """
 import argparse
@@ -30,13 +31,17 @@ def main():
 
     from pyctcdecode_amd import build_ctcdecoder
 
-    dec = build_ctcdecoder(labels, lm.path)
+    from pyctcdecode_amd import _binding as B
+
+    decs = {"": build_ctcdecoder(labels, lm.path)}
+    cur_lib = ""
+    default_lib = B.get_library()
     dev = torch.from_numpy(xs).cuda()
     torch.cuda.synchronize()
     del xs
     ref_texts = {}
     for cfg in args.configs:
-        env, n, bw = {}, args.batch, bench.BEAM
+        env, n, bw, lib = {}, args.batch, bench.BEAM, ""
         for kv in cfg.split(","):
             if not kv:
                 continue
@@ -45,10 +50,18 @@ def main():
                 n = int(v)
             elif k == "bw":
                 bw = int(v)
+            elif k == "lib":
+                lib = v
             else:
                 env[k] = v
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
+        if lib != cur_lib:  # another build of the library: its own decoder (the previous one is freed first: workspaces are big)
+            decs.clear()
+            B._LIB = B.Library(lib) if lib else default_lib
+            decs[lib] = build_ctcdecoder(labels, lm.path)
+            cur_lib = lib
+        dec = decs[cur_lib]
         try:
             batch = dev[:n]
             texts = dec.decode_batch(None, batch, beam_width=bw, hotwords=hot)  # warm-up
