@@ -945,8 +945,14 @@ __global__ __launch_bounds__(PRUNE_WAVES * 64) void frame_prune_f32x4_listed(Pru
 //     (set_order_small.h: 48 table slots per lane) and the output records -- the serial tail, 64 rows at a time.
 // Rows this does not cover (non-finite maximum or NaN, more than 16 candidates / 15 survivors, survivor counts at the
 // max_surv bound) go onto a list and frame_prune_f32x4_listed runs the per-row code on them right behind this kernel.
-constexpr int PF_ROWS = 64;
-constexpr int PF_CAND = 16;
+#ifndef CTC_PF_ROWS
+#define CTC_PF_ROWS 64
+#endif
+#ifndef CTC_PF_CAND
+#define CTC_PF_CAND 16
+#endif
+constexpr int PF_ROWS = CTC_PF_ROWS;
+constexpr int PF_CAND = CTC_PF_CAND;
 constexpr size_t PF_LDS_IDS = (size_t)PF_ROWS * PF_CAND * 2;
 constexpr size_t PF_LDS_X = (size_t)PF_ROWS * PF_CAND * 4;
 constexpr int PF_MAX_LABELS = 2048;  // 64 lanes x 8 groups of four labels
@@ -1026,17 +1032,21 @@ struct LaneTab {
 
 // DT: ctcdec_dtype of the rows -- 0 float32 (NC 16-byte loads of four labels per lane), 2 float16 / 3 bfloat16 (NC / 2 loads
 // of eight labels, widened exactly to the same NC float4 groups: the arithmetic below never knows the difference)
+// (native vector types: what a load returns stays in its registers untouched until the row is worked on -- and, unlike the HIP
+//  vector classes, they can be read through a pointer with an address space)
+typedef float PfF4 __attribute__((ext_vector_type(4)));
+typedef uint32_t PfU4 __attribute__((ext_vector_type(4)));
 template <int DT>
 struct PfRaw {
-  typedef float4 type;
+  typedef PfF4 type;
 };
 template <>
 struct PfRaw<2> {
-  typedef uint4 type;
+  typedef PfU4 type;
 };
 template <>
 struct PfRaw<3> {
-  typedef uint4 type;
+  typedef PfU4 type;
 };
 template <int DT>
 __device__ __forceinline__ float pf_widen(uint32_t h16) {
@@ -1070,42 +1080,64 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   auto id_of = [&](int k, int e) { return WIDE ? (k * 64 + lane) * 4 + e : ((k >> 1) * 64 + lane) * 8 + (k & 1) * 4 + e; };
   auto in_row = [&](int k) { return (WIDE ? k : (k >> 1)) * 64 + lane < n4; };
 
-  // rows are walked in order: the utterance of the first one by bisection, the rest by stepping
-  int u = find_utt(a.utt_row0, a.n_utts, row_lo);
-  int64_t u_r0 = a.utt_row0[u], u_r1 = a.utt_row0[u + 1];
-  const char* u_base = (const char*)a.utt_logits[u];
+  // rows are walked in order: the utterance of the first one by bisection, the rest by stepping.
+  // Round 5: the utterance bookkeeping is SCALAR (uniform loads from the constant address space: s_load, counted by lgkmcnt)
+  // and the rows are read through a GLOBAL-address-space pointer. Until then the rows' base pointer -- fetched from the
+  // per-utterance pointer array by a vector load -- made every row load a flat_load and put an unconditional
+  // `s_waitcnt vmcnt(0)` in front of each row's arithmetic: the two rows "in flight" behind the one being worked on were waited
+  // for the moment they were requested, and every row paid a full HBM round trip (3.8 TB/s at V = 1024, ~8 500 cycles a row).
+  typedef const int64_t __attribute__((address_space(4))) * ConstI64;
+  typedef const void* const __attribute__((address_space(4))) * ConstPtrs;
+  typedef const Raw __attribute__((address_space(1))) * GlobalRaw;
+  const ConstI64 row0_c = (ConstI64)a.utt_row0;
+  const ConstPtrs logits_c = (ConstPtrs)a.utt_logits;
+  int u = __builtin_amdgcn_readfirstlane(find_utt(a.utt_row0, a.n_utts, row_lo));
+  int64_t u_r0 = row0_c[u], u_r1 = row0_c[u + 1];
+  const char __attribute__((address_space(1))) * u_base = (const char __attribute__((address_space(1)))*)logits_c[u];
   auto load_row = [&](int64_t row, Raw(&r)[NL]) {
     while (row >= u_r1) {
       ++u;
       u_r0 = u_r1;
-      u_r1 = a.utt_row0[u + 1];
-      u_base = (const char*)a.utt_logits[u];
+      u_r1 = row0_c[u + 1];
+      u_base = (const char __attribute__((address_space(1)))*)logits_c[u];
     }
-    const Raw* x4 = (const Raw*)(u_base + (size_t)(row - u_r0) * V * (WIDE ? 4 : 2));
+    const GlobalRaw x4 = (GlobalRaw)(u_base + (size_t)(row - u_r0) * V * (WIDE ? 4 : 2));
+    // Every load is UNCONDITIONAL (a lane past the row's end re-reads the row's first group; `widen` puts -inf there when the
+    // row is worked on): a load behind a lane mask is a branch, and at the join the compiler can no longer count how many loads
+    // are outstanding -- it waits for all of them, the prefetched rows included.
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       const int i4 = k * 64 + lane;
       if constexpr (!AL) {
-        const float* xf = (const float*)x4;
+        const float __attribute__((address_space(1)))* xf = (const float __attribute__((address_space(1)))*)x4;
         const int e0 = i4 * 4;
-        float4 v;
-        v.x = e0 < V ? xf[e0] : -INFINITY;
-        v.y = e0 + 1 < V ? xf[e0 + 1] : -INFINITY;
-        v.z = e0 + 2 < V ? xf[e0 + 2] : -INFINITY;
-        v.w = e0 + 3 < V ? xf[e0 + 3] : -INFINITY;
+        Raw v;
+        v.x = xf[e0 < V ? e0 : 0];
+        v.y = xf[e0 + 1 < V ? e0 + 1 : 0];
+        v.z = xf[e0 + 2 < V ? e0 + 2 : 0];
+        v.w = xf[e0 + 3 < V ? e0 + 3 : 0];
         r[k] = v;
-      } else if constexpr (WIDE) {
-        r[k] = i4 < n4 ? x4[i4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
       } else {
-        const uint32_t ninf = DT == 2 ? 0xFC00FC00u : 0xFF80FF80u;  // -inf twice
-        r[k] = i4 < n4 ? x4[i4] : make_uint4(ninf, ninf, ninf, ninf);
+        r[k] = x4[i4 < n4 ? i4 : 0];
       }
     }
   };
   auto widen = [&](const Raw(&raw)[NL], float4(&r)[NC]) {
+    const float ninf = -INFINITY;
     if constexpr (WIDE) {
 #pragma unroll
-      for (int k = 0; k < NC; ++k) r[k] = raw[k];
+      for (int k = 0; k < NC; ++k) {
+        r[k] = make_float4(raw[k].x, raw[k].y, raw[k].z, raw[k].w);
+        if constexpr (!AL) {  // labels past the end of the row
+          const int e0 = (k * 64 + lane) * 4;
+          if (e0 >= V) r[k].x = ninf;
+          if (e0 + 1 >= V) r[k].y = ninf;
+          if (e0 + 2 >= V) r[k].z = ninf;
+          if (e0 + 3 >= V) r[k].w = ninf;
+        } else if (!in_row(k)) {
+          r[k] = make_float4(ninf, ninf, ninf, ninf);
+        }
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
@@ -1113,6 +1145,10 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
                                pf_widen<DT>(raw[k].y >> 16));
         r[2 * k + 1] = make_float4(pf_widen<DT>(raw[k].z & 0xFFFFu), pf_widen<DT>(raw[k].z >> 16), pf_widen<DT>(raw[k].w & 0xFFFFu),
                                    pf_widen<DT>(raw[k].w >> 16));
+        if (!in_row(2 * k)) {
+          r[2 * k] = make_float4(ninf, ninf, ninf, ninf);
+          r[2 * k + 1] = make_float4(ninf, ninf, ninf, ninf);
+        }
       }
     }
   };
@@ -1157,10 +1193,17 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       const f32x2 mm = (f32x2)(m);
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
+#ifdef CTC_PF_SKIP_EXP  // diagnostics only (timing the rest of phase A): no exponentials, a made-up sum
+        acc += ((f32x2){r[k].x, r[k].y} - mm) * (f32x2)(1e-9f) + ((f32x2){r[k].z, r[k].w} - mm) * (f32x2)(1e-9f);
+#else
         acc += exp_nonpos_f32x2m((f32x2){r[k].x, r[k].y} - mm);
         acc += exp_nonpos_f32x2m((f32x2){r[k].z, r[k].w} - mm);
+#endif
       }
       s = wave_sum((double)(acc.x + acc.y));
+#ifdef CTC_PF_SKIP_EXP
+      s = 1.02 + s * 1e-30;
+#endif
       // candidates: a float32 screen that cannot miss a survivor -- the threshold on the logits from a float32 logarithm
       // (|error| < 1e-6 (1 + lse)), lowered by a margin two orders above that and above the rounding of the sum
       const float xthr = (m + __logf((float)s)) + tminf;
@@ -1215,35 +1258,34 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     }
   };
 
+  // Rows in flight behind the one being worked on. EVERY iteration issues the same loads whatever the block's length (past its
+  // end the last row is requested again: an L2 hit nobody looks at): the compiler places `s_waitcnt vmcnt(n)` by counting the
+  // loads outstanding on every path into a block and keeping the SMALLEST count, so a single path that skips a row's loads
+  // (a short block, the loop's last iterations) turned every wait into "all of them" -- the prefetch existed in the source only.
+  const int64_t row_last = row_lo + nrows - 1;
+  auto row_at = [&](int i) { return row_lo + i < row_last ? row_lo + i : row_last; };
   if constexpr (NC <= 4) {
-    // two rows in flight behind the one being worked on (three register buffers in rotation): at 13 waves per CU (LDS) and
-    // 4 KB a row, one row ahead leaves ~50 KB per CU on its way -- short of what ~8 TB/s times the memory latency asks for
+    // two rows in flight (three register buffers in rotation): at 13 waves per CU (LDS) and 4 KB a row that is ~100 KB per CU
+    // on its way, what ~6 TB/s times the loaded memory latency asks for
     Raw ra[NL], rb[NL], rc[NL];
-    load_row(row_lo, ra);
-    if (nrows > 1) load_row(row_lo + 1, rb);
+    load_row(row_at(0), ra);
+    load_row(row_at(1), rb);
     for (int i = 0; i < nrows; i += 3) {
-      if (i + 2 < nrows) load_row(row_lo + i + 2, rc);
+      load_row(row_at(i + 2), rc);
       phase_a(i, ra);
-      if (i + 1 < nrows) {
-        if (i + 3 < nrows) load_row(row_lo + i + 3, ra);
-        phase_a(i + 1, rb);
-      }
-      if (i + 2 < nrows) {
-        if (i + 4 < nrows) load_row(row_lo + i + 4, rb);
-        phase_a(i + 2, rc);
-      }
+      load_row(row_at(i + 3), ra);
+      if (i + 1 < nrows) phase_a(i + 1, rb);
+      load_row(row_at(i + 4), rb);
+      if (i + 2 < nrows) phase_a(i + 2, rc);
     }
   } else {
     Raw ra[NL], rb[NL];
-    load_row(row_lo, ra);
+    load_row(row_at(0), ra);
     for (int i = 0; i < nrows; i += 2) {
-      const bool two = i + 1 < nrows;
-      if (two) load_row(row_lo + i + 1, rb);
+      load_row(row_at(i + 1), rb);
       phase_a(i, ra);
-      if (two) {
-        if (i + 2 < nrows) load_row(row_lo + i + 2, ra);
-        phase_a(i + 1, rb);
-      }
+      load_row(row_at(i + 2), ra);
+      if (i + 1 < nrows) phase_a(i + 1, rb);
     }
   }
   __syncthreads();  // (one wave: orders phase A's LDS writes before phase B's reads)
@@ -1252,6 +1294,14 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   const int64_t row = row_lo + lane;
   const uint32_t ms = (uint32_t)a.max_surv;
   bool slow = false;
+#ifdef CTC_PF_SKIP_B  // diagnostics only (timing phase A alone): one made-up survivor per row
+  if (lane < nrows) {
+    a.surv_id[(size_t)row * ms] = 0;
+    a.surv_lp[(size_t)row * ms] = -1.0 + 1e-30 * (double)(my_cnt + (uint32_t)my_first) + 1e-30 * my_s;
+    a.surv_cnt[row] = 1;
+    a.row_sum[row] = (double)my_rs + (double)my_m * 1e-30;
+  }
+#else
   if (lane < nrows) {
     const uint32_t cnt = my_cnt;
     slow = cnt > (uint32_t)PF_CAND;
@@ -1303,6 +1353,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       }
     }
   }
+#endif
   const uint64_t sm = __ballot(slow);
   if (sm) {
     uint32_t base = 0;
