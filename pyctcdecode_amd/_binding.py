@@ -212,7 +212,7 @@ def _pytexts():
                                                    C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32), C.py_object,
                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
-                                                   C.POINTER(C.c_double)]
+                                                   C.POINTER(C.c_double), C.py_object]
                 _PYTEXTS = dll
             except (OSError, AttributeError):
                 _PYTEXTS = False
@@ -241,14 +241,15 @@ def output_beams(cls, pk: "Packed", states: Optional[list]) -> Optional[list]:
                                       pk.word_cnt_off, pk.word_start, pk.word_end, states)
 
 
-def lm_beams(cls, n_streams: int, pk: "Packed", labels: list) -> Optional[list]:
-    """The LMBeam lists of a packed streaming result, built in C (csrc/pytexts.c); None when the helper was not built."""
+def lm_beams(cls, n_streams: int, pk: "Packed", labels: list, frames_of=None) -> Optional[list]:
+    """The LMBeam lists of a packed streaming result, built in C (csrc/pytexts.c); None when the helper was not built.
+    frames_of(w0, w1): the caller's (lazy) text_frames object for words w0 .. w1-1 of the result, instead of eager lists."""
     dll = _pytexts()
     if not dll:
         return None
     return dll.ctcdec_py_lm_beams(cls, n_streams, pk.beam_off, pk.text_off, pk.text_blob, pk.partial_off, pk.partial_blob,
                                   pk.last_char, labels, pk.word_cnt_off, pk.word_start, pk.word_end, pk.partial_start,
-                                  pk.partial_end, pk.logit_score, pk.lm_score)
+                                  pk.partial_end, pk.logit_score, pk.lm_score, frames_of)
 
 
 def split_texts(blob_ptr, nbytes: int, n: int, sep: bytes):

@@ -161,10 +161,13 @@ fail:
  * `cls` is the frozen dataclass LMBeam; `labels`: list of str, last_char = labels[k] for k >= 0, None below. */
 static PyObject *k_next, *k_partial, *k_last, *k_pframes;
 
+/* frames_of (a callable, or None): when given, a beam's text_frames is frames_of(w0, w1) -- the caller's lazy view of words
+ * w0 .. w1-1 of the result -- instead of a list of (start, end) tuples built here: a stream that has run for a thousand frames
+ * carries ~250 words per beam, and their tuples were most of the cost of reading the beams (round 5). */
 PyObject* ctcdec_py_lm_beams(PyObject* cls, int64_t n_streams, const int64_t* beam_off, const int64_t* text_off,
                              const char* text_blob, const int64_t* partial_off, const char* partial_blob, const int32_t* last_char,
                              PyObject* labels, const int64_t* word_cnt_off, const int32_t* word_start, const int32_t* word_end,
-                             const int32_t* pstart, const int32_t* pend, const double* logit, const double* lm) {
+                             const int32_t* pstart, const int32_t* pend, const double* logit, const double* lm, PyObject* frames_of) {
   if (beam_attr_names() < 0) return NULL;
   if (!k_next) {
     k_next = PyUnicode_InternFromString("next_word");
@@ -197,9 +200,12 @@ PyObject* ctcdec_py_lm_beams(PyObject* cls, int64_t n_streams, const int64_t* be
       const int64_t w0 = word_cnt_off[k], w1 = word_cnt_off[k + 1];
       PyObject* text = PyUnicode_DecodeUTF8(text_blob + text_off[k], (Py_ssize_t)(text_off[k + 1] - text_off[k]), "strict");
       PyObject* part = text ? PyUnicode_DecodeUTF8(partial_blob + partial_off[k], (Py_ssize_t)(partial_off[k + 1] - partial_off[k]), "strict") : NULL;
-      PyObject* frames = part ? PyList_New((Py_ssize_t)(w1 - w0)) : NULL;
+      const int lazy = frames_of != NULL && frames_of != Py_None;
+      PyObject* frames = !part ? NULL
+                         : lazy ? PyObject_CallFunction(frames_of, "LL", (long long)w0, (long long)w1)
+                                : PyList_New((Py_ssize_t)(w1 - w0));
       int ok = frames != NULL;
-      for (int64_t w = w0; ok && w < w1; ++w) {
+      for (int64_t w = w0; ok && !lazy && w < w1; ++w) {
         PyObject* a = PyLong_FromLong((long)word_start[w]);
         PyObject* b = a ? PyLong_FromLong((long)word_end[w]) : NULL;
         PyObject* span = b ? PyTuple_Pack(2, a, b) : NULL;

@@ -388,18 +388,18 @@ class _DeviceStreams:
         b_off = np.ctypeslib.as_array(pk.beam_off, shape=(n + 1,))
         if self.parents is None and not os.environ.get("CTCDEC_PY_UNPACK"):
             # the same lists from one C loop (csrc/pytexts.c); the memo entries of new texts are added here
-            built = B.lm_beams(LMBeam, n, pk, dec._labels_list)
+            frames_of = None
+            if not os.environ.get("CTCDEC_EAGER_FRAMES"):  # (diagnostics / tests: plain lists of tuples built in C)
+                if nw:
+                    ws = np.ctypeslib.as_array(pk.word_start, shape=(nw,)).copy()
+                    we = np.ctypeslib.as_array(pk.word_end, shape=(nw,)).copy()
+                else:
+                    ws = we = np.zeros(0, dtype=np.int32)
+                frames_of = _lazy_frames_factory(ws, we)
+            built = B.lm_beams(LMBeam, n, pk, dec._labels_list, frames_of)
             if built is not None:
                 if has_lm:
-                    raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,))
-                    for u in range(n):
-                        memo = self.memos[u] if u < len(self.memos) else {}
-                        j = int(b_off[u])
-                        for beam in built[u]:
-                            key = (beam.text, False)
-                            if key not in memo:
-                                memo[key] = (float(raw[j]), float(raw[j]), self._state_of(res, pk, u, j, j - int(b_off[u]), n_lms))
-                            j += 1
+                    self._note_memo_entries(res, pk, built, b_off, nb, n_lms)
                 return built
         t_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))
         tblob = C.string_at(pk.text_blob, int(t_off[nb])) if t_off[nb] else b""
@@ -433,6 +433,34 @@ class _DeviceStreams:
             out.append(outs)
         return out
 
+    def _note_memo_entries(self, res, pk, built, b_off, nb: int, n_lms: int) -> None:
+        """The caller's caches get an entry for every returned text, as the reference's decode leaves them (decoder.py:387-396);
+        the entries' LM-state objects are made on demand from a private copy of the read's packed states."""
+        raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,)).tolist()
+        st_bytes = C.string_at(C.cast(pk.lm_state, C.c_void_p), nb * C.sizeof(B.LmState))
+        more = None
+        if n_lms > 1:  # the other models' states: one native call per (stream, beam) -- kept eager (rare, short lists)
+            more = True
+        ssz = C.sizeof(B.LmState)
+
+        def state_maker(j):
+            def make():
+                return KenlmState(NgramState.from_c(B.LmState.from_buffer_copy(st_bytes, j * ssz)))
+            return make
+
+        for u in range(self.n):
+            memo = self.memos[u] if u < len(self.memos) else {}
+            j = int(b_off[u])
+            j0 = j
+            for beam in built[u]:
+                key = (beam.text, False)
+                if key not in memo:
+                    if more:
+                        memo[key] = (raw[j], raw[j], self._state_of(res, pk, u, j, j - j0, n_lms))
+                    else:
+                        memo[key] = _MemoEntry(raw[j], state_maker(j))
+                j += 1
+
     def _state_of(self, res, pk, u: int, j: int, j_in_stream: int, n_lms: int) -> AbstractLMState:
         state: AbstractLMState = KenlmState(NgramState.from_c(pk.lm_state[j]))
         if n_lms > 1:
@@ -443,6 +471,82 @@ class _DeviceStreams:
                 parts.append(KenlmState(NgramState.from_c(cst)))
             state = MultiLanguageModelState(parts)
         return state
+
+
+class _LazyFrames(list):
+    """text_frames of a streaming LMBeam: the (start, end) frame pairs of the beam's words, kept as a window of the read's two
+    int32 arrays until somebody looks (then an ordinary list of tuples, equal to what the reference returns,
+    decoder.py:653-667). A stream that has run for a thousand frames carries ~250 words per beam; building their tuples for
+    every beam of every stream was most of the time of reading the beams (round 4: 7.8 ms for 64 streams, 11.3 ms with the
+    last chunk), and a caller that hands the beams back, shows the best text or looks at one beam's frames never needs them.
+    Same caveat as _ResidentBeams for code that reads list storage through the C API without calling a method."""
+
+    __slots__ = ("_src", "_lo", "_hi")
+
+    def _fill(self) -> None:
+        src = self._src
+        if src is not None:
+            self._src = None
+            ws, we = src
+            list.extend(self, zip(ws[self._lo:self._hi].tolist(), we[self._lo:self._hi].tolist()))
+
+    _touch = _fill
+
+    def __reduce__(self):
+        self._fill()
+        return (list, (list(list.__iter__(self)),))
+
+
+def _lazy_frames_factory(word_start, word_end):
+    """frames_of(w0, w1) over private copies of a result's word_start / word_end arrays (the result is freed after the read)"""
+    src = (word_start, word_end)
+
+    def frames_of(lo, hi):
+        f = _LazyFrames()
+        f._src = src
+        f._lo = lo
+        f._hi = hi
+        return f
+
+    return frames_of
+
+
+class _MemoEntry(tuple):
+    """A memo entry (lm_score + hot-word score, raw lm_score, LM state) of a text a device read returned -- the tuple the
+    reference's cache holds (decoder.py:387-396) -- whose STATE object is built from the read's packed states when somebody
+    unpacks or indexes the entry (the import path of edited beams does; a caller that only hands its caches back never does)."""
+
+    def __new__(cls, raw, make_state):
+        self = tuple.__new__(cls, (raw, raw, None))
+        self._make = make_state
+        self._state = None
+        return self
+
+    def _full(self):
+        if self._make is not None:
+            self._state = self._make()
+            self._make = None
+        return (tuple.__getitem__(self, 0), tuple.__getitem__(self, 1), self._state)
+
+    def __getitem__(self, k):
+        return self._full()[k]
+
+    def __iter__(self):
+        return iter(self._full())
+
+    def __eq__(self, other):
+        return self._full() == (other._full() if isinstance(other, _MemoEntry) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None  # type: ignore[assignment]
+
+    def __repr__(self):
+        return repr(self._full())
+
+    def __reduce__(self):
+        return (tuple, (self._full(),))
 
 
 class _ResidentBeams(list):
@@ -494,9 +598,18 @@ class _ResidentBeams(list):
         self._edited = True
 
 
+def _fill_args(args) -> None:
+    # (the list type's own C code reads another lazy list's storage directly: a comparison / concatenation / extend with one
+    #  has to fill it first)
+    for x in args:
+        if isinstance(x, (_LazyFrames, _ResidentBeams)):
+            x._fill()
+
+
 def _reader(name):
     def method(self, *a, **k):
         self._fill()
+        _fill_args(a)
         return getattr(list, name)(self, *a, **k)
 
     method.__name__ = name
@@ -506,6 +619,7 @@ def _reader(name):
 def _writer(name):
     def method(self, *a, **k):
         self._touch()
+        _fill_args(a)
         return getattr(list, name)(self, *a, **k)
 
     method.__name__ = name
@@ -519,6 +633,22 @@ for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "exte
            "reverse"):
     setattr(_ResidentBeams, _n, _writer(_n))
 _ResidentBeams.__hash__ = None  # type: ignore[assignment]
+
+
+def _radd(self, other):
+    # plain_list + lazy: a subclass's reflected method is tried first, which is the only chance to fill before list's C code
+    # concatenates the (still empty) storage
+    self._fill()
+    return list(other) + list(list.__iter__(self))
+
+
+_ResidentBeams.__radd__ = _radd  # type: ignore[attr-defined]
+_LazyFrames.__radd__ = _radd  # type: ignore[attr-defined]
+for _n in ("__len__", "__iter__", "__contains__", "__repr__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__add__",
+           "__mul__", "__rmul__", "__reversed__", "index", "count", "copy", "__getitem__", "__setitem__", "__delitem__", "__iadd__",
+           "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort", "reverse"):
+    setattr(_LazyFrames, _n, _reader(_n))
+_LazyFrames.__hash__ = None  # type: ignore[assignment]
 
 
 class BeamSearchDecoderCTC:

@@ -365,3 +365,35 @@ def test_more_carried_beams_than_the_wave_table_holds(sim_library, monkeypatch):
         with np.errstate(all="ignore"):
             ob = orc.partial_decode_beams(x[12:], st, 12, beam_width=100, beam_prune_logp=-30.0, is_end=True)
         check_beams(_lm_beams(beams), _oracle_beams(ob), what="carry 128 -> 100")
+
+
+def test_lazy_text_frames_and_memo_entries_behave_like_the_plain_objects():
+    """The text_frames of a streaming read are windows of the read's arrays until looked at (decoder._LazyFrames), the memo
+    entries build their LM-state objects on demand (decoder._MemoEntry): every way of looking must see the plain list / tuple."""
+    import copy
+    import pickle
+
+    from pyctcdecode_amd.decoder import _MemoEntry, _lazy_frames_factory
+
+    ws, we = np.array([0, 7, 20], dtype=np.int32), np.array([6, 13, 25], dtype=np.int32)
+    make = _lazy_frames_factory(ws, we)
+    plain = [(0, 6), (7, 13)]
+    assert make(0, 2) == plain and plain == make(0, 2) and make(0, 2) == make(0, 2) and make(0, 2) != make(1, 3)
+    assert len(make(0, 3)) == 3 and make(1, 3)[0] == (7, 13) and list(make(2, 3)) == [(20, 25)] and make(1, 1) == []
+    assert make(0, 2) + make(2, 3) == plain + [(20, 25)] and plain + make(2, 3) == plain + [(20, 25)]
+    f = make(0, 2)
+    f.append((30, 31))
+    assert f == plain + [(30, 31)] and isinstance(f[0][0], int)
+    assert pickle.loads(pickle.dumps(make(0, 2))) == plain and type(pickle.loads(pickle.dumps(make(0, 2)))) is list
+    assert copy.deepcopy(make(0, 2)) == plain and repr(make(0, 2)) == repr(plain) and (7, 13) in make(0, 2)
+    calls = []
+
+    def state():
+        calls.append(1)
+        return "STATE"
+
+    e = _MemoEntry(-1.5, state)
+    assert not calls and len(e) == 3
+    lm_hw, raw, st = e
+    assert (lm_hw, raw, st) == (-1.5, -1.5, "STATE") and e[2] == "STATE" and len(calls) == 1
+    assert e == (-1.5, -1.5, "STATE") and pickle.loads(pickle.dumps(e)) == (-1.5, -1.5, "STATE")
