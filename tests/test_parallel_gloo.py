@@ -170,3 +170,23 @@ def test_shard_bounds_by_frames_balance_ragged_batches():
     # equal lengths: the same as the count-balanced split up to one utterance
     spans = [shard_bounds_by_frames([100] * 10, 3, r) for r in range(3)]
     assert [b - a for a, b in spans] in ([4, 3, 3], [3, 4, 3], [3, 3, 4], [4, 4, 2])
+
+
+def test_chunked_batch_generation_equals_the_whole_batch():
+    """bench.py --gpus N > 1 generates each rank's batch chunk by chunk into one small shared buffer (bounded host memory on an
+    8-GPU node): the chunks must be the very utterances bench.make_batch would have produced, bit for bit."""
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = os.path.join(root, "bench_cache") if os.access(root, os.W_OK) else "/tmp/ctc_bench"
+    lm, labels, hot = bench.build_assets(cache, 20000, 60000)
+    whole = bench.make_batch(lm, labels, 37, 10, 40, 6.0, 1)
+    cb = bench.ChunkedBatch(lm, labels, 40, 6.0, 2, chunk=4)
+    try:
+        got = []
+        for c0 in range(0, 10, 4):
+            n = min(4, 10 - c0)
+            got.append(np.array(cb.fill(37 + c0, n)))  # (copied: the buffer is reused)
+    finally:
+        cb.close()
+    assert np.array_equal(np.concatenate(got), whole)

@@ -325,6 +325,10 @@ def test_hip_bench_n_gt_1_path_rehearsed_on_one_gpu():
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 1 and line["scaling"] == scaling and line["value"] > 0  # n_gpus = what the process group reports
         assert "RCCL all_gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
+        # every rank's own step and stage times ride in the N > 1 line (an imbalance between the GPUs must be visible), and the
+        # batch came from the bounded-memory chunked generator
+        assert [r["rank"] for r in line["per_rank_stages_ms"]] == [0] and line["per_rank_stages_ms"][0]["beam"] > 0
+        assert "generated in chunks" in out.stderr
     # `--gpus 2` on a box with one GPU must fail loudly, not fall back to one rank
     import torch
 
