@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   int my_first = 0;
   uint32_t my_cnt = 0;
 
-  auto phase_a = [&](int i, const Raw(&raw)[NL]) {
+  auto phase_a = [&](int i, const Raw(&raw)[NL]) -> uint32_t {
     float4 r[NC];
     widen(raw, r);
     float mf = -INFINITY, rsf;
@@ -1256,7 +1256,13 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       my_first = first;
       my_cnt = cnt;
     }
+    return cnt;  // (wave-uniform)
   };
+  // Small vocabularies with DENSE rows (a character model fed flat logits: all 29 labels of BASELINE configs[1] pass the
+  // threshold in every row) have more candidates per row than this kernel keeps: when the block's first row says so, the whole
+  // block goes to the per-row kernel at once instead of being screened row by row first -- what such inputs cost before this
+  // kernel took small vocabularies at all. (Only below 65 labels, where density is a property of the input, not of a row.)
+  bool dense = false;
 
   // Rows in flight behind the one being worked on. EVERY iteration issues the same loads whatever the block's length (past its
   // end the last row is requested again: an L2 hit nobody looks at): the compiler places `s_waitcnt vmcnt(n)` by counting the
@@ -1272,7 +1278,11 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     load_row(row_at(1), rb);
     for (int i = 0; i < nrows; i += 3) {
       load_row(row_at(i + 2), rc);
-      phase_a(i, ra);
+      const uint32_t c0 = phase_a(i, ra);
+      if (i == 0 && V <= 64 && c0 != 0xFFFFu && c0 > (uint32_t)PF_CAND) {
+        dense = true;
+        break;
+      }
       load_row(row_at(i + 3), ra);
       if (i + 1 < nrows) phase_a(i + 1, rb);
       load_row(row_at(i + 4), rb);
@@ -1302,7 +1312,9 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     a.row_sum[row] = (double)my_rs + (double)my_m * 1e-30;
   }
 #else
-  if (lane < nrows) {
+  if (dense) {
+    slow = lane < nrows;
+  } else if (lane < nrows) {
     const uint32_t cnt = my_cnt;
     slow = cnt > (uint32_t)PF_CAND;
     if (!slow) {

@@ -509,26 +509,18 @@ CTC_UNROLL
     const uint64_t key = ok ? q_lo(p0) : ~0ull, hk = with_hist ? q_hi(p0) : 0ull;
     uint32_t rank = 0, dup = 0;
     if (!TIES) {
-      // The four entries of the NEXT step are requested before this step's are compared (a wave's frame is bound by round
-      // trips like this one -- ~65 cycles to LDS and back -- not by the instructions in between: the walk used to be one
-      // exposed round trip per four entries). Past the end the first entries are read again and not looked at.
-      u32x4 r0 = L.pk[0], r1 = L.pk[1], r2 = L.pk[2], r3 = L.pk[3];
       if (with_hist) {
         for (uint32_t j = 0; j < n; j += 4u) {
-          const uint32_t jn = j + 4u < n ? j + 4u : 0u;
-          const u32x4 n0 = L.pk[jn], n1 = L.pk[jn + 1u], n2 = L.pk[jn + 2u], n3 = L.pk[jn + 3u];
+          const u32x4 r0 = L.pk[j], r1 = L.pk[j + 1u], r2 = L.pk[j + 2u], r3 = L.pk[j + 3u];
           const bool b0 = q_lo(r0) < key, b1 = q_lo(r1) < key, b2 = q_lo(r2) < key, b3 = q_lo(r3) < key;
           rank += (b0 ? 1u : 0u) + (b1 ? 1u : 0u) + (b2 ? 1u : 0u) + (b3 ? 1u : 0u);
           // (bitwise, not short-circuit: the latter became a ladder of exec-mask branches)
           dup |= (uint32_t)((b0 & (q_hi(r0) == hk)) | (b1 & (q_hi(r1) == hk)) | (b2 & (q_hi(r2) == hk)) | (b3 & (q_hi(r3) == hk)));
-          r0 = n0; r1 = n1; r2 = n2; r3 = n3;
         }
       } else {
         for (uint32_t j = 0; j < n; j += 4u) {
-          const uint32_t jn = j + 4u < n ? j + 4u : 0u;
-          const u32x4 n0 = L.pk[jn], n1 = L.pk[jn + 1u], n2 = L.pk[jn + 2u], n3 = L.pk[jn + 3u];
+          const u32x4 r0 = L.pk[j], r1 = L.pk[j + 1u], r2 = L.pk[j + 2u], r3 = L.pk[j + 3u];
           rank += (q_lo(r0) < key ? 1u : 0u) + (q_lo(r1) < key ? 1u : 0u) + (q_lo(r2) < key ? 1u : 0u) + (q_lo(r3) < key ? 1u : 0u);
-          r0 = n0; r1 = n1; r2 = n2; r3 = n3;
         }
       }
     } else {
@@ -1064,9 +1056,9 @@ CTC_UNROLL
     c.is_rep = c.valid && rep == v;
     ctx.wsync();
     tick<W_PROF_MATCH>();
-    const TabView t = resolve_tables(c);
-    tick<W_PROF_TABLES>();
     // ---- fold the group's logits in ascending beam rank (decoder.py:217-223); donor = last arrival
+    // (before the table probes and the ColdRec chunk that gen requested are looked at: the fold needs neither, and whatever it
+    //  costs is taken off the wait for them)
     uint32_t imax = c.bi, dbr = c.br;
     {
       uint32_t g0 = 0, g1 = 0;
@@ -1103,6 +1095,8 @@ CTC_UNROLL
       }
     }
     tick<W_PROF_FOLD>();
+    const TabView t = resolve_tables(c);
+    tick<W_PROF_TABLES>();
     score_push(c, t, imax, dbr);
   }
 
