@@ -955,7 +955,7 @@ constexpr int PF_ROWS = CTC_PF_ROWS;
 constexpr int PF_CAND = CTC_PF_CAND;
 constexpr size_t PF_LDS_IDS = (size_t)PF_ROWS * PF_CAND * 2;
 constexpr size_t PF_LDS_X = (size_t)PF_ROWS * PF_CAND * 4;
-constexpr int PF_MAX_LABELS = 2048;  // 64 lanes x 8 groups of four labels
+constexpr int PF_MAX_LABELS = 4095;  // 64 lanes x 16 groups of four labels, less one: label ids have to fit the 12-bit set tables
 constexpr size_t PF_LDS = PF_LDS_IDS + PF_LDS_X + (size_t)PF_ROWS * SMALL_SET_SLOTS * 2;  // 12 KiB: 13 waves per CU
 
 // exp(d), d <= 0, two at a time, as exp_nonpos_f32x2 with the rounding and the scaling done by the 1.5 * 2^23 trick
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       load_row(row_at(i + 4), rb);
       if (i + 2 < nrows) phase_a(i + 2, rc);
     }
-  } else {
+  } else if constexpr (NC <= 8) {
     Raw ra[NL], rb[NL];
     load_row(row_at(0), ra);
     for (int i = 0; i < nrows; i += 2) {
@@ -1296,6 +1296,14 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
       phase_a(i, ra);
       load_row(row_at(i + 2), ra);
       if (i + 1 < nrows) phase_a(i + 1, rb);
+    }
+  } else {
+    // 2049 .. 4095 labels (round 5): a row is up to 64 registers per lane, there is no room for a second one in flight --
+    // the other waves of the CU cover the wait (round 5 measured what the rows in flight are worth at V = 1024: 4 %)
+    Raw ra[NL];
+    for (int i = 0; i < nrows; ++i) {
+      load_row(row_at(i), ra);
+      phase_a(i, ra);
     }
   }
   __syncthreads();  // (one wave: orders phase A's LDS writes before phase B's reads)
@@ -1412,7 +1420,7 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     const dim3 fgrid((unsigned)((a.n_rows + PF_ROWS - 1) / PF_ROWS)), fblock(64);
     const unsigned rest = (unsigned)std::min<int64_t>((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES, 2048);
     if (rows64) {
-      const int nc = ((a.n_labels + 3) / 4 + 63) / 64;  // groups of four labels per lane: 1 .. 8
+      const int nc = ((a.n_labels + 3) / 4 + 63) / 64;  // groups of four labels per lane: 1 .. 16
       // rows the fast kernel hands over: the per-row float4 kernel where it applies (<= 1024 aligned labels), else the generic one
 #define CTC_LAUNCH_FAST(NCV, ALV)                                                                                         \
   do {                                                                                                                    \
@@ -1440,7 +1448,9 @@ int launch_prune(const PruneArgs& a, std::string* err) {
         case 5: CTC_LAUNCH_FAST_NC(5); break;
         case 6: CTC_LAUNCH_FAST_NC(6); break;
         case 7: CTC_LAUNCH_FAST_NC(7); break;
-        default: CTC_LAUNCH_FAST_NC(8); break;
+        case 8: CTC_LAUNCH_FAST_NC(8); break;
+        case 9: case 10: case 11: case 12: CTC_LAUNCH_FAST_NC(12); break;  // (groups past the row's end are masked)
+        default: CTC_LAUNCH_FAST_NC(16); break;
       }
 #undef CTC_LAUNCH_FAST_NC
 #undef CTC_LAUNCH_FAST
