@@ -29,7 +29,7 @@ def both_beam_kernels(request, monkeypatch):
 
 @pytest.fixture(params=["pk", "f64"])
 def both_prune_exps(request, monkeypatch):
-    """Float32 rows (up to 2048 labels) go through the register-resident frame-prune kernel, whose exponentials are packed
+    """Float32 rows (up to 4095 labels) go through the register-resident frame-prune kernel, whose exponentials are packed
     float32 polynomials by default (the precision the reference itself works at for float32 input) and the round-2 fp64
     routine under CTCDEC_PRUNE_EXP=f64. The differential tests run under both: `f64` is exact against the oracle
     (1e-9), the default within the float32 bound (tests/test_gpu_parity._tol)."""

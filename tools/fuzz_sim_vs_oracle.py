@@ -192,7 +192,7 @@ def run_case(rng, execute=True):
         return "both raise"
     assert err is None, "oracle raised %r, product did not" % (err,)
     tol = TOL
-    f32_path = TOL_F32 is not None and ((x.dtype == np.float32 and x.shape[1] <= 2048) or
+    f32_path = TOL_F32 is not None and ((x.dtype == np.float32 and x.shape[1] <= 4095) or
                                         (x.dtype == np.float16 and x.shape[1] % 8 == 0 and x.shape[1] <= 1024))
     tkw = {"tol": TOL_F32, "tie_tol": 4e-5} if f32_path else {"tol": TOL, "tie_tol": 1e-9}
     expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
