@@ -14,7 +14,13 @@ SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip", "beam_wave_hip.hip",
 # machine-level loop-invariant code motion hoists every constant and address computation it finds out of that loop and
 # keeps them in registers across it: 105 registers spilled to scratch memory (and every reload of one waits for the
 # stores in flight). Without the pass: none.
-HIP_FLAGS = {"beam_wave_hip.hip": ["-mllvm", "-disable-machine-licm"],
+# Round 5: the machine scheduler's "max-ilp" strategy for the frame-prune and wave kernels. Their occupancy is fixed by LDS and by
+# the waves-per-SIMD attribute, so the default strategy's goal (the fewest registers, loads issued right before their use) buys
+# nothing; scheduling for instruction-level parallelism took 6 % off frame_prune_fast (4.22 -> 3.98 ms, A/B in one process) and
+# 1.4 % off a lone wave's frame; at sixteen waves per CU the wave kernel is unchanged (profiles/r05_ab_experiments.log).
+_MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+HIP_FLAGS = {"backend_hip.hip": _MAX_ILP,
+             "beam_wave_hip.hip": ["-mllvm", "-disable-machine-licm"] + _MAX_ILP,
              # (the workgroup kernel: 238 -> 195 registers, 255 -> 138 scalar registers spilled to vector lanes)
              "beam_group_hip.hip": ["-mllvm", "-disable-machine-licm"]}
 HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "set_order_small.h", "backend.h", "host_tables.h", "np_sum.h",
