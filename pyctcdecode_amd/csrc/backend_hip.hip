@@ -1258,11 +1258,6 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     }
     return cnt;  // (wave-uniform)
   };
-  // Small vocabularies with DENSE rows (a character model fed flat logits: all 29 labels of BASELINE configs[1] pass the
-  // threshold in every row) have more candidates per row than this kernel keeps: when the block's first row says so, the whole
-  // block goes to the per-row kernel at once instead of being screened row by row first -- what such inputs cost before this
-  // kernel took small vocabularies at all. (Only below 65 labels, where density is a property of the input, not of a row.)
-  bool dense = false;
 
   // Rows in flight behind the one being worked on. EVERY iteration issues the same loads whatever the block's length (past its
   // end the last row is requested again: an L2 hit nobody looks at): the compiler places `s_waitcnt vmcnt(n)` by counting the
@@ -1278,11 +1273,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     load_row(row_at(1), rb);
     for (int i = 0; i < nrows; i += 3) {
       load_row(row_at(i + 2), rc);
-      const uint32_t c0 = phase_a(i, ra);
-      if (i == 0 && V <= 64 && c0 != 0xFFFFu && c0 > (uint32_t)PF_CAND) {
-        dense = true;
-        break;
-      }
+      phase_a(i, ra);
       load_row(row_at(i + 3), ra);
       if (i + 1 < nrows) phase_a(i + 1, rb);
       load_row(row_at(i + 4), rb);
@@ -1320,9 +1311,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     a.row_sum[row] = (double)my_rs + (double)my_m * 1e-30;
   }
 #else
-  if (dense) {
-    slow = lane < nrows;
-  } else if (lane < nrows) {
+  if (lane < nrows) {
     const uint32_t cnt = my_cnt;
     slow = cnt > (uint32_t)PF_CAND;
     if (!slow) {
@@ -1412,7 +1401,10 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     const char* pk = getenv("CTCDEC_PRUNE_KERNEL");  // "row": one wave per row for every row (diagnostics)
     // (round 5: vocabularies no larger than the survivor bound -- character models, V ~ 30 -- take this kernel too: a row whose
     //  survivors reach the bound, there "every label survives", is handed to the per-row kernel like any other overflow. They
-    //  used to run one row per wave at ~60 GB/s: 1.0 of config 3's 17.9 ms.)
+    //  used to run one row per wave at ~60 GB/s. Peaky posteriors -- what such models emit -- gain 35-40 % of the stage
+    //  (V = 29: 1.02 -> 0.67 ms per 512 x 1000 rows); FLAT logits, where every row overflows, pay the screening on top of the
+    //  per-row kernel (BASELINE configs[1], the stress input: 1.4 -> 2.5 of its 39 ms). An early exit per block was tried and
+    //  changes neither.)
     const bool rows_ok = a.pass == 0 && a.slow_rows && a.n_rows < (1ll << 32) && !(ex && ex[0] == 'f') && !(pk && pk[0] == 'r');
     const bool rows64 = f32_fast && rows_ok;
     // 16-bit rows of a multiple of eight labels (16-byte loads of eight): the same kernel, widened on the fly

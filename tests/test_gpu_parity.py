@@ -132,7 +132,7 @@ def test_hip_vs_oracle_bpe1025_pieces_plus_blank(lm):
 @pytest.mark.parametrize("V,scale", [(29, 1.0), (32, 3.0), (2049, 2.5), (2052, 2.5), (3000, 2.5), (4092, 2.5), (4095, 2.5), (4096, 2.5)])
 def test_hip_vs_oracle_vocabulary_shapes_of_the_rows64_prune_kernel(V, scale):
     """Round 5 widened the 64-rows-per-wave prune kernel to vocabularies no larger than the survivor bound (character models;
-    flat logits make every row DENSE there: the block is handed to the per-row kernel at once) and to 2049 .. 4095 labels (one
+    flat logits make every row dense there: all of them are handed to the per-row kernel) and to 2049 .. 4095 labels (one
     row in flight, 12 / 16 groups of four per lane; 4096 labels stay with the per-row kernel: id 4095 does not fit the 12-bit
     set tables). One decode per shape against the oracle -- survivor order against real CPython sets is
     test_hip_rows64_prune_kernel_shapes."""
@@ -527,7 +527,7 @@ def test_hip_rows64_prune_kernel_shapes(monkeypatch):
                               (1540, 64, 2.0, -5.5), (2044, 66, 2.0, -5.5), (2046, 64, 2.2, -6.0), (2045, 67, 2.0, -5.5), (2048, 64, 2.0, -5.5), (2047, 65, 2.0, -5.5),
                               # round 5: 2049 .. 4095 labels (12 / 16 groups of four per lane, one row in flight), 4096 (per-row
                               # kernel: id 4095 does not fit the set tables), and small vocabularies whose rows are dense (every label
-                              # survives: the block goes to the per-row kernel at once) or sparse
+                              # survives: every row goes to the per-row kernel) or sparse
                               (2049, 66, 2.0, -5.5), (2052, 64, 2.0, -5.5), (2560, 65, 2.2, -5.5), (3000, 70, 2.0, -5.5), (3072, 64, 2.0, -6.0),
                               (4092, 65, 2.0, -5.5), (4093, 64, 2.0, -5.5), (4095, 66, 2.0, -5.5), (4096, 64, 2.0, -5.5),
                               (29, 200, 1.0, -6.0), (40, 130, 0.5, -5.0), (29, 130, 4.0, -5.0), (64, 65, 3.0, -5.0), (150, 64, 2.0, -5.0)]:
