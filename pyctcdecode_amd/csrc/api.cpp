@@ -1059,14 +1059,19 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   // queued right behind it on the same stream: the host never sits between the two kernels. The two
   // rare events the prune stage can report (probability-like input, survivor overflow) are read back
   // afterwards and simply redo the affected stage(s).
-  if (dec->w_flags.ensure(16, &err) || dec->w_head.ensure(16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  if (dec->w_flags.ensure(32, &err) || dec->w_head.ensure(16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  ba.surv_x16 = 0;
+  // Small batches choose their beam kernel by the input (backend: wave_kernel_chosen): their beam stage is launched when the
+  // prune stage has reported -- like a resident stream's --, one small read-back between the two stages.
+  const bool by_input = !rs && be::beam_kernel_depends_on_input(ba);
+  const bool late_beam = rs != nullptr || by_input;
   for (int attempt = 0; attempt < 2; ++attempt) {
     size_t rows = (size_t)std::max<int64_t>(R, 1);
     if (dec->w_rowsum.ensure(rows * 8, &err) || dec->w_isprob.ensure((size_t)n_utts * 4, &err) ||
         dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
-        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err) || dec->w_slow.ensure(rows * 4, &err))
+        dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(32, &err) || dec->w_slow.ensure(rows * 4, &err))
       return fail(CTCDEC_ERR_DEVICE, err);
-    if (be::zero(dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    if (be::zero(dec->w_flags.p, 32, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     be::PruneArgs pa;
     pa.utt_logits = (const void* const*)dec->w_ptrs.p;
     pa.utt_row0 = (const int64_t*)dec->w_row0.p;
@@ -1096,34 +1101,45 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     ba.surv_lp = (const double*)dec->w_slp.p;
     dp.max_surv = max_surv;
     // the wave kernel's payload lines (one per candidate a frame can push into its pool)
-    ba.pay = nullptr;
-    ba.pay_stride = 0;
-    if (be::wave_kernel_chosen(ba)) {  // reserved only for launches that will use it (2 GB at the bench size)
-      ba.pay_stride = (uint64_t)wave_pay_stride(dp);
-      if (dec->w_pay.ensure((size_t)n_utts * (size_t)ba.pay_stride * sizeof(PoolPay), &err)) return fail(CTCDEC_ERR_DEVICE, err);
-      ba.pay = (PoolPay*)dec->w_pay.p;
-    }
+    auto reserve_pay = [&]() -> int {
+      ba.pay = nullptr;
+      ba.pay_stride = 0;
+      if (be::wave_kernel_chosen(ba)) {  // reserved only for launches that will use it (2 GB at the bench size)
+        ba.pay_stride = (uint64_t)wave_pay_stride(dp);
+        if (dec->w_pay.ensure((size_t)n_utts * (size_t)ba.pay_stride * sizeof(PoolPay), &err)) return -1;
+        ba.pay = (PoolPay*)dec->w_pay.p;
+      }
+      return 0;
+    };
+    if (!by_input && reserve_pay()) return fail(CTCDEC_ERR_DEVICE, err);
     auto run_beam = [&]() -> int {
       if (be::zero(dec->w_head.p, 16, &err)) return -1;
       return be::launch_beam(ba, &err);
     };
     // (a resident stream's beam kernel advances persistent state: it is launched once, when the prune stage has
-    // reported -- everything else launches it right behind the first prune pass and redoes it in the two rare cases)
-    if (be::launch_prune(pa, &err) || (!rs && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
-    uint32_t flags[4] = {0, 0, 0, 0};
-    if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    // reported -- and so is a small batch's, whose kernel is chosen by what the prune stage counted; everything else
+    // launches it right behind the first prune pass and redoes it in the two rare cases)
+    if (be::launch_prune(pa, &err) || (!late_beam && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
+    uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (be::d2h(flags, dec->w_flags.p, 32, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    const uint32_t surv_total = flags[4];  // (pass 0 counted every row as logits)
     if (flags[2]) {  // rows that sum to about 1: the reference's test in its own dtype and summation order (decoder.py:760)
       if (be::launch_sniff_exact(pa, &err) || be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
     if (flags[1]) {  // some utterance holds probabilities: redo those rows as log(clip(p)), then the beams
       pa.pass = 1;
       if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
-      if (be::launch_prune(pa, &err) || (!rs && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
+      if (be::launch_prune(pa, &err) || (!late_beam && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
       if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
     const uint32_t ovf = flags[0];
     if (!ovf) {
-      if (rs && run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
+      if (by_input) {
+        const double mean = R > 0 ? (double)surv_total / (double)R : 0.0;
+        ba.surv_x16 = (int32_t)std::min(1.0e6, std::max(1.0, mean * 16.0 + 0.5));
+        if (reserve_pay()) return fail(CTCDEC_ERR_DEVICE, err);
+      }
+      if (late_beam && run_beam()) return fail(CTCDEC_ERR_DEVICE, err);
       break;
     }
     if (max_surv == V) return fail(CTCDEC_ERR_INTERNAL, "survivor overflow at full vocabulary");
@@ -1427,7 +1443,7 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   }
   if (upload(dec->w_ptrs, ptrs, &err) || upload(dec->w_row0, row0, &err) || dec->w_rowsum.ensure(rows * 8, &err) ||
       dec->w_isprob.ensure(4, &err) || dec->w_scnt.ensure(rows * 4, &err) || dec->w_sid.ensure(rows * max_surv * 2, &err) ||
-      dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(16, &err) || be::zero(dec->w_flags.p, 16, &err) ||
+      dec->w_slp.ensure(rows * max_surv * 8, &err) || dec->w_flags.ensure(32, &err) || be::zero(dec->w_flags.p, 32, &err) ||
       dec->w_slow.ensure(rows * 4, &err))
     return fail(CTCDEC_ERR_DEVICE, err);
   be::PruneArgs pa;

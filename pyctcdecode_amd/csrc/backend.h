@@ -55,7 +55,8 @@ struct PruneArgs {
   uint32_t* surv_cnt;    // [n_rows]
   uint16_t* surv_id;     // [n_rows * max_surv]
   double* surv_lp;       // [n_rows * max_surv]
-  uint32_t* overflow;    // [4] [0]: a row had more than max_surv survivors, [1]: a probability-like utterance exists,
+  uint32_t* overflow;    // [8] ([4]: the survivors of all rows, summed -- utt_sniff; the caller decides small batches' beam kernel
+                         //      by the mean per frame) [0]: a row had more than max_surv survivors, [1]: a probability-like utterance exists,
                          // [2]: an utterance is marked 2 in utt_is_prob (its rows sum to about 1: launch_sniff_exact decides)
                          // [3]: device-side counter of slow_rows
   int32_t pass;          // 0: all utterances as logits + row sums + sniff; 1: redo the probability-like ones
@@ -119,12 +120,17 @@ struct BeamArgs {
                                // hands the next workgroup to the first free slot: longest-processing-time-first scheduling)
   int32_t resident_in;         // 1: `imports` is the carry buffer itself (stream u: imports + u * carry_stride, sstate[u].n_carry
                                // beams; import_xstates likewise), import_off is not used
+  int32_t surv_x16;            // 16 x the mean number of survivors per frame of this launch's rows, as the prune stage counted
+                               // them (0: not known). Small batches choose their kernel by it (wave_kernel_chosen).
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 // Will launch_beam run the wave kernel on these arguments (given payload lines)? THE kernel-selection rule, shared by the
 // launcher and by the caller that reserves the wave kernel's scratch: eligibility, the carried-in beams, the batch-size
 // rule and the CTCDEC_BEAM_KERNEL override. `a.pay` itself is not looked at.
 bool wave_kernel_chosen(const BeamArgs& a);
+// Is this batch small enough for the choice to depend on the input (then the caller reads the prune stage's survivor count
+// before it launches the beam stage -- one small read-back between the two stages)?
+bool beam_kernel_depends_on_input(const BeamArgs& a);
 
 // stage timing (ms) of the last launch_prune / launch_beam pair, measured on the decode stream
 void last_timing(double* prune_ms, double* beam_ms);

@@ -222,10 +222,16 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
   const int u = blockIdx.x;
   const int lane = threadIdx.x;
   const int64_t r0 = a.utt_row0[u], r1 = a.utt_row0[u + 1];
-  double s = 0.0;
-  for (int64_t r = r0 + lane; r < r1; r += 64) s += a.row_sum[r];
+  double s = 0.0, c = 0.0;
+  for (int64_t r = r0 + lane; r < r1; r += 64) {
+    s += a.row_sum[r];
+    c += (double)a.surv_cnt[r];
+  }
   s = wave_sum(s);
+  c = wave_sum(c);
   if (lane == 0) {
+    // (the survivors of all rows, summed: what a small batch's beam kernel is chosen by; saturating, only read for small batches)
+    if (a.pass == 0) atomicAdd(&a.overflow[4], (uint32_t)fmin(c, 1.0e9));
     double mean = r1 > r0 ? s / (double)(r1 - r0) : NAN;
     // (an infinite mean -- rows masked with -inf -- is never close: math.isclose(+-inf, 1) is False.) The window:
     // float32 pairwise sums of rows of ordinary logits are off by < 1e-2; float64 ones by < 1e-12.
@@ -1580,9 +1586,22 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
 static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
 int last_beam_kernel() { return g_last_kernel; }
 
+bool beam_kernel_depends_on_input(const BeamArgs& a) {
+  return !getenv("CTCDEC_BEAM_KERNEL") && a.n_utts > 0 && a.n_utts <= 2 * g_cus && wave_eligible(a.tables, a.params) &&
+         a.max_import <= wave_bucket(a.params.beam_width);
+}
+
 bool wave_kernel_chosen(const BeamArgs& a) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");
-  const bool want_group = force ? force[0] == 'g' : a.n_utts <= 2 * g_cus;
+  // Small batches (the GPU is under-filled): by the input. Round 5 measured one utterance per call on real-posterior-like
+  // input (371 x 29, ~1.3 survivors a frame, most frames consumed as single-label runs): 1.01 ms on one wave against 1.69 ms
+  // on the workgroup kernel; on the bench input (~6 survivors a frame) 11.3 against 10.5 ms for one utterance and 11.95
+  // against 12.2 ms for 512; on flat logits (29 survivors a frame, thousands of candidates) the workgroup kernel is four times
+  // faster. Hence: up to one utterance per CU the wave kernel below 3 survivors a frame, up to two per CU below 8; unknown
+  // (surv_x16 == 0: the caller did not ask) the workgroup kernel.
+  bool small_group = true;
+  if (a.surv_x16 > 0) small_group = a.surv_x16 > (a.n_utts <= g_cus ? 3 * 16 : 8 * 16);
+  const bool want_group = force ? force[0] == 'g' : (a.n_utts <= 2 * g_cus && small_group);
   // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
   return a.n_utts > 0 && !want_group && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width);
 }

@@ -268,6 +268,7 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   if (rc == 0 && a.n_utts > 0 && a.params.texts_only && a.text_scratch) assemble_texts(a);
   return rc;
 }
+bool beam_kernel_depends_on_input(const BeamArgs&) { return false; }  // (the simulator runs the wave kernel unless told otherwise)
 bool wave_kernel_chosen(const BeamArgs& a) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");  // "wave" / "group": same switch as the HIP backend (default here: wave)
   const bool want_group = force && force[0] == 'g';

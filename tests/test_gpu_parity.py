@@ -731,3 +731,34 @@ def test_hip_flat_model_file_round_trip(lm, tmp_path):
         NgramModel(str(bad))
     with pytest.raises(NotImplementedError):  # kenlm's own binaries stay refused (no sample to pin a reader against)
         NgramModel(str(tmp_path / "model.binary"))
+
+
+def test_hip_small_batches_choose_their_beam_kernel_by_the_input(lm):
+    """Up to two utterances per CU the launcher looks at what the prune stage counted (api.cpp: one read-back between the two
+    stages; backend_hip.hip: wave_kernel_chosen): real-posterior-like input (about one survivor a frame) runs on the wave
+    kernel, the bench-like input (about six) on the workgroup kernel -- and both kernels return the same beams either way."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    _loaded_native()
+    if os.environ.get("CTCDEC_BEAM_KERNEL"):
+        pytest.skip("the kernel is forced in this run")
+    labels = synth.LIBRI_LABELS
+    dec = build_ctcdecoder(labels, lm.path)
+    peaky = torch.from_numpy(synth.d_peaky(7, 0, 300, labels, False, lm.words, lm.sentences, 28)).cuda()
+    flat = torch.from_numpy(synth.d_flat(2, 0, 120, 29)).cuda()
+    out_p = dec.decode_beams(peaky, beam_width=50)
+    assert dec.last_beam_kernel == 1, "peaky posteriors: the wave kernel"
+    out_f = dec.decode_beams(flat, beam_width=50)
+    assert dec.last_beam_kernel == 2, "flat logits (29 survivors a frame): the workgroup kernel"
+    as_t = lambda beams: [(b.text, tuple(b.text_frames), b.logit_score, b.lm_score) for b in beams]  # noqa: E731
+    for x, got in ((peaky, out_p), (flat, out_f)):
+        for forced, code in (("wave", 1), ("group", 2)):
+            os.environ["CTCDEC_BEAM_KERNEL"] = forced
+            try:
+                again = dec.decode_beams(x, beam_width=50)
+                assert dec.last_beam_kernel == code
+            finally:
+                del os.environ["CTCDEC_BEAM_KERNEL"]
+            assert as_t(again) == as_t(got), forced
