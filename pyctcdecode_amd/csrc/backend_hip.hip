@@ -1587,20 +1587,22 @@ static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
 int last_beam_kernel() { return g_last_kernel; }
 
 bool beam_kernel_depends_on_input(const BeamArgs& a) {
-  return !getenv("CTCDEC_BEAM_KERNEL") && a.n_utts > 0 && a.n_utts <= 2 * g_cus && wave_eligible(a.tables, a.params) &&
+  return !getenv("CTCDEC_BEAM_KERNEL") && a.n_utts > 0 && a.n_utts <= g_cus && wave_eligible(a.tables, a.params) &&
          a.max_import <= wave_bucket(a.params.beam_width);
 }
 
 bool wave_kernel_chosen(const BeamArgs& a) {
   const char* force = getenv("CTCDEC_BEAM_KERNEL");
-  // Small batches (the GPU is under-filled): by the input. Round 5 measured one utterance per call on real-posterior-like
+  // Small batches (at most one utterance per CU): by the input. Round 5 measured one utterance per call on real-posterior-like
   // input (371 x 29, ~1.3 survivors a frame, most frames consumed as single-label runs): 1.01 ms on one wave against 1.69 ms
-  // on the workgroup kernel; on the bench input (~6 survivors a frame) 11.3 against 10.5 ms for one utterance and 11.95
-  // against 12.2 ms for 512; on flat logits (29 survivors a frame, thousands of candidates) the workgroup kernel is four times
-  // faster. Hence: up to one utterance per CU the wave kernel below 3 survivors a frame, up to two per CU below 8; unknown
-  // (surv_x16 == 0: the caller did not ask) the workgroup kernel.
+  // on the workgroup kernel; on the bench input (~6 survivors a frame) 11.3 against 10.5 ms for one utterance; on flat logits
+  // (29 survivors a frame, thousands of candidates) the workgroup kernel is four times faster. Hence: the wave kernel below 3
+  // survivors a frame; unknown (surv_x16 == 0: the caller did not ask) the workgroup kernel. Between one and two utterances
+  // per CU the density says too little -- 512 bench utterances 11.5 vs 12.1 ms in favour of the wave kernel, 512 utterances of
+  // BASELINE configs[2] (32 character labels, a 4-gram: ~5 survivors but many live beams) 31.7 vs 17.9 ms against it: the
+  // workgroup kernel stays.
   bool small_group = true;
-  if (a.surv_x16 > 0) small_group = a.surv_x16 > (a.n_utts <= g_cus ? 3 * 16 : 8 * 16);
+  if (a.surv_x16 > 0 && a.n_utts <= g_cus) small_group = a.surv_x16 > 3 * 16;
   const bool want_group = force ? force[0] == 'g' : (a.n_utts <= 2 * g_cus && small_group);
   // (streaming: a stream may carry in more beams than this call's beam_width -- up to the workgroup kernel's table)
   return a.n_utts > 0 && !want_group && wave_eligible(a.tables, a.params) && a.max_import <= wave_bucket(a.params.beam_width);
