@@ -118,3 +118,19 @@ def test_python_limits_match_the_header():
     with open(os.path.join(ROOT, "include", "ctcdec.h")) as f:
         header = f.read()
     assert int(re.search(r"#define\s+CTCDEC_MAX_BEAM_WIDTH\s+(\d+)", header).group(1)) == B.MAX_BEAM_WIDTH
+
+
+def test_wave_kernel_keeps_its_register_budget():
+    """Four waves per SIMD -- sixteen utterances per CU, the headline batch in one round -- need the wave kernel within 128
+    registers WITHOUT spills to scratch memory; that rests on an internal LLVM switch (-mllvm -disable-machine-licm, build.py)
+    that a toolchain upgrade could silently change. The compiler's own resource remarks for the shipped flags are the check."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "beam_wave<100, 4, false"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1000:]
+    rows = [ln.split() for ln in out.stdout.splitlines() if "beam_wave<100, 4, false>" in ln]
+    assert len(rows) == 1, out.stdout
+    sgpr, vgpr, agpr, scratch, sgpr_spill, vgpr_spill, occ = (int(v) for v in rows[0][-8:-1])
+    assert vgpr + agpr <= 128 and vgpr_spill == 0 and occ == 4, rows[0]
