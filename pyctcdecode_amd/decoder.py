@@ -434,31 +434,26 @@ class _DeviceStreams:
         return out
 
     def _note_memo_entries(self, res, pk, built, b_off, nb: int, n_lms: int) -> None:
-        """The caller's caches get an entry for every returned text, as the reference's decode leaves them (decoder.py:387-396);
-        the entries' LM-state objects are made on demand from a private copy of the read's packed states."""
-        raw = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,)).tolist()
-        st_bytes = C.string_at(C.cast(pk.lm_state, C.c_void_p), nb * C.sizeof(B.LmState))
-        more = None
-        if n_lms > 1:  # the other models' states: one native call per (stream, beam) -- kept eager (rare, short lists)
-            more = True
-        ssz = C.sizeof(B.LmState)
-
-        def state_maker(j):
-            def make():
-                return KenlmState(NgramState.from_c(B.LmState.from_buffer_copy(st_bytes, j * ssz)))
-            return make
-
+        """The caller's caches get an entry for every returned text, as the reference's decode leaves them (decoder.py:387-396).
+        A cache that get_starting_state() handed out (_LazyMemo) takes ONE note per read and makes the entries when somebody
+        looks; a caller's own dict is filled here. The entries' LM-state objects are made on demand from a private copy of the
+        read's packed states (several LMs: eagerly, one native call per beam -- rare, short lists)."""
+        raws = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,)).tolist()
+        store = _StateStore(C.string_at(C.cast(pk.lm_state, C.c_void_p), nb * C.sizeof(B.LmState)))
         for u in range(self.n):
             memo = self.memos[u] if u < len(self.memos) else {}
-            j = int(b_off[u])
-            j0 = j
+            j0 = int(b_off[u])
+            if n_lms == 1 and type(memo) is _LazyMemo:
+                memo._note(built[u], raws, store, j0)
+                continue
+            j = j0
             for beam in built[u]:
                 key = (beam.text, False)
                 if key not in memo:
-                    if more:
-                        memo[key] = (raw[j], raw[j], self._state_of(res, pk, u, j, j - j0, n_lms))
+                    if n_lms > 1:
+                        memo[key] = (raws[j], raws[j], self._state_of(res, pk, u, j, j - j0, n_lms))
                     else:
-                        memo[key] = _MemoEntry(raw[j], state_maker(j))
+                        memo[key] = _MemoEntry.make(raws[j], store, j)
                 j += 1
 
     def _state_of(self, res, pk, u: int, j: int, j_in_stream: int, n_lms: int) -> AbstractLMState:
@@ -511,22 +506,42 @@ def _lazy_frames_factory(word_start, word_end):
     return frames_of
 
 
+class _StateStore:
+    """The packed LM states of one device read (a private copy: the result is freed after the read) and the state objects made
+    from them so far."""
+
+    __slots__ = ("_bytes", "_made")
+
+    def __init__(self, state_bytes: bytes):
+        self._bytes = state_bytes
+        self._made: Dict[int, AbstractLMState] = {}
+
+    def state(self, j: int) -> AbstractLMState:
+        st = self._made.get(j)
+        if st is None:
+            st = KenlmState(NgramState.from_c(B.LmState.from_buffer_copy(self._bytes, j * C.sizeof(B.LmState))))
+            self._made[j] = st
+        return st
+
+
 class _MemoEntry(tuple):
     """A memo entry (lm_score + hot-word score, raw lm_score, LM state) of a text a device read returned -- the tuple the
     reference's cache holds (decoder.py:387-396) -- whose STATE object is built from the read's packed states when somebody
-    unpacks or indexes the entry (the import path of edited beams does; a caller that only hands its caches back never does)."""
+    unpacks or indexes the entry (the import path of edited beams does; a caller that only hands its caches back never does).
+    Storage: (raw, raw, store, index); every way of looking sees the three-tuple."""
 
-    def __new__(cls, raw, make_state):
-        self = tuple.__new__(cls, (raw, raw, None))
-        self._make = make_state
-        self._state = None
-        return self
+    __slots__ = ()
+
+    @staticmethod
+    def make(raw, store: _StateStore, j: int) -> "_MemoEntry":
+        return tuple.__new__(_MemoEntry, (raw, raw, store, j))
 
     def _full(self):
-        if self._make is not None:
-            self._state = self._make()
-            self._make = None
-        return (tuple.__getitem__(self, 0), tuple.__getitem__(self, 1), self._state)
+        g = tuple.__getitem__
+        return (g(self, 0), g(self, 1), g(self, 2).state(g(self, 3)))
+
+    def __len__(self):
+        return 3
 
     def __getitem__(self, k):
         return self._full()[k]
@@ -547,6 +562,53 @@ class _MemoEntry(tuple):
 
     def __reduce__(self):
         return (tuple, (self._full(),))
+
+
+class _LazyMemo(dict):
+    """`cached_lm_scores` as get_starting_state() hands it out (decoder.py:669-679): a dict that remembers what the device reads
+    of its stream returned -- one O(1) note per read -- and turns the notes into entries when somebody LOOKS (any dict method;
+    the import path of edited beams does). The reference fills this cache as a side effect of decoding; doing that eagerly was
+    a tuple, a dict probe and an entry object per returned beam on every read, for a caller that almost never looks.
+    A caller's own plain dict is filled eagerly as before."""
+
+    __slots__ = ("_pending",)
+
+    def __init__(self, *a, **k):
+        dict.__init__(self, *a, **k)
+        self._pending: List[Any] = []
+
+    def _note(self, beams, raws, store: _StateStore, j0: int) -> None:
+        self._pending.append((beams, raws, store, j0))
+
+    def _settle(self) -> None:
+        pend = self._pending
+        if pend:
+            self._pending = []
+            has, put, make = dict.__contains__, dict.__setitem__, _MemoEntry.make
+            for beams, raws, store, j0 in pend:
+                for k, beam in enumerate(beams):
+                    key = (beam.text, False)
+                    if not has(self, key):
+                        put(self, key, make(raws[j0 + k], store, j0 + k))
+
+    def __reduce__(self):
+        self._settle()
+        return (dict, (dict(dict.items(self)),))
+
+
+def _settling(name):
+    def method(self, *a, **k):
+        self._settle()
+        return getattr(dict, name)(self, *a, **k)
+
+    method.__name__ = name
+    return method
+
+
+for _n in ("__getitem__", "__contains__", "__iter__", "__len__", "__repr__", "__eq__", "__ne__", "get", "keys", "values", "items",
+           "copy", "pop", "popitem", "setdefault", "update", "__delitem__", "clear", "__or__", "__ror__", "__ior__", "__reversed__"):
+    setattr(_LazyMemo, _n, _settling(_n))
+_LazyMemo.__hash__ = None  # type: ignore[assignment]
 
 
 class _ResidentBeams(list):
@@ -1057,7 +1119,8 @@ class BeamSearchDecoderCTC:
         if language_model is None:
             cached_lm_scores: Dict[Any, Any] = {}
         else:
-            cached_lm_scores = {("", False): (0.0, 0.0, language_model.get_start_state())}
+            # (a dict -- with the reference's one starting entry -- that files what device reads return lazily: _LazyMemo)
+            cached_lm_scores = _LazyMemo({("", False): (0.0, 0.0, language_model.get_start_state())})
         cached_p_lm_scores: Dict[str, float] = {}
         return start_beam, cached_lm_scores, cached_p_lm_scores
 

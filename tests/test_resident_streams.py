@@ -390,14 +390,37 @@ def test_lazy_text_frames_and_memo_entries_behave_like_the_plain_objects():
     assert f == plain + [(30, 31)] and isinstance(f[0][0], int)
     assert pickle.loads(pickle.dumps(make(0, 2))) == plain and type(pickle.loads(pickle.dumps(make(0, 2)))) is list
     assert copy.deepcopy(make(0, 2)) == plain and repr(make(0, 2)) == repr(plain) and (7, 13) in make(0, 2)
-    calls = []
+    # memo entries: the state object is made from the read's packed states on first use, once
+    import ctypes as C
 
-    def state():
-        calls.append(1)
-        return "STATE"
+    from pyctcdecode_amd import _binding as B
+    from pyctcdecode_amd.decoder import _LazyMemo, _StateStore
+    from pyctcdecode_amd.language_model import KenlmState
 
-    e = _MemoEntry(-1.5, state)
-    assert not calls and len(e) == 3
+    raw_states = (B.LmState * 3)()
+    raw_states[1].length = 2
+    store = _StateStore(C.string_at(C.addressof(raw_states), C.sizeof(raw_states)))
+    e = _MemoEntry.make(-1.5, store, 1)
+    assert len(e) == 3 and not store._made
     lm_hw, raw, st = e
-    assert (lm_hw, raw, st) == (-1.5, -1.5, "STATE") and e[2] == "STATE" and len(calls) == 1
-    assert e == (-1.5, -1.5, "STATE") and pickle.loads(pickle.dumps(e)) == (-1.5, -1.5, "STATE")
+    assert (lm_hw, raw) == (-1.5, -1.5) and isinstance(st, KenlmState) and st.state.to_c().length == 2
+    assert e[2] is st and len(store._made) == 1 and e == (-1.5, -1.5, st) and e == _MemoEntry.make(-1.5, store, 1)
+    assert pickle.loads(pickle.dumps(e))[:2] == (-1.5, -1.5) and type(pickle.loads(pickle.dumps(e))) is tuple
+
+    # the cache get_starting_state() hands out: reads are noted in O(1) and become entries when somebody looks
+    class _B:  # (what a returned beam is to the memo: its text)
+        def __init__(self, text):
+            self.text = text
+
+    memo = _LazyMemo({("", False): (0.0, 0.0, "START")})
+    memo._note([_B("a"), _B("a b"), _B("")], [-1.0, -2.0, -9.0], store, 0)
+    assert memo._pending and dict.__len__(memo) == 1  # nothing filed yet
+    assert ("a b", False) in memo and not memo._pending and len(memo) == 3
+    assert memo[("a", False)][0] == -1.0 and memo.get(("a b", False))[1] == -2.0
+    assert memo[("", False)] == (0.0, 0.0, "START")  # (an entry that is already there is not replaced)
+    memo._note([_B("c")], [-3.0], store, 2)
+    memo[("c", False)] = (1.0, 1.0, "MINE")  # a caller's own entry wins over a pending note
+    assert memo[("c", False)] == (1.0, 1.0, "MINE") and sorted(k[0] for k in memo) == ["", "a", "a b", "c"]
+    memo._note([_B("d")], [-4.0], store, 0)
+    plain = pickle.loads(pickle.dumps(memo))
+    assert type(plain) is dict and ("d", False) in plain and len(plain) == 5
