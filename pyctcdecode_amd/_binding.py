@@ -206,7 +206,7 @@ def _pytexts():
                 dll.ctcdec_py_output_beams.restype = C.py_object
                 dll.ctcdec_py_output_beams.argtypes = [C.py_object, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
                                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
-                                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.py_object]
+                                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.py_object, C.py_object]
                 dll.ctcdec_py_lm_beams.restype = C.py_object
                 dll.ctcdec_py_lm_beams.argtypes = [C.py_object, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p,
                                                    C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int32), C.py_object,
@@ -232,13 +232,14 @@ def texts_of(lib: "Library", res) -> Optional[list]:
     return dll.ctcdec_py_texts_from_blocks(pool, off, ln, n.value)
 
 
-def output_beams(cls, pk: "Packed", states: Optional[list]) -> Optional[list]:
-    """The OutputBeam lists of a packed result, built in C (csrc/pytexts.c); None when the helper was not built."""
+def output_beams(cls, pk: "Packed", states: Optional[list], frames_of=None) -> Optional[list]:
+    """The OutputBeam lists of a packed result, built in C (csrc/pytexts.c); None when the helper was not built.
+    frames_of(text, w0, w1): the caller's (lazy) text_frames object for words w0 .. w1-1 of the result."""
     dll = _pytexts()
     if not dll:
         return None
     return dll.ctcdec_py_output_beams(cls, pk.n_utts, pk.beam_off, pk.text_off, pk.text_blob, pk.logit_score, pk.lm_score,
-                                      pk.word_cnt_off, pk.word_start, pk.word_end, states)
+                                      pk.word_cnt_off, pk.word_start, pk.word_end, states, frames_of)
 
 
 def lm_beams(cls, n_streams: int, pk: "Packed", labels: list, frames_of=None) -> Optional[list]:

@@ -96,9 +96,12 @@ static PyObject* word_frames(const char* p, int64_t len, int64_t n_words, const 
   return frames;
 }
 
+/* frames_of (a callable, or None): when given, a beam's text_frames is frames_of(text, w0, w1) -- the caller's lazy view of the
+ * words w0 .. w1-1 of the result, paired with the words of `text` when somebody looks -- instead of the list built here: a
+ * decode_beams_batch of thousands of utterances returns tens of millions of (word, (start, end)) tuples (round 5). */
 PyObject* ctcdec_py_output_beams(PyObject* cls, int64_t n_utts, const int64_t* beam_off, const int64_t* text_off,
                                  const char* text_blob, const double* logit, const double* lm, const int64_t* word_cnt_off,
-                                 const int32_t* word_start, const int32_t* word_end, PyObject* states) {
+                                 const int32_t* word_start, const int32_t* word_end, PyObject* states, PyObject* frames_of) {
   if (beam_attr_names() < 0) return NULL;
   if (!PyType_Check(cls)) {
     PyErr_SetString(PyExc_TypeError, "OutputBeam class expected");
@@ -121,7 +124,10 @@ PyObject* ctcdec_py_output_beams(PyObject* cls, int64_t n_utts, const int64_t* b
       if (!obj) goto fail;
       PyList_SET_ITEM(beams, (Py_ssize_t)(k - k0), obj);
       PyObject* text = PyUnicode_DecodeUTF8(tp0, (Py_ssize_t)tlen, "strict");
-      PyObject* frames = text ? word_frames(tp0, tlen, w1 - w0, word_start ? word_start + w0 : NULL, word_end ? word_end + w0 : NULL) : NULL;
+      const int lazy = frames_of != NULL && frames_of != Py_None;
+      PyObject* frames = !text ? NULL
+                         : lazy ? PyObject_CallFunction(frames_of, "OLL", text, (long long)w0, (long long)w1)
+                                : word_frames(tp0, tlen, w1 - w0, word_start ? word_start + w0 : NULL, word_end ? word_end + w0 : NULL);
       PyObject* lg = frames ? PyFloat_FromDouble(logit[k]) : NULL;
       PyObject* ls = lg ? PyFloat_FromDouble(lm[k]) : NULL;
       PyObject* st = Py_None;

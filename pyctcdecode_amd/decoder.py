@@ -469,21 +469,28 @@ class _DeviceStreams:
 
 
 class _LazyFrames(list):
-    """text_frames of a streaming LMBeam: the (start, end) frame pairs of the beam's words, kept as a window of the read's two
+    """text_frames of a returned beam -- an LMBeam's (start, end) pairs, an OutputBeam's (word, (start, end)) pairs --, kept as a
+    window of the result's two
     int32 arrays until somebody looks (then an ordinary list of tuples, equal to what the reference returns,
     decoder.py:653-667). A stream that has run for a thousand frames carries ~250 words per beam; building their tuples for
     every beam of every stream was most of the time of reading the beams (round 4: 7.8 ms for 64 streams, 11.3 ms with the
     last chunk), and a caller that hands the beams back, shows the best text or looks at one beam's frames never needs them.
     Same caveat as _ResidentBeams for code that reads list storage through the C API without calling a method."""
 
-    __slots__ = ("_src", "_lo", "_hi")
+    __slots__ = ("_src", "_lo", "_hi", "_text")
 
     def _fill(self) -> None:
         src = self._src
         if src is not None:
             self._src = None
             ws, we = src
-            list.extend(self, zip(ws[self._lo:self._hi].tolist(), we[self._lo:self._hi].tolist()))
+            spans = zip(ws[self._lo:self._hi].tolist(), we[self._lo:self._hi].tolist())
+            text = self._text
+            if text is None:  # an LMBeam's frames: (start, end) per word
+                list.extend(self, spans)
+            else:  # an OutputBeam's: (word, (start, end)) (decoder.py:653-667)
+                self._text = None
+                list.extend(self, zip(text.split(" ") if text else (), spans))
 
     _touch = _fill
 
@@ -501,6 +508,22 @@ def _lazy_frames_factory(word_start, word_end):
         f._src = src
         f._lo = lo
         f._hi = hi
+        f._text = None
+        return f
+
+    return frames_of
+
+
+def _lazy_word_frames_factory(word_start, word_end):
+    """frames_of(text, w0, w1) for OutputBeams: the words of `text` paired with their frames when somebody looks"""
+    src = (word_start, word_end)
+
+    def frames_of(text, lo, hi):
+        f = _LazyFrames()
+        f._src = src
+        f._lo = lo
+        f._hi = hi
+        f._text = text
         return f
 
     return frames_of
@@ -914,7 +937,15 @@ class BeamSearchDecoderCTC:
                 for u in range(nu):
                     for k in range(int(beam_off[u]), int(beam_off[u + 1])):
                         states.append(self._beam_state(res, pk, u, k, k - int(beam_off[u])))
-            built = B.output_beams(OutputBeam, pk, states)
+            frames_of = None
+            if not os.environ.get("CTCDEC_EAGER_FRAMES"):  # (diagnostics / tests: plain lists of tuples built in C)
+                if nw:
+                    ws = np.ctypeslib.as_array(pk.word_start, shape=(nw,)).copy()
+                    we = np.ctypeslib.as_array(pk.word_end, shape=(nw,)).copy()
+                else:
+                    ws = we = np.zeros(0, dtype=np.int32)
+                frames_of = _lazy_word_frames_factory(ws, we)
+            built = B.output_beams(OutputBeam, pk, states, frames_of)
             if built is not None:
                 return built
         text_off = np.ctypeslib.as_array(pk.text_off, shape=(nb + 1,))

@@ -390,6 +390,12 @@ def test_lazy_text_frames_and_memo_entries_behave_like_the_plain_objects():
     assert f == plain + [(30, 31)] and isinstance(f[0][0], int)
     assert pickle.loads(pickle.dumps(make(0, 2))) == plain and type(pickle.loads(pickle.dumps(make(0, 2)))) is list
     assert copy.deepcopy(make(0, 2)) == plain and repr(make(0, 2)) == repr(plain) and (7, 13) in make(0, 2)
+    # an OutputBeam's frames: the words of the beam's text paired with their (start, end) when somebody looks
+    from pyctcdecode_amd.decoder import _lazy_word_frames_factory
+
+    wmake = _lazy_word_frames_factory(ws, we)
+    assert wmake("bugs bunny", 0, 2) == [("bugs", (0, 6)), ("bunny", (7, 13))] and wmake("", 0, 0) == []
+    assert [w for w, _ in wmake("a b c", 0, 3)] == ["a", "b", "c"] and wmake("x", 2, 3)[0] == ("x", (20, 25))
     # memo entries: the state object is made from the read's packed states on first use, once
     import ctypes as C
 
