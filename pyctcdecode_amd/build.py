@@ -80,9 +80,37 @@ def _obj_dir() -> str:
     return os.path.join(HERE, "csrc", "_obj")
 
 
+def source_tag() -> str:
+    """SHA-256 over what the library is made from: every source and header (name and bytes), every translation unit's command line
+    (paths relative to the package) and the compilers' versions. Two trees with the same tag build the same kernels; the library
+    FILE is not that stable: hipcc derives each translation unit's `__hip_cuid_*` symbol from the absolute path it compiles."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS) + ["../../include/ctcdec.h"]:
+        with open(os.path.join(SRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    for src in SOURCES:
+        cmd = _compile_cmd(src, os.path.join(_obj_dir(), src + ".o"))
+        h.update((" ".join(cmd).replace(HERE, "$PKG") + "\n" + _tool_version(cmd[0]) + "\n").encode())
+    return h.hexdigest()
+
+
+def _lib_stamp_ok():
+    """True / False when libctcdec.so.stamp says the library is / is not built from this tree, None without a stamp."""
+    try:
+        with open(OUT + ".stamp") as f:
+            return f.read().strip() == source_tag()
+    except OSError:
+        return None
+
+
 def needs_build() -> bool:
     if not os.path.exists(OUT):
         return True
+    ok = _lib_stamp_ok()
+    if ok is not None:
+        return not ok  # (contents, not mtimes: a checkout that refreshes every file's time does not rebuild the same library)
     t = os.path.getmtime(OUT)
     deps = [os.path.join(SRC, f) for f in SOURCES + HEADERS + ["pytexts.c"]] + [os.path.join(HERE, "..", "include", "ctcdec.h")]
     if any(os.path.getmtime(d) > t for d in deps):
@@ -129,6 +157,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     os.replace(OUT + ".tmp", OUT)
+    with open(OUT + ".stamp", "w") as f:
+        f.write(source_tag())
     build_pytexts(verbose)
     return OUT
 

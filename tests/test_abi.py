@@ -134,3 +134,33 @@ def test_wave_kernel_keeps_its_register_budget():
     assert len(rows) == 1, out.stdout
     sgpr, vgpr, agpr, scratch, sgpr_spill, vgpr_spill, occ = (int(v) for v in rows[0][-8:-1])
     assert vgpr + agpr <= 128 and vgpr_spill == 0 and occ == 4, rows[0]
+
+
+def test_committed_pmc_summary_is_bound_to_the_tree_it_was_measured_on(monkeypatch):
+    """bench.py fills roofline.traffic only from a PMC summary of THIS library: by the file's hash, or -- a rebuild of the same tree
+    under another root differs in hipcc's path-derived symbols -- by the hash of sources, command lines and compilers."""
+    import argparse
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    tag = build_mod.source_tag()
+    assert build_mod.source_tag() == tag and len(tag) == 64
+    monkeypatch.setenv("CTCDEC_HIPCC_EXTRA", "-DSOMETHING_ELSE")
+    assert build_mod.source_tag() != tag  # other flags are another library
+    monkeypatch.delenv("CTCDEC_HIPCC_EXTRA")
+    with open(os.path.join(root, bench.PMC_FILE)) as f:
+        pmc = json.load(f)
+    args = argparse.Namespace(frames=bench.T, workload="headline")
+    got, why = bench.load_pmc(args)
+    if pmc["source_sha16"] == tag[:16] and build_mod._lib_stamp_ok():
+        assert got is not None and "bound_by" in got, why
+    else:  # the tree moved on after the passes: the summary must be refused, loudly
+        assert got is None and "traffic withheld" in why
+    monkeypatch.setattr(bench, "binary_tag", lambda: "0" * 16)
+    monkeypatch.setattr(build_mod, "source_tag", lambda: "1" * 64)
+    got, why = bench.load_pmc(args)
+    assert got is None and "traffic withheld" in why
