@@ -92,7 +92,9 @@ def source_tag() -> str:
             h.update(name.encode() + b"\0" + f.read() + b"\0")
     for src in SOURCES:
         cmd = _compile_cmd(src, os.path.join(_obj_dir(), src + ".o"))
-        h.update((" ".join(cmd).replace(HERE, "$PKG") + "\n" + _tool_version(cmd[0]) + "\n").encode())
+        # (the compiler by its name and version, not by where this machine keeps it)
+        line = " ".join([os.path.basename(cmd[0])] + cmd[1:]).replace(HERE, "$PKG")
+        h.update((line + "\n" + _tool_version(cmd[0]) + "\n").encode())
     return h.hexdigest()
 
 
