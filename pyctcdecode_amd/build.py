@@ -99,12 +99,17 @@ def source_tag() -> str:
 
 
 def _lib_stamp_ok():
-    """True / False when libctcdec.so.stamp says the library is / is not built from this tree, None without a stamp."""
+    """True / False when libctcdec.so.stamp says the library is / is not built from this tree, None without a stamp.
+    A box that ships the library and its stamp but no hipcc cannot rebuild anything: what is there counts as built."""
     try:
         with open(OUT + ".stamp") as f:
-            return f.read().strip() == source_tag()
+            stamp = f.read().strip()
     except OSError:
         return None
+    try:
+        return stamp == source_tag()
+    except RuntimeError:  # hipcc not found
+        return True
 
 
 def needs_build() -> bool:
@@ -127,7 +132,7 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
-        if not os.path.exists(PYTEXTS):
+        if pytexts_needs_build():
             build_pytexts(verbose)
         return OUT
     obj_dir = _obj_dir()
@@ -168,23 +173,52 @@ def build(force: bool = False, verbose: bool = True) -> str:
 PYTEXTS = os.path.join(HERE, "_pytexts.so")
 
 
-def build_pytexts(verbose: bool = True) -> str:
-    """The shell's one C helper (csrc/pytexts.c: a result's texts as a list of str without three passes over the blob).
-    Optional: without Python's headers the shell splits the blob in Python."""
+def _pytexts_cmd():
     import sysconfig
 
     inc = sysconfig.get_paths().get("include")
-    src = os.path.join(SRC, "pytexts.c")
     if not inc or not os.path.exists(os.path.join(inc, "Python.h")):
-        return ""
+        return None
     cc = os.environ.get("CC") or shutil.which("gcc") or "gcc"
-    cmd = [cc, "-O2", "-fPIC", "-shared", "-I" + inc, src, "-o", PYTEXTS + ".tmp"]
+    return [cc, "-O2", "-fPIC", "-shared", "-I" + inc, os.path.join(SRC, "pytexts.c"), "-o", PYTEXTS + ".tmp"]
+
+
+def _pytexts_tag(cmd) -> str:
+    """The helper's own stamp (the library's source_tag() does not cover it): its source bytes, command line and compiler."""
+    import hashlib
+
+    with open(os.path.join(SRC, "pytexts.c"), "rb") as f:
+        body = f.read()
+    return hashlib.sha256(body + b"\0" + _stamp(cmd).encode()).hexdigest()
+
+
+def pytexts_needs_build() -> bool:
+    cmd = _pytexts_cmd()
+    if cmd is None:
+        return False  # cannot be built here (no Python headers): the shell splits the blob in Python
+    if not os.path.exists(PYTEXTS):
+        return True
+    try:
+        with open(PYTEXTS + ".stamp") as f:
+            return f.read().strip() != _pytexts_tag(cmd)
+    except OSError:
+        return os.path.getmtime(os.path.join(SRC, "pytexts.c")) > os.path.getmtime(PYTEXTS)
+
+
+def build_pytexts(verbose: bool = True) -> str:
+    """The shell's one C helper (csrc/pytexts.c: a result's texts as a list of str without three passes over the blob).
+    Optional: without Python's headers the shell splits the blob in Python."""
+    cmd = _pytexts_cmd()
+    if cmd is None:
+        return ""
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:
         subprocess.check_call(cmd)
     except (OSError, subprocess.CalledProcessError):
         return ""
+    with open(PYTEXTS + ".stamp", "w") as f:
+        f.write(_pytexts_tag(cmd))
     os.replace(PYTEXTS + ".tmp", PYTEXTS)
     return PYTEXTS
 

@@ -1122,15 +1122,17 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     if (be::launch_prune(pa, &err) || (!late_beam && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
     uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (be::d2h(flags, dec->w_flags.p, 32, &err)) return fail(CTCDEC_ERR_DEVICE, err);
-    const uint32_t surv_total = flags[4];  // (pass 0 counted every row as logits)
+    uint32_t surv_total = flags[4];  // (pass 0 counted every row as logits)
     if (flags[2]) {  // rows that sum to about 1: the reference's test in its own dtype and summation order (decoder.py:760)
       if (be::launch_sniff_exact(pa, &err) || be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
     if (flags[1]) {  // some utterance holds probabilities: redo those rows as log(clip(p)), then the beams
       pa.pass = 1;
-      if (be::zero(dec->w_flags.p, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);  // pass-0 overflows of those rows are void
+      // pass-0 overflows of those rows are void, and so is its survivor count (flags[4]: the pass counts them again)
+      if (be::zero(dec->w_flags.p, 4, &err) || be::zero((char*)dec->w_flags.p + 16, 4, &err)) return fail(CTCDEC_ERR_DEVICE, err);
       if (be::launch_prune(pa, &err) || (!late_beam && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
-      if (be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      if (be::d2h(flags, dec->w_flags.p, 32, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+      surv_total = flags[4];
     }
     const uint32_t ovf = flags[0];
     if (!ovf) {

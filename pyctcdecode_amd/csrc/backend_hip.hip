@@ -240,6 +240,18 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
     if (amb) a.overflow[2] = 1u;  // flags[2]: some utterance needs the exact test
   }
 }
+// pass 1 redid the rows of the probability utterances as log(clip(p)): the survivors of all rows counted again (pass 0 counted
+// those rows as logits -- softmax outputs read as logits are nearly flat, almost every label survives -- and a small batch
+// chooses its beam kernel by this number). The caller zeroes overflow[4] before the pass.
+__global__ __launch_bounds__(64) void utt_recount(PruneArgs a) {
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t r0 = a.utt_row0[u], r1 = a.utt_row0[u + 1];
+  double c = 0.0;
+  for (int64_t r = r0 + lane; r < r1; r += 64) c += (double)a.surv_cnt[r];
+  c = wave_sum(c);
+  if (lane == 0) atomicAdd(&a.overflow[4], (uint32_t)fmin(c, 1.0e9));
+}
 // one workgroup per ambiguous utterance, one thread per row (rare path: probability inputs, or logits whose rows sum to ~1)
 __global__ __launch_bounds__(256) void utt_sniff_exact(PruneArgs a) {
   const int u = blockIdx.x;
@@ -1493,8 +1505,9 @@ int launch_prune(const PruneArgs& a, std::string* err) {
 #undef CTC_LAUNCH_PRUNE
     HIP_TRY(hipGetLastError());
   }
-  if (a.pass == 0 && a.n_utts > 0) {
-    hipLaunchKernelGGL(utt_sniff, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
+  if (a.n_utts > 0) {
+    if (a.pass == 0) hipLaunchKernelGGL(utt_sniff, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
+    else hipLaunchKernelGGL(utt_recount, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, a);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(g_ev[1], g_stream));

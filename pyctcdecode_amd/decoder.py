@@ -439,21 +439,25 @@ class _DeviceStreams:
         looks; a caller's own dict is filled here. The entries' LM-state objects are made on demand from a private copy of the
         read's packed states (several LMs: eagerly, one native call per beam -- rare, short lists)."""
         raws = np.ctypeslib.as_array(pk.raw_lm_score, shape=(nb,)).tolist()
-        store = _StateStore(C.string_at(C.cast(pk.lm_state, C.c_void_p), nb * C.sizeof(B.LmState)))
+        sz = C.sizeof(B.LmState)
+        whole = C.string_at(C.cast(pk.lm_state, C.c_void_p), nb * sz)
         for u in range(self.n):
             memo = self.memos[u] if u < len(self.memos) else {}
             j0 = int(b_off[u])
+            beams = built[u]
+            # (a stream's entries keep only that stream's slice of the read's packed states and scores alive)
+            store = _StateStore(whole[j0 * sz:(j0 + len(beams)) * sz])
             if n_lms == 1 and type(memo) is _LazyMemo:
-                memo._note(built[u], raws, store, j0)
+                memo._note(beams, raws[j0:j0 + len(beams)], store)
                 continue
             j = j0
-            for beam in built[u]:
+            for beam in beams:
                 key = (beam.text, False)
                 if key not in memo:
                     if n_lms > 1:
                         memo[key] = (raws[j], raws[j], self._state_of(res, pk, u, j, j - j0, n_lms))
                     else:
-                        memo[key] = _MemoEntry.make(raws[j], store, j)
+                        memo[key] = _MemoEntry.make(raws[j], store, j - j0)
                 j += 1
 
     def _state_of(self, res, pk, u: int, j: int, j_in_stream: int, n_lms: int) -> AbstractLMState:
@@ -478,6 +482,14 @@ class _LazyFrames(list):
     Same caveat as _ResidentBeams for code that reads list storage through the C API without calling a method."""
 
     __slots__ = ("_src", "_lo", "_hi", "_text")
+
+    def __init__(self, *a) -> None:
+        # (an instance made as type(frames)(iterable) -- dataclasses.asdict and copy-like idioms rebuild list fields that way --
+        #  is an ordinary, already filled list)
+        self._src = None
+        self._lo = self._hi = 0
+        self._text = None
+        list.__init__(self, *a)
 
     def _fill(self) -> None:
         src = self._src
@@ -600,19 +612,26 @@ class _LazyMemo(dict):
         dict.__init__(self, *a, **k)
         self._pending: List[Any] = []
 
-    def _note(self, beams, raws, store: _StateStore, j0: int) -> None:
-        self._pending.append((beams, raws, store, j0))
+    _MAX_PENDING = 8
+
+    def _note(self, beams, raws, store: _StateStore) -> None:
+        # a snapshot of the read's beams (the caller may sort / delete in the list it was handed; entries pair beams with the
+        # stream's slice of the read's raw scores and states BY POSITION); a stream that is read
+        # every chunk and never looks at its cache settles after a few notes instead of pinning every read it ever made
+        self._pending.append((tuple(beams), raws, store))
+        if len(self._pending) > self._MAX_PENDING:
+            self._settle()
 
     def _settle(self) -> None:
         pend = self._pending
         if pend:
             self._pending = []
             has, put, make = dict.__contains__, dict.__setitem__, _MemoEntry.make
-            for beams, raws, store, j0 in pend:
+            for beams, raws, store in pend:
                 for k, beam in enumerate(beams):
                     key = (beam.text, False)
                     if not has(self, key):
-                        put(self, key, make(raws[j0 + k], store, j0 + k))
+                        put(self, key, make(raws[k], store, k))
 
     def __reduce__(self):
         self._settle()

@@ -151,3 +151,60 @@ def test_streaming_intermediate_beams_and_batch(sim_library):  # noqa: F811
         assert [(g.text, g.partial_word, g.last_char, tuple(g.partial_frames)) for g in got] == [
             (e.text, e.partial, e.last, tuple(e.pframes)) for e in exp]
     assert outs[0][0].partial_word == "bug" or outs[0][0].partial_word == "bun"
+
+
+def test_returned_beams_survive_dataclasses_asdict_and_json(sim_library):  # noqa: F811
+    """dataclasses.asdict rebuilds list fields as type(field)(iterable): a lazily filled text_frames has to come out of that
+    as an ordinary list (round-5 advisor finding: it raised AttributeError), and json.dumps of the result has to work."""
+    import dataclasses
+    import json
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    dec = build_ctcdecoder(SAMPLE_LABELS, TOY_ARPA)
+    outs = dec.decode_beams(TEST_LOGITS)
+    plain = [(b.text, [(w, (int(s), int(e))) for w, (s, e) in b.text_frames]) for b in outs]
+    for b, (text, frames) in zip(dec.decode_beams(TEST_LOGITS), plain):
+        d = dataclasses.asdict(dataclasses.replace(b, last_lm_state=None))
+        assert d["text"] == text and len(d["text_frames"]) == len(frames)
+        assert [(w, tuple(se)) for w, se in d["text_frames"]] == frames
+        back = json.loads(json.dumps(d))
+        assert [(w, tuple(se)) for w, se in back["text_frames"]] == frames
+    beams, c1, c2 = dec.get_starting_state()
+    part = dec.partial_decode_beams(TEST_LOGITS, c1, c2, beams, 0, is_end=True)
+    for p in part:
+        d = dataclasses.asdict(p)
+        assert [tuple(f) for f in d["text_frames"]] == [tuple(f) for f in p.text_frames]
+        json.dumps(d)
+    # and the idiom itself: a copy made through the type is an ordinary, equal list
+    tf = dec.decode_beams(TEST_LOGITS)[0].text_frames
+    assert type(tf)(iter(tf)) == plain[0][1] and len(type(tf)()) == 0
+
+
+def test_memo_notes_are_snapshots_and_bounded(sim_library, monkeypatch):  # noqa: F811
+    """The cache get_starting_state() hands out files its entries lazily, by position in the list a read returned: editing
+    that list in place must not mispair texts with LM scores / states, and a stream that is read every chunk without ever
+    looking at its cache must not pin every read it made."""
+    from pyctcdecode_amd import build_ctcdecoder
+    from pyctcdecode_amd import decoder as D
+
+    monkeypatch.setenv("CTCDEC_RESIDENT_STREAMS", "0")  # (the returned list IS the list that was noted)
+    dec = build_ctcdecoder(SAMPLE_LABELS, TOY_ARPA)
+    beams, c1, c2 = dec.get_starting_state()
+    ref_beams, r1, r2 = dec.get_starting_state()
+    out = dec.partial_decode_beams(TEST_LOGITS[:8], c1, c2, beams, 0, beam_prune_logp=-100.0, token_min_logp=-20.0)
+    ref = dec.partial_decode_beams(TEST_LOGITS[:8], r1, r2, ref_beams, 0, beam_prune_logp=-100.0, token_min_logp=-20.0)
+    want = {k: (v[0], v[1], v[2].state) for k, v in dict(r1).items()}
+    out.reverse()  # the caller edits what it was handed before anybody looks at the cache
+    del out[0]
+    got = {k: (v[0], v[1], v[2].state) for k, v in dict(c1).items()}
+    assert got == want
+    assert len(ref) >= 4 and len({b.text for b in ref}) >= 2
+    # bounded notes
+    beams, c1, c2 = dec.get_starting_state()
+    assert type(c1) is D._LazyMemo
+    done = 0
+    for k in range(0, TEST_LOGITS.shape[0]):
+        beams = dec.partial_decode_beams(TEST_LOGITS[k:k + 1], c1, c2, list(beams), done)
+        done += 1
+        assert len(c1._pending) <= D._LazyMemo._MAX_PENDING
