@@ -122,6 +122,10 @@ struct BeamArgs {
                                // beams; import_xstates likewise), import_off is not used
   int32_t surv_x16;            // 16 x the mean number of survivors per frame of this launch's rows, as the prune stage counted
                                // them (0: not known). Small batches choose their kernel by it (wave_kernel_chosen).
+  // wave kernel, set by launch_beam itself:
+  unsigned long long* wave_clock;  // diagnostics (CTCDEC_WAVE_TIMES=<file>), else nullptr: [n_utts * 4] per workgroup {start, end of
+                               // its wave (100 MHz real-time counter), HW_ID | XCC_ID << 32, frames}
+  int32_t prio_shift;          // >= 0: the wave's issue priority rotates every 2^prio_shift frames (beam_wave_hip.hip); -1: left alone
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 // Will launch_beam run the wave kernel on these arguments (given payload lines)? THE kernel-selection rule, shared by the

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <algorithm>
+#include <vector>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1631,9 +1632,27 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   // batch-size rule (tests, tuning; `wave` still falls back when the decode is not eligible for it).
   const bool wave = a.pay && wave_kernel_chosen(a);
   if (wave) {
-    const int rc = launch_wave(a, g_stream, err);
+    BeamArgs wa = a;
+    // issue priority rotated among the waves of a SIMD (WaveGpuCtx::frame_tick): only where waves share SIMDs
+    const char* pr = getenv("CTCDEC_WAVE_PRIO");
+    wa.prio_shift = pr ? atoi(pr) : -1;
+    // diagnostics: when and where each wave ran -> CTCDEC_WAVE_TIMES=<file> (n_utts x 4 uint64; synchronous)
+    const char* wt = getenv("CTCDEC_WAVE_TIMES");
+    wa.wave_clock = nullptr;
+    if (wt && wt[0]) HIP_TRY(hipMalloc((void**)&wa.wave_clock, (size_t)a.n_utts * 32));
+    const int rc = launch_wave(wa, g_stream, err);
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
+    if (wa.wave_clock) {
+      std::vector<unsigned long long> h((size_t)a.n_utts * 4);
+      HIP_TRY(hipStreamSynchronize(g_stream));
+      HIP_TRY(hipMemcpy(h.data(), wa.wave_clock, h.size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipFree(wa.wave_clock));
+      if (FILE* f = fopen(wt, "wb")) {
+        fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+      }
+    }
     g_last_kernel = 1;
   } else if (a.n_utts > 0) {
     // Eight waves per utterance instead of four when every CU holds at most one utterance (the LDS of a workgroup allows

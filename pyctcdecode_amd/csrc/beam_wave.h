@@ -1978,7 +1978,10 @@ CTC_UNROLL
       tok_load(tr);
       tok_commit(tr);
     }
-    for (int t = 0; t < io.T;) t = step(t);
+    for (int t = 0; t < io.T;) {
+      ctx.frame_tick(t);
+      t = step(t);
+    }
     finalise();
     tick<W_PROF_FINAL>();
   }

@@ -30,6 +30,24 @@ typedef const BeamArgs __attribute__((address_space(4))) * KernArgs;  // the ker
 struct WaveGpuCtx {
   int lane;
   KernArgs ka;
+  // Issue priority (s_setprio). The SIMD's arbiter prefers, at equal priority, the OLDEST of its ready waves: of four resident
+  // waves the first-dispatched runs at nearly a lone wave's pace and the last gets what is left (tools/micro/valu_rates.hip: 5.1 vs
+  // 10 - 17 cycles per instruction) -- the utterances of one launch then finish far apart and the launch lasts as long as the
+  // slowest. Rotating the four priority levels among the waves of a SIMD every 2^prio_shift frames gives each the same share.
+  // Nothing is held for it across the frame loop (the kernel has no scalar register to spare): the shift is re-read from the
+  // argument block, and the wave's slot on its SIMD (HW_ID.wave_id) stands in for its age.
+  __device__ __forceinline__ void frame_tick(int t) {
+    const int32_t sh = fresh()->prio_shift;
+    if (sh < 0) return;
+    uint32_t hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+    switch ((hw + ((uint32_t)t >> sh)) & 3u) {  // (the level is an immediate of the instruction)
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
   // launch constants, re-read where they are used (scalar loads; see WaveDecoder::tab)
   __device__ __forceinline__ KernArgs fresh() const {
     KernArgs p = ka;
@@ -163,8 +181,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BW <= 100 ? 
     io.import_xstates = a.import_xstates ? a.import_xstates + (size_t)u * a.carry_stride * 0 : nullptr;
   }
   WaveGpuCtx ctx{(int)threadIdx.x, (KernArgs)__builtin_amdgcn_kernarg_segment_ptr()};
+  // diagnostics: when did this wave run, and where (the record's address lives in two VECTOR registers across the frame loop:
+  // the kernel has none of the scalar kind to spare)
+  unsigned long long* rec = a.wave_clock ? a.wave_clock + (size_t)blockIdx.x * 4 : nullptr;
+  asm volatile("" : "+v"(rec));
+  if (rec && threadIdx.x == 0) {
+    rec[0] = wall_clock64();
+    rec[3] = (unsigned long long)io.T | ((unsigned long long)(uint32_t)u << 32);
+  }
   WaveDecoder<WaveGpuCtx, BW, ORD, PROF> dec(ctx, view, io);
   dec.run();
+  if (rec && threadIdx.x == 0) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    rec[1] = wall_clock64();
+    rec[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
 }
 
 
