@@ -1061,6 +1061,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   // afterwards and simply redo the affected stage(s).
   if (dec->w_flags.ensure(32, &err) || dec->w_head.ensure(16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   ba.surv_x16 = 0;
+  ba.total_rows = R;
   // Small batches choose their beam kernel by the input (backend: wave_kernel_chosen): their beam stage is launched when the
   // prune stage has reported -- like a resident stream's --, one small read-back between the two stages.
   const bool by_input = !rs && be::beam_kernel_depends_on_input(ba);

@@ -122,10 +122,16 @@ struct BeamArgs {
                                // beams; import_xstates likewise), import_off is not used
   int32_t surv_x16;            // 16 x the mean number of survivors per frame of this launch's rows, as the prune stage counted
                                // them (0: not known). Small batches choose their kernel by it (wave_kernel_chosen).
+  int64_t total_rows;          // frames of all utterances of this launch
   // wave kernel, set by launch_beam itself:
   unsigned long long* wave_clock;  // diagnostics (CTCDEC_WAVE_TIMES=<file>), else nullptr: [n_utts * 4] per workgroup {start, end of
                                // its wave (100 MHz real-time counter), HW_ID | XCC_ID << 32, frames}
-  int32_t prio_shift;          // >= 0: the wave's issue priority rotates every 2^prio_shift frames (beam_wave_hip.hip); -1: left alone
+  int32_t prio_mode;           // issue priority of a wave among the waves of its SIMD (beam_wave_hip.hip, WaveGpuCtx::frame_done):
+                               // 0 left alone; 1 + k: rotated every 2^k frames; 32: by the frames it still has to decode against
+                               // the launch's average (`progress`)
+  unsigned long long* progress;  // [1] frames decoded so far by all waves of the launch (prio_mode 32; zeroed by launch_beam)
+  unsigned long long total_frames;
+  float inv_n_utts;
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 // Will launch_beam run the wave kernel on these arguments (given payload lines)? THE kernel-selection rule, shared by the

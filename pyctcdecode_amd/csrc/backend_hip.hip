@@ -1633,9 +1633,23 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   const bool wave = a.pay && wave_kernel_chosen(a);
   if (wave) {
     BeamArgs wa = a;
-    // issue priority rotated among the waves of a SIMD (WaveGpuCtx::frame_tick): only where waves share SIMDs
+    // issue priority among the waves that share a SIMD (WaveGpuCtx::frame_done). CTCDEC_WAVE_PRIO=none | rot<k> | dyn
     const char* pr = getenv("CTCDEC_WAVE_PRIO");
-    wa.prio_shift = pr ? atoi(pr) : -1;
+    wa.prio_mode = 0;
+    if (pr && pr[0] == 'r') wa.prio_mode = 1 + (pr[1] && pr[2] && pr[3] ? atoi(pr + 3) & 15 : 5);
+    if (pr && pr[0] == 'd') wa.prio_mode = 32;
+    wa.progress = nullptr;
+    wa.total_frames = 0;
+    wa.inv_n_utts = 0.f;
+    if (wa.prio_mode == 32) {
+      static unsigned long long* g_progress = nullptr;
+      if (!g_progress) HIP_TRY(hipMalloc((void**)&g_progress, 8));
+      HIP_TRY(hipMemsetAsync(g_progress, 0, 8, g_stream));
+      wa.progress = g_progress;
+      wa.total_frames = (unsigned long long)a.total_rows;
+      wa.inv_n_utts = 1.0f / (float)a.n_utts;
+      if (a.total_rows >= (1ll << 32)) wa.prio_mode = 0;
+    }
     // diagnostics: when and where each wave ran -> CTCDEC_WAVE_TIMES=<file> (n_utts x 4 uint64; synchronous)
     const char* wt = getenv("CTCDEC_WAVE_TIMES");
     wa.wave_clock = nullptr;

@@ -1979,8 +1979,9 @@ CTC_UNROLL
       tok_commit(tr);
     }
     for (int t = 0; t < io.T;) {
-      ctx.frame_tick(t);
-      t = step(t);
+      const int t2 = step(t);
+      ctx.frame_done(t, t2, io.T);
+      t = t2;
     }
     finalise();
     tick<W_PROF_FINAL>();

@@ -32,21 +32,43 @@ struct WaveGpuCtx {
   KernArgs ka;
   // Issue priority (s_setprio). The SIMD's arbiter prefers, at equal priority, the OLDEST of its ready waves: of four resident
   // waves the first-dispatched runs at nearly a lone wave's pace and the last gets what is left (tools/micro/valu_rates.hip: 5.1 vs
-  // 10 - 17 cycles per instruction) -- the utterances of one launch then finish far apart and the launch lasts as long as the
-  // slowest. Rotating the four priority levels among the waves of a SIMD every 2^prio_shift frames gives each the same share.
-  // Nothing is held for it across the frame loop (the kernel has no scalar register to spare): the shift is re-read from the
-  // argument block, and the wave's slot on its SIMD (HW_ID.wave_id) stands in for its age.
-  __device__ __forceinline__ void frame_tick(int t) {
-    const int32_t sh = fresh()->prio_shift;
-    if (sh < 0) return;
-    uint32_t hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
-    switch ((hw + ((uint32_t)t >> sh)) & 3u) {  // (the level is an immediate of the instruction)
+  // 10 - 17 cycles per instruction; CTCDEC_WAVE_TIMES on the 4096-utterance launch: the four age ranks of a SIMD finish after
+  // 12.9 / 13.7 / 14.5 / 15.6 ms on average) -- and the launch lasts as long as its slowest wave (18.0 ms) while the average wave
+  // is done after 79 % of that. Two remedies, both a handful of scalar instructions per 16 frames:
+  //   rotation (mode 1 + k): the four priority levels go round the waves of a SIMD every 2^k frames -- equal shares
+  //     (age ranks: 13.9 .. 14.6 ms; launch 16.8 ms);
+  //   by remaining work (mode 32): utterances differ (candidates per frame), so equal shares still end 12 - 17 ms apart. Every
+  //     16 frames a wave adds its progress to one counter of the launch and reads back everybody's: whoever has more frames
+  //     left than the average runs at a higher level, whoever is ahead at a lower one.
+  // Nothing is held for it across the frame loop (the kernel has no scalar register to spare): the mode and the counter's
+  // address are re-read from the argument block, and the wave's slot on its SIMD (HW_ID.wave_id) stands in for its age.
+  __device__ __forceinline__ void set_prio(uint32_t p) {
+    switch (p) {  // (the level is an immediate of the instruction)
       case 0: __builtin_amdgcn_s_setprio(0); break;
       case 1: __builtin_amdgcn_s_setprio(1); break;
       case 2: __builtin_amdgcn_s_setprio(2); break;
       default: __builtin_amdgcn_s_setprio(3); break;
     }
+  }
+  // the frames [t, t2) have just been decoded; T: the utterance's length
+  __device__ __forceinline__ void frame_done(int t, int t2, int T) {
+    if ((((uint32_t)t ^ (uint32_t)t2) >> 4) == 0u) return;  // (every 16 frames)
+    const KernArgs k = fresh();
+    const int32_t mode = k->prio_mode;
+    if (mode == 0) return;
+    if (mode < 32) {
+      uint32_t hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(hw));
+      set_prio((hw + ((uint32_t)t2 >> (mode - 1))) & 3u);
+      return;
+    }
+    const uint32_t units = (((uint32_t)t2 >> 4) - ((uint32_t)t >> 4)) << 4;
+    unsigned long long old = 0;
+    if (lane == 0) old = atomicAdd(k->progress, (unsigned long long)units);
+    const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old) + units;  // (launches of < 2^32 frames)
+    const float avg_left = (float)((uint32_t)k->total_frames - done) * k->inv_n_utts;
+    const float d = (float)(T - t2) - avg_left;  // > 0: behind the launch's average
+    set_prio(d > 24.f ? 3u : d > 0.f ? 2u : d > -24.f ? 1u : 0u);
   }
   // launch constants, re-read where they are used (scalar loads; see WaveDecoder::tab)
   __device__ __forceinline__ KernArgs fresh() const {

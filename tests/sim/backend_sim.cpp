@@ -18,6 +18,7 @@
 #include "group_fibers.h"
 #include "../../pyctcdecode_amd/csrc/set_order.h"
 #include "../../pyctcdecode_amd/csrc/np_sum.h"
+#include "../../pyctcdecode_amd/csrc/np_f32.h"
 
 namespace ctc {
 namespace be {
@@ -104,8 +105,34 @@ int launch_prune(const PruneArgs& a, std::string*) {
     const double mean = T > 0 ? np_mean_of_sums(a.row_sum + r0, a.dtype, T) : NAN;
     bool is_prob = np_mean_is_one(mean);
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
+    // float32 rows: the reference's arithmetic stays float32 (decoder.py:180-197, 762 on a float32 array: numpy's float32
+    // exp / log -- its SIMD kernels, restated in np_f32.h --, a float32 pairwise sum, float32 subtractions) and only the clip
+    // against ln(1e-15) widens the result: restated step by step, so that a frame's log-probabilities are the reference's bits.
+    // CTCDEC_PRUNE_EXP=f64 keeps the round-2 behaviour (everything in fp64 from the exact upcast).
+    const char* pe = getenv("CTCDEC_PRUNE_EXP");
+    const bool f32_exact = a.dtype == 0 && !(pe && pe[0] == 'f');
     for (int64_t t = 0; t < T; ++t) {
-      if (is_prob) {
+      if (f32_exact) {
+        const float* xr = (const float*)x + (size_t)t * V;
+        if (is_prob) {
+          const float lo = (float)1e-15;
+          for (int v = 0; v < V; ++v) {
+            float p = xr[v];
+            p = p < lo ? lo : (p > 1.0f ? 1.0f : p);  // (NaN stays NaN, like np.clip)
+            lp[(size_t)v] = (double)np_log_f32(p);
+          }
+        } else {
+          float mx = -INFINITY;
+          for (int v = 0; v < V; ++v) mx = fmaxf(mx, xr[v]);
+          if (!std::isfinite(mx)) mx = 0.0f;
+          const float se = np_pairwise<float>([&](int64_t v) { return np_exp_f32(xr[v] - mx); }, (int64_t)V);
+          const float lse = np_log_f32(se);
+          for (int v = 0; v < V; ++v) {
+            const double y = (double)((xr[v] - mx) - lse);
+            lp[(size_t)v] = y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
+          }
+        }
+      } else if (is_prob) {
         for (int v = 0; v < V; ++v) {
           double p = load(x, a.dtype, (size_t)t * V + v);
           p = p < 1e-15 ? 1e-15 : (p > 1.0 ? 1.0 : p);

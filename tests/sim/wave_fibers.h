@@ -135,7 +135,7 @@ struct SimWaveCtx {
   void wsync() { all(0, 1); }
   void mem_sync() { all(0, 2); }
   void vm_wait() {}  // (device: every global access issued so far has completed)
-  void frame_tick(int) {}  // (device: issue-priority rotation)
+  void frame_done(int, int, int) {}  // (device: issue priority among the waves of a SIMD)
   uint64_t ballot(bool p) {
     const uint64_t* s = all(p ? 1u : 0u, 3);
     uint64_t m = 0;
