@@ -65,6 +65,12 @@ struct PruneArgs {
   int64_t row_base;      // first row of this launch (utt_row0 and the row-indexed arrays are absolute); n_rows rows follow
   uint32_t* slow_rows;   // [n_rows] scratch, or nullptr: rows (relative to row_base) the 64-rows-per-wave kernel hands to the
                          // per-row one; their count is kept in overflow[3]
+  // set by launch_prune itself:
+  int32_t f32_np;        // float32 rows in the reference's own float32 arithmetic (np_f32.h + numpy's summation order): the default;
+                         // 0 under CTCDEC_PRUNE_EXP=pk (round 5's packed polynomial, fp64 from there on) / =f64
+  const uint8_t* np_prog;  // frame_prune_fast, f32_np: the pairwise tree over the leaf sums of one row as (dst, src) pairs
+  const uint16_t* np_leaf; // ... and the leaves as (offset, length) pairs; np_n_leaf of them
+  int32_t np_n_leaf;
 };
 int launch_prune(const PruneArgs& a, std::string* err);
 // decoder.py:760 in the input dtype and numpy's summation order for the utterances pass 0 marked ambiguous

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 #include <math.h>
 #include <stdio.h>
@@ -21,6 +22,7 @@
 #include "beam_core.h"
 #include "beam_wave.h"
 #include "set_order.h"
+#include "np_f32.h"
 #include "set_order_small.h"
 #include "np_sum.h"
 #include "text_wave.h"
@@ -497,6 +499,20 @@ __device__ __forceinline__ double to_logp(double xv, bool is_prob, double mx, do
   return y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
 }
 
+// float32 rows in the reference's own arithmetic (decoder.py:180-197 and :762 on a float32 array): (x - max) - log(sum) in
+// float32 with numpy's float32 log (np_f32.h), widened by the clip; probability rows: numpy's float32 log of the float32 clip.
+__device__ __forceinline__ double to_logp_np32(float xv, bool is_prob, float mf, float l32) {
+  const double clip_lo = -34.538776394910684;  // ln(1e-15)
+  if (is_prob) {
+    const float lo = (float)1e-15;
+    const float p = xv < lo ? lo : (xv > 1.0f ? 1.0f : xv);  // (NaN stays NaN, like np.clip)
+    return (double)np_log_f32(p);
+  }
+  const float t = xv - mf;
+  const double y = (double)(t - l32);
+  return y < clip_lo ? clip_lo : (y > 0.0 ? 0.0 : y);
+}
+
 // float64 rows: sum_v exp(x[v] - m) in the order numpy's np.sum adds a contiguous float64 row (pairwise: np_sum.h), by one
 // wave. The reference's log-softmax (decoder.py:180-197) is x - max - log(np.sum(np.exp(x - max))): with the normaliser
 // summed in this order a frame's log-probabilities are the reference's own bit for bit wherever exp / log round like
@@ -504,7 +520,16 @@ __device__ __forceinline__ double to_logp(double xv, bool is_prob, double mx, do
 // (<= 128 elements: eight strided accumulators, then the leftovers) go to groups of eight lanes, eight leaves at a time;
 // lane 0 lists them first and combines their sums last, both by walking the recursion with a small stack in LDS.
 // Returns false for rows of more than NP_LEAVES leaves (the caller then sums in lane order: same value to ~1 ulp).
-__device__ __forceinline__ bool np_order_exp_sum(const double* x, int V, double m, int lane, const PruneLds& w, double* out) {
+// T = double: the terms are exp(x - m) in fp64; T = float: numpy's float32 exp of the float32 difference, float32 additions
+// (the leaf sums travel through the fp64 LDS words unchanged: every float32 is a double).
+template <typename T>
+__device__ __forceinline__ T np_term(const T* x, int i, T m);
+template <>
+__device__ __forceinline__ double np_term<double>(const double* x, int i, double m) { return exp(x[i] - m); }
+template <>
+__device__ __forceinline__ float np_term<float>(const float* x, int i, float m) { return np_exp_f32(x[i] - m); }
+template <typename T>
+__device__ __forceinline__ bool np_order_exp_sum(const T* x, int V, T m, int lane, const PruneLds& w, T* out) {
   uint16_t* leaf_off = w.np_tab;
   uint16_t* leaf_len = w.np_tab + NP_LEAVES;
   uint16_t* stk_n = w.np_tab + 2 * NP_LEAVES;
@@ -547,21 +572,21 @@ __device__ __forceinline__ bool np_order_exp_sum(const double* x, int V, double 
     const int k = base + g;
     const bool mine = k < nl;
     const int off = mine ? leaf_off[k] : 0, n = mine ? leaf_len[k] : 0;
-    double res = 0.0;
+    T res = (T)0;
     if (n < 8) {
-      for (int i = 0; i < n; ++i) res = res + exp(x[off + i] - m);
+      for (int i = 0; i < n; ++i) res = res + np_term<T>(x, off + i, m);
     } else {
-      double r = exp(x[off + j] - m);
+      T r = np_term<T>(x, off + j, m);
       const int body = n - (n % 8);
-      for (int i = 8; i < body; i += 8) r = r + exp(x[off + i + j] - m);
+      for (int i = 8; i < body; i += 8) r = r + np_term<T>(x, off + i + j, m);
       // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): additions commute, so an xor butterfly inside the group is that very tree
       r = r + __shfl_xor(r, 1, 64);
       r = r + __shfl_xor(r, 2, 64);
       r = r + __shfl_xor(r, 4, 64);
       res = r;
-      for (int i = body; i < n; ++i) res = res + exp(x[off + i] - m);
+      for (int i = body; i < n; ++i) res = res + np_term<T>(x, off + i, m);
     }
-    if (mine && j == 0) w.np_sum[k] = res;
+    if (mine && j == 0) w.np_sum[k] = (double)res;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -571,11 +596,11 @@ __device__ __forceinline__ bool np_order_exp_sum(const double* x, int V, double 
     int sp = 1, k = 0;
     stk_n[0] = (uint16_t)V;
     stk_st[0] = 0;
-    double ret = 0.0;
+    T ret = (T)0;
     while (sp > 0) {
       const int n = stk_n[sp - 1], st = stk_st[sp - 1];
       if (n <= 128) {
-        ret = w.np_sum[k++];
+        ret = (T)w.np_sum[k++];
         --sp;
         continue;
       }
@@ -587,21 +612,21 @@ __device__ __forceinline__ bool np_order_exp_sum(const double* x, int V, double 
         stk_st[sp] = 0;
         ++sp;
       } else if (st == 1) {
-        acc[sp - 1] = ret;
+        acc[sp - 1] = (double)ret;
         stk_st[sp - 1] = 2;
         stk_n[sp] = (uint16_t)(n - n2);
         stk_st[sp] = 0;
         ++sp;
       } else {
-        ret = acc[sp - 1] + ret;
+        ret = (T)acc[sp - 1] + ret;
         --sp;
       }
     }
-    w.np_sum[0] = ret;
+    w.np_sum[0] = (double)ret;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  *out = w.np_sum[0];
+  *out = (T)w.np_sum[0];
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   return true;
@@ -610,7 +635,7 @@ template <typename T>
 __device__ __forceinline__ bool np_order_exp_sum_t(const T*, int, double, int, const PruneLds&, double*) { return false; }
 template <>
 __device__ __forceinline__ bool np_order_exp_sum_t<double>(const double* x, int V, double m, int lane, const PruneLds& w, double* out) {
-  return np_order_exp_sum(x, V, m, lane, w, out);
+  return np_order_exp_sum<double>(x, V, m, lane, w, out);
 }
 
 // Generic frame-prune: one wave per frame row, any V / dtype; the row is swept three times (max and
@@ -626,6 +651,10 @@ __device__ __forceinline__ void prune_row_generic(const PruneArgs& a, int64_t ro
   if (is_prob && a.utt_is_prob[u] != 1u) return;
   const T* x = (const T*)a.utt_logits[u] + (size_t)(row - a.utt_row0[u]) * V;
   double mx = 0.0, lse = 0.0;
+  // float32 rows: the reference's own float32 arithmetic (to_logp_np32); rows of more leaves than a wave lists fall back to fp64
+  constexpr bool F32 = std::is_same<T, float>::value;
+  bool np32 = F32 && a.f32_np && is_prob;
+  float mf = 0.f, l32 = 0.f;
   if (!is_prob) {
     double m = -INFINITY, rs = 0.0;
     for (int v = lane; v < V; v += 64) {
@@ -637,13 +666,25 @@ __device__ __forceinline__ void prune_row_generic(const PruneArgs& a, int64_t ro
     rs = wave_sum(rs);
     if (lane == 0) a.row_sum[row] = rs;
     if (!isfinite(m)) m = 0.0;  // decoder.py:186-189
-    double s = 0.0;
-    if (!np_order_exp_sum_t<T>(x, V, m, lane, w, &s)) {  // (float64 rows: numpy's own summation order)
-      for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
-      s = wave_sum(s);
+    if constexpr (F32) {
+      if (a.f32_np) {
+        float s32 = 0.f;
+        mf = (float)m;  // (exact: the maximum of float32 values)
+        if (np_order_exp_sum<float>((const float*)x, V, mf, lane, w, &s32)) {
+          l32 = np_log_f32(s32);
+          np32 = true;
+        }
+      }
+    }
+    if (!np32) {
+      double s = 0.0;
+      if (!np_order_exp_sum_t<T>(x, V, m, lane, w, &s)) {  // (float64 rows: numpy's own summation order)
+        for (int v = lane; v < V; v += 64) s += exp(ld(x, v) - m);
+        s = wave_sum(s);
+      }
+      lse = log(s);
     }
     mx = m;
-    lse = log(s);
   }
   uint32_t n = 0;
   double best = -INFINITY;
@@ -654,7 +695,8 @@ __device__ __forceinline__ void prune_row_generic(const PruneArgs& a, int64_t ro
     double y = -INFINITY;
     bool in = v < V;
     if (in) {
-      y = to_logp(ld(x, v), is_prob, mx, lse);
+      if constexpr (F32) y = np32 ? to_logp_np32(((const float*)x)[v], is_prob, mf, l32) : to_logp(ld(x, v), is_prob, mx, lse);
+      else y = to_logp(ld(x, v), is_prob, mx, lse);
       argmax_take(y, v, best, best_id);
     }
     bool keep = in && y >= a.token_min_logp;
@@ -819,9 +861,15 @@ __device__ __forceinline__ void prune_row_f32x4(const PruneArgs& a, int64_t row,
       // the degree its purpose needs (1e-11 per term, errors of either sign), fp64 accumulation.
       const float mfw = (float)m;  // exact: m is the maximum of float32 values
       double sl = 0.0;
+      // round 6: the reference's float32 arithmetic itself (numpy's float32 exp, its pairwise float32 sum, its float32 log:
+      // np_f32.h, np_order_exp_sum<float>; the row is read a second time, from L1 / L2) -- a frame's log-probabilities are the
+      // reference's bits. The polynomial variants below stay for CTCDEC_PRUNE_EXP=pk / f64.
+      float l32 = 0.f, s32 = 0.f;
+      const bool np32 = a.f32_np && np_order_exp_sum<float>((const float*)x4, V, mfw, lane, w, &s32);
+      if (np32) l32 = np_log_f32(s32);
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
-        if (k * 64 + lane < n4) {
+        if (!np32 && k * 64 + lane < n4) {
           if (PK) {
             // (x - m in float32: one rounding, as in the reference's float32 `x - x_max`)
             const f32x2 e01 = exp_nonpos_f32x2((f32x2){r[k].x - mfw, r[k].y - mfw});
@@ -833,8 +881,12 @@ __device__ __forceinline__ void prune_row_f32x4(const PruneArgs& a, int64_t row,
           }
         }
       }
-      const double s = wave_sum(sl);
-      lse = log_ge1(s);
+      if (!np32) {
+        const double s = wave_sum(sl);
+        lse = log_ge1(s);
+      } else {
+        lse = (double)l32;
+      }
       // argmax of the log-probs = first maximum of the logits (x -> clip(x - m - lse) is monotone, and two
       // different fp32 logits never round to the same fp64 value after the two subtractions)
       int first = 0x7FFFFFFF;
@@ -849,12 +901,14 @@ __device__ __forceinline__ void prune_row_f32x4(const PruneArgs& a, int64_t row,
         }
       }
       first = wave_min_i32(first);
-      const double best = to_logp((double)mfw, false, m, lse);
+      const double best = np32 ? to_logp_np32(mfw, false, mfw, l32) : to_logp((double)mfw, false, m, lse);
       // survivors: an fp32 screen that cannot miss (threshold rounded down, with a margin far above the fp64
       // rounding of the exact test), then the exact fp64 test only in the 256-label chunks that have a candidate
       const double xthr = m + lse + a.token_min_logp;
       // (a threshold at or below the clip keeps every label: decoder.py:444 tests the clipped values)
-      const float pre = a.token_min_logp <= -34.538776394910684 ? -INFINITY : __double2float_rd(xthr - 1e-6 * (1.0 + fabs(xthr)));
+      // (float32 arithmetic: two roundings of up to half an ulp of |x - m| and |y| each -- a wider margin)
+      const float pre = a.token_min_logp <= -34.538776394910684 ? -INFINITY
+                                                                  : __double2float_rd(xthr - (np32 ? 3e-5 * (4.0 + fabs(xthr)) : 1e-6 * (1.0 + fabs(xthr))));
       uint32_t n = 0;
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
@@ -863,7 +917,12 @@ __device__ __forceinline__ void prune_row_f32x4(const PruneArgs& a, int64_t row,
         if (__ballot(cand)) {
           const int v0 = (k * 64 + lane) * 4;
           double y0 = -INFINITY, y1 = -INFINITY, y2 = -INFINITY, y3 = -INFINITY;
-          if (cand) {
+          if (cand && np32) {
+            y0 = to_logp_np32(r[k].x, false, mfw, l32);
+            y1 = to_logp_np32(r[k].y, false, mfw, l32);
+            y2 = to_logp_np32(r[k].z, false, mfw, l32);
+            y3 = to_logp_np32(r[k].w, false, mfw, l32);
+          } else if (cand) {
             y0 = to_logp((double)r[k].x, false, m, lse);
             y1 = to_logp((double)r[k].y, false, m, lse);
             y2 = to_logp((double)r[k].z, false, m, lse);
@@ -902,11 +961,18 @@ __device__ __forceinline__ void prune_row_f32x4(const PruneArgs& a, int64_t row,
     const bool in = k * 64 + lane < n4;
     const int v0 = (k * 64 + lane) * 4;
     double y0 = -INFINITY, y1 = -INFINITY, y2 = -INFINITY, y3 = -INFINITY;
-    if (in) {
+    if (in && is_prob && a.f32_np) {  // (probability rows: numpy's float32 log of the float32 clip)
+      y0 = to_logp_np32(r[k].x, true, 0.f, 0.f);
+      y1 = to_logp_np32(r[k].y, true, 0.f, 0.f);
+      y2 = to_logp_np32(r[k].z, true, 0.f, 0.f);
+      y3 = to_logp_np32(r[k].w, true, 0.f, 0.f);
+    } else if (in) {
       y0 = to_logp((double)r[k].x, is_prob, mx, lse);
       y1 = to_logp((double)r[k].y, is_prob, mx, lse);
       y2 = to_logp((double)r[k].z, is_prob, mx, lse);
       y3 = to_logp((double)r[k].w, is_prob, mx, lse);
+    }
+    if (in) {
       argmax_take(y0, v0, best, best_id);
       argmax_take(y1, v0 + 1, best, best_id);
       argmax_take(y2, v0 + 2, best, best_id);
@@ -1072,11 +1138,47 @@ __device__ __forceinline__ float pf_widen(uint32_t h16) {
   return DT == 2 ? __half2float(__ushort_as_half((unsigned short)h16)) : __uint_as_float(h16 << 16);
 }
 
+// numpy's float32 exp (np_f32.h: np_exp_f32) for the arguments of a clean row's log-softmax, t = x - max <= 0 or -inf, without
+// its special-case branches: the same operations in the same order, the underflow rule as a select.
+__device__ __forceinline__ float np_exp_nonpos_dev(float t) {
+#pragma clang fp contract(off)
+  const float tc = fmaxf(t, -104.0f);  // (keeps the polynomial's inputs finite; t <= xmin is answered by the select below)
+  float q = tc * 1.442695040888963407359924681001892137f;
+  q = (q + 12582912.0f) - 12582912.0f;
+  float r = fmaf(q, -6.93145752e-1f, tc);
+  r = fmaf(q, -1.42860677e-6f, r);
+  float num = fmaf(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f);
+  num = fmaf(num, r, 5.114512081637298353406e-02f);
+  num = fmaf(num, r, 2.473615434895520810817e-01f);
+  num = fmaf(num, r, 7.257664613233124478488e-01f);
+  num = fmaf(num, r, 9.999999999980870924916e-01f);
+  float den = fmaf(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f);
+  den = fmaf(den, r, 1.000000000000000000000e+00f);
+  const float v = ldexpf(num / den, (int)q);
+  return t <= -103.97208404541015625f ? 0.0f : v;
+}
+// index of element i of a row in the exchange buffer: eight floats of padding per 128 (the accumulator lanes of different
+// leaves then read different banks)
+__device__ __forceinline__ int np_pad(int i) { return i + ((i >> 7) << 3); }
+constexpr size_t PF_TABS_BYTES = (size_t)PF_ROWS * SMALL_SET_SLOTS * 2;
+// LDS a block needs beyond PF_LDS in numpy-order mode: the leaf sums of its 64 rows, and the exchange buffer of one row when it
+// does not fit the set tables' bytes (which are idle during phase A)
+__host__ __device__ inline size_t pf_np_rowbuf_bytes(int nc) { return ((size_t)(nc * 256 + nc * 16 + 16) * 4 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t pf_np_extra_lds(int nc, int n_leaf) {
+  const size_t ls = (size_t)n_leaf * PF_ROWS * 4;
+  return ls + (pf_np_rowbuf_bytes(nc) <= PF_TABS_BYTES ? 0 : pf_np_rowbuf_bytes(nc));
+}
+
 // AL: rows start on 16-byte boundaries and hold a multiple of four (16-bit: eight) labels: 16-byte loads. !AL (float32 only):
 // any label count and any 4-byte-aligned rows -- each lane fetches its four consecutive labels one by one (the common
 // "1024 BPE pieces + blank = 1025 labels" shape); labels past the row's end read as -inf.
-template <int NC, int DT, bool AL = true>
-__global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
+// NP (float32 rows): the sum of exponentials in the reference's own float32 arithmetic -- numpy's float32 exp per label, its
+// pairwise summation order (np_sum.h) and, in phase B, its float32 log: a row's exponentials cross LDS once so that lane
+// (leaf, j) adds the elements numpy's accumulator j of that leaf adds, in numpy's order; the leaf sums wait in LDS for phase B,
+// where every lane combines its row's along the recursion's tree (a.np_prog). A frame's log-probabilities are then the
+// reference's bits, and the decode of float32 logits equals the reference's to the last bit of every score.
+template <int NC, int DT, bool AL = true, bool NP = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 : 1, NC <= 4 ? 3 : 8))) void frame_prune_fast(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int64_t row_lo = a.row_base + (int64_t)blockIdx.x * PF_ROWS;
@@ -1086,6 +1188,9 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   uint16_t* ar_id = (uint16_t*)smem;                       // [PF_CAND][64 rows]
   float* ar_x = (float*)(smem + PF_LDS_IDS);               // [PF_CAND][64 rows]
   uint16_t* tabs = (uint16_t*)(smem + PF_LDS_IDS + PF_LDS_X);  // [SMALL_SET_SLOTS][64 rows]
+  static_assert(!NP || DT == 0, "numpy-order sums: float32 rows");
+  float* np_ls = (float*)(smem + PF_LDS);        // NP: [n_leaf][64 rows] leaf sums
+  float* np_rb = pf_np_rowbuf_bytes(NC) <= PF_TABS_BYTES ? (float*)tabs : (float*)(smem + PF_LDS + (size_t)a.np_n_leaf * PF_ROWS * 4);
   constexpr bool WIDE = DT == 0;                 // float32 rows
   constexpr int NL = WIDE ? NC : NC / 2;         // 16-byte loads per lane and row
   constexpr int PER = WIDE ? 4 : 8;              // labels per load
@@ -1207,6 +1312,63 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     int first = 0;
     double s = 1.0;
     if (isfinite(m) && rs == rs) {
+      if constexpr (NP) {
+        // numpy's float32 exp of every label, in place; through the exchange buffer; numpy's accumulators
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          float4 e;
+          e.x = np_exp_nonpos_dev(r[k].x - m);
+          e.y = np_exp_nonpos_dev(r[k].y - m);
+          e.z = np_exp_nonpos_dev(r[k].z - m);
+          e.w = np_exp_nonpos_dev(r[k].w - m);
+          *(float4*)(np_rb + np_pad((k * 64 + lane) * 4)) = e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int g = lane >> 3, j = lane & 7;
+        const int nl = a.np_n_leaf;
+        float part = 0.f;
+        for (int base = 0; base < nl; base += 8) {
+          const int leaf = base + g;
+          const bool mine = leaf < nl;
+          int off = 0, len = 0;
+          if (mine) {
+            off = a.np_leaf[2 * leaf];
+            len = a.np_leaf[2 * leaf + 1];
+          }
+          float res = 0.f;
+          if (len == 128 && (off & 127) == 0) {  // (the usual leaf: sixteen terms per accumulator, constant offsets from one address)
+            const float* q = np_rb + np_pad(off) + j;
+            float t0 = q[0], t1 = q[8], t2 = q[16], t3 = q[24], t4 = q[32], t5 = q[40], t6 = q[48], t7 = q[56];
+            float t8 = q[64], t9 = q[72], t10 = q[80], t11 = q[88], t12 = q[96], t13 = q[104], t14 = q[112], t15 = q[120];
+            float rr = t0 + t1;
+            rr = rr + t2; rr = rr + t3; rr = rr + t4; rr = rr + t5; rr = rr + t6; rr = rr + t7; rr = rr + t8;
+            rr = rr + t9; rr = rr + t10; rr = rr + t11; rr = rr + t12; rr = rr + t13; rr = rr + t14; rr = rr + t15;
+            res = rr;
+          } else if (len >= 8) {
+            const int body = len - (len & 7);
+            float rr = np_rb[np_pad(off + j)];
+            for (int i = 8; i < body; i += 8) rr = rr + np_rb[np_pad(off + i + j)];
+            res = rr;
+          }
+          // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) inside the group of eight lanes: additions commute, an xor butterfly is that tree
+          res = res + dpp_f32<0xB1, 0xf>(0.f, res);   // quad_perm [1, 0, 3, 2]
+          res = res + dpp_f32<0x4E, 0xf>(0.f, res);   // quad_perm [2, 3, 0, 1]
+          res = res + dpp_f32<0x141, 0xf>(0.f, res);  // row_half_mirror (both quads hold their sums in every lane by now)
+          if ((len & 7) != 0 || len < 8) {  // leftovers (and leaves shorter than eight: a plain loop from 0), one by one
+            const int body = len >= 8 ? len - (len & 7) : 0;
+            if (len < 8) res = 0.f;
+            for (int i = body; i < len; ++i) res = res + np_rb[np_pad(off + i)];
+          }
+          if (mine && j == 0) {
+            np_ls[leaf * PF_ROWS + i] = res;
+            part += res;
+          }
+        }
+        s = (double)wave_sum_f32(part);  // (any order: only the screen below looks at it; phase B combines the leaves exactly)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      } else {
       // sum of exponentials: float32 per lane (16 terms), fp64 across the lanes
       f32x2 acc = (f32x2)(0.f);
       const f32x2 mm = (f32x2)(m);
@@ -1223,6 +1385,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
 #ifdef CTC_PF_SKIP_EXP
       s = 1.02 + s * 1e-30;
 #endif
+      }
       // candidates: a float32 screen that cannot miss a survivor -- the threshold on the logits from a float32 logarithm
       // (|error| < 1e-6 (1 + lse)), lowered by a margin two orders above that and above the rounding of the sum
       const float xthr = (m + __logf((float)s)) + tminf;
@@ -1336,8 +1499,20 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
     if (!slow) {
       const double s = my_s;
       const double md = (double)my_m;
-      const double lse = log_ge1(s);
-      const double best = to_logp(md, false, md, lse);
+      double lse = 0.0;
+      float l32 = 0.f;
+      if constexpr (NP) {
+        // this row's leaf sums, combined along numpy's recursion (every lane walks the same (dst, src) list on its own column)
+        for (int q = 0; q + 1 < a.np_n_leaf; ++q) {
+          const int dst = a.np_prog[2 * q], src = a.np_prog[2 * q + 1];
+          np_ls[dst * PF_ROWS + lane] = np_ls[dst * PF_ROWS + lane] + np_ls[src * PF_ROWS + lane];
+        }
+        l32 = np_log_f32(np_ls[lane]);
+      } else {
+        lse = log_ge1(s);
+      }
+      auto logp_of = [&](float x) { return NP ? to_logp_np32(x, false, my_m, l32) : to_logp((double)x, false, md, lse); };
+      const double best = logp_of(my_m);
       uint16_t* ids = ar_id + lane;
       float* xs = ar_x + lane;
       // the exact test (fp64, as in the per-row kernel) + insertion sort by id, in place
@@ -1347,7 +1522,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
         const uint16_t id = ids[j * PF_ROWS];
         const float x = xs[j * PF_ROWS];
         if (x == my_m && id < first) first = id;
-        if (to_logp((double)x, false, md, lse) >= a.token_min_logp) {
+        if (logp_of(x) >= a.token_min_logp) {
           uint32_t p = n;
           while (p > 0 && ids[(p - 1) * PF_ROWS] > id) {
             ids[p * PF_ROWS] = ids[(p - 1) * PF_ROWS];
@@ -1372,7 +1547,7 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
           if (v != SMALL_SET_EMPTY) {
             const uint32_t pay = v >> SMALL_SET_ID_BITS;
             out_id[pos] = (uint16_t)(v & SMALL_SET_ID_MASK);
-            out_lp[pos] = pay == SMALL_SET_ARGMAX ? best : to_logp((double)xs[pay * PF_ROWS], false, md, lse);
+            out_lp[pos] = pay == SMALL_SET_ARGMAX ? best : logp_of(xs[pay * PF_ROWS]);
             ++pos;
           }
         }
@@ -1391,7 +1566,67 @@ __global__ __launch_bounds__(64) void frame_prune_fast(PruneArgs a) {
   }
 }
 
-int launch_prune(const PruneArgs& a, std::string* err) {
+// numpy's pairwise recursion over a row of V elements (np_sum.h): its leaves (offset, length) left to right and the additions
+// that combine their sums, as (dst, src) leaf indices -- the result of a node lives where its leftmost leaf's did
+struct NpPlan {
+  int V = -1, n_leaf = 0;
+  uint16_t* d_leaf = nullptr;
+  uint8_t* d_prog = nullptr;
+};
+static int np_plan_node(int off, int n, std::vector<uint16_t>& leaf, std::vector<uint8_t>& prog) {
+  if (n <= 128) {
+    leaf.push_back((uint16_t)off);
+    leaf.push_back((uint16_t)n);
+    return (int)leaf.size() / 2 - 1;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  const int l = np_plan_node(off, n2, leaf, prog), r = np_plan_node(off + n2, n - n2, leaf, prog);
+  prog.push_back((uint8_t)l);
+  prog.push_back((uint8_t)r);
+  return l;
+}
+static int np_plan_for(int V, NpPlan** out, std::string* err) {
+  static NpPlan plans[4];
+  static int next = 0;
+  for (NpPlan& p : plans)
+    if (p.V == V) {
+      *out = &p;
+      return 0;
+    }
+  NpPlan& p = plans[next];
+  next = (next + 1) % 4;
+  std::vector<uint16_t> leaf;
+  std::vector<uint8_t> prog;
+  np_plan_node(0, V, leaf, prog);
+  prog.push_back(0);  // (never empty)
+  prog.push_back(0);
+  HIP_TRY(hipStreamSynchronize(g_stream));  // (a launch in flight may still read the plan this one replaces)
+  if (p.d_leaf) (void)hipFree(p.d_leaf);
+  if (p.d_prog) (void)hipFree(p.d_prog);
+  p.d_leaf = nullptr;
+  p.d_prog = nullptr;
+  p.V = -1;
+  HIP_TRY(hipMalloc((void**)&p.d_leaf, leaf.size() * 2));
+  HIP_TRY(hipMalloc((void**)&p.d_prog, prog.size()));
+  HIP_TRY(hipMemcpy(p.d_leaf, leaf.data(), leaf.size() * 2, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p.d_prog, prog.data(), prog.size(), hipMemcpyHostToDevice));
+  p.n_leaf = (int)leaf.size() / 2;
+  p.V = V;
+  *out = &p;
+  return 0;
+}
+
+int launch_prune(const PruneArgs& a_in, std::string* err) {
+  PruneArgs a = a_in;
+  {
+    // float32 rows: the reference's own float32 arithmetic unless told otherwise (pk: round 5's packed polynomial; f64: round 2's)
+    const char* ex0 = getenv("CTCDEC_PRUNE_EXP");
+    a.f32_np = (a.dtype == 0 && !(ex0 && (ex0[0] == 'p' || ex0[0] == 'f'))) ? 1 : 0;
+    a.np_prog = nullptr;
+    a.np_leaf = nullptr;
+    a.np_n_leaf = 0;
+  }
   if (a.pass == 0) {
     g_timing_valid = false;
     g_timing_override[0] = g_timing_override[1] = -1.0;
@@ -1432,10 +1667,25 @@ int launch_prune(const PruneArgs& a, std::string* err) {
     const unsigned rest = (unsigned)std::min<int64_t>((a.n_rows + PRUNE_WAVES - 1) / PRUNE_WAVES, 2048);
     if (rows64) {
       const int nc = ((a.n_labels + 3) / 4 + 63) / 64;  // groups of four labels per lane: 1 .. 16
+      size_t flds = PF_LDS;
+      if (a.f32_np) {  // numpy's summation plan for rows of this length
+        NpPlan* plan = nullptr;
+        if (np_plan_for(a.n_labels, &plan, err)) return -1;
+        a.np_leaf = plan->d_leaf;
+        a.np_prog = plan->d_prog;
+        a.np_n_leaf = plan->n_leaf;
+        flds += pf_np_extra_lds(nc <= 8 ? nc : (nc <= 12 ? 12 : 16), plan->n_leaf);
+      }
       // rows the fast kernel hands over: the per-row float4 kernel where it applies (<= 1024 aligned labels), else the generic one
+#define CTC_LAUNCH_FAST_K(KERN)                                                                                           \
+  do {                                                                                                                    \
+    HIP_TRY(hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));               \
+    hipLaunchKernelGGL(KERN, fgrid, fblock, flds, g_stream, a);                                                           \
+  } while (0)
 #define CTC_LAUNCH_FAST(NCV, ALV)                                                                                         \
   do {                                                                                                                    \
-    hipLaunchKernelGGL((frame_prune_fast<NCV, 0, ALV>), fgrid, fblock, PF_LDS, g_stream, a);                              \
+    if (a.f32_np) CTC_LAUNCH_FAST_K((frame_prune_fast<NCV, 0, ALV, true>));                                               \
+    else CTC_LAUNCH_FAST_K((frame_prune_fast<NCV, 0, ALV, false>));                                                       \
     if (ALV && NCV <= 4) {                                                                                                \
       HIP_TRY(hipFuncSetAttribute((const void*)frame_prune_f32x4_listed<(NCV <= 4 ? NCV : 4)>,                            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
@@ -1465,6 +1715,7 @@ int launch_prune(const PruneArgs& a, std::string* err) {
       }
 #undef CTC_LAUNCH_FAST_NC
 #undef CTC_LAUNCH_FAST
+#undef CTC_LAUNCH_FAST_K
     } else if (rows64h) {
       const int nl = (a.n_labels / 8 + 63) / 64;  // 16-byte loads per lane: 1 (up to 512 labels) or 2
 #define CTC_LAUNCH_FAST16(NCV, DTV, T)                                                                                    \
@@ -1634,10 +1885,13 @@ int launch_beam(const BeamArgs& a, std::string* err) {
   if (wave) {
     BeamArgs wa = a;
     // issue priority among the waves that share a SIMD (WaveGpuCtx::frame_done). CTCDEC_WAVE_PRIO=none | rot<k> | dyn
+    // Default: by remaining work (measured on the 4096-utterance bench launch, round 6: 17.95 -> 17.1 ms; rot5 the same; the
+    // waves of a launch end 12.3 .. 16.1 ms (5th .. 95th percentile) apart without it, 13.6 .. 15.2 ms with it; batches of one
+    // wave per SIMD or fewer are unaffected).
     const char* pr = getenv("CTCDEC_WAVE_PRIO");
-    wa.prio_mode = 0;
+    wa.prio_mode = 32;
+    if (pr && pr[0] == 'n') wa.prio_mode = 0;
     if (pr && pr[0] == 'r') wa.prio_mode = 1 + (pr[1] && pr[2] && pr[3] ? atoi(pr + 3) & 15 : 5);
-    if (pr && pr[0] == 'd') wa.prio_mode = 32;
     wa.progress = nullptr;
     wa.total_frames = 0;
     wa.inv_n_utts = 0.f;

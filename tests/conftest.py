@@ -27,16 +27,16 @@ def both_beam_kernels(request, monkeypatch):
     return request.param
 
 
-@pytest.fixture(params=["pk", "f64"])
+@pytest.fixture(params=["np", "pk", "f64"])
 def both_prune_exps(request, monkeypatch):
-    """Float32 rows (up to 4095 labels) go through the register-resident frame-prune kernel, whose exponentials are packed
-    float32 polynomials by default (the precision the reference itself works at for float32 input) and the round-2 fp64
-    routine under CTCDEC_PRUNE_EXP=f64. The differential tests run under both: `f64` is exact against the oracle
-    (1e-9), the default within the float32 bound (tests/test_gpu_parity._tol)."""
-    if request.param == "f64":
-        monkeypatch.setenv("CTCDEC_PRUNE_EXP", "f64")
-    else:
+    """How the frame-prune kernels treat float32 rows. `np` (the default since round 6): the reference's own float32 arithmetic --
+    numpy's float32 exp / log and its pairwise summation order restated (csrc/np_f32.h, np_sum.h) -- exact against the oracle
+    fed the float32 array itself (1e-9, strict order). `pk`: round 5's packed float32 polynomial, the float32 bound
+    (tests/test_gpu_parity._tol). `f64`: the round-2 fp64 routine, exact against the oracle on the float64 upcast."""
+    if request.param == "np":
         monkeypatch.delenv("CTCDEC_PRUNE_EXP", raising=False)
+    else:
+        monkeypatch.setenv("CTCDEC_PRUNE_EXP", request.param)
     return request.param
 
 

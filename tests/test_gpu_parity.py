@@ -17,14 +17,30 @@ CASES, INPUTS = load_cases()
 TOL = 1e-9  # absolute (tests/golden_util.check_beams); the device's fp64 scores differ from the oracle's by < 1e-12
 
 
+def _mode():
+    """n: float32 rows in the reference's own float32 arithmetic (the default, round 6); p: round 5's packed polynomial;
+    f: everything in fp64 from the exact upcast (tests/conftest.py::both_prune_exps)"""
+    return os.environ.get("CTCDEC_PRUNE_EXP", "np")[0]
+
+
+def _f64(x):
+    """What the oracle is fed for a decode of `x`: float32 logits IN THEIR OWN DTYPE when the device computes them the way the
+    reference does (the oracle, like the reference, keeps the input dtype through its log-softmax), else the exact upcast."""
+    a = np.asarray(x)
+    if a.dtype == np.float32 and _mode() == "n":
+        return a
+    return a.astype(np.float64)
+
+
 def _tol(x):
-    """Bounds for a decode of logits `x` against the oracle run on their exact float64 upcast: float32 rows (up to 4095
-    labels; 16-bit rows: a multiple of eight up to 1024) take the packed float32 exponential unless CTCDEC_PRUNE_EXP=f64 --
-    1e-4 absolute, order exact outside runs closer than 4e-5 (the north star's float32 bound); everything else is fp64: 1e-9."""
+    """Bounds for a decode of logits `x` against the oracle (fed _f64(x)). float32 rows: 1e-9 in the default mode -- the device
+    restates the reference's float32 log-softmax bit for bit (np_f32.h); under CTCDEC_PRUNE_EXP=pk (up to 4095 labels) the
+    packed float32 polynomial: 1e-4 absolute, order exact outside runs closer than 4e-5. 16-bit rows (a multiple of eight labels
+    up to 1024) take that polynomial unless CTCDEC_PRUNE_EXP=f64. Everything else is fp64: 1e-9."""
     dt = str(getattr(x, "dtype", "")).replace("torch.", "")
     V = int(x.shape[-1])
-    pk = os.environ.get("CTCDEC_PRUNE_EXP", "pk")[0] != "f"
-    f32_path = dt == "float32" and V <= 4095 and pk
+    pk = _mode() != "f"
+    f32_path = dt == "float32" and V <= 4095 and _mode() == "p"
     # (float16 / bfloat16 rows of a multiple of eight labels: the 64-rows-per-wave kernel widens them and runs the same
     # float32 exponentials; the reference itself computes such rows in float16)
     h_path = dt in ("float16", "bfloat16") and V % 8 == 0 and V <= 1024 and pk
@@ -80,7 +96,7 @@ def test_hip_vs_oracle_flat_char_beam100(lm):
     # device-resident fp32 input, decode_beams_batch
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], prune_history=True)
     for u, x in enumerate(xs):
-        exp = _oracle_expected(orc, x.astype(np.float64), {"prune_history": True})
+        exp = _oracle_expected(orc, _f64(x), {"prune_history": True})
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="flat%d" % u, **_tol(x))
 
 
@@ -99,7 +115,7 @@ def test_hip_vs_oracle_bpe1024_lm_hotwords(lm, bpe):
     xs.append(synth.d_flat(4, 7, 40, 1024))
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], hotwords=hot, prune_history=True)
     for u, x in enumerate(xs):
-        exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
+        exp = _oracle_expected(orc, _f64(x), {"hotwords": hot, "prune_history": True})
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="bpe%d" % u, **_tol(x))
     texts = dec.decode_batch(None, xs, hotwords=hot)
     assert texts == [g[0].text for g in got]
@@ -124,7 +140,7 @@ def test_hip_vs_oracle_bpe1025_pieces_plus_blank(lm):
     xs.append(synth.d_flat(4, 9, 40, 1025))
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], hotwords=hot, prune_history=True)
     for u, x in enumerate(xs):
-        exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
+        exp = _oracle_expected(orc, _f64(x), {"hotwords": hot, "prune_history": True})
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="bpe1025_%d" % u, **_tol(x))
     assert dec.decode_batch(None, xs, hotwords=hot) == [g[0].text for g in got]
 
@@ -151,7 +167,7 @@ def test_hip_vs_oracle_vocabulary_shapes_of_the_rows64_prune_kernel(V, scale):
     rng = np.random.default_rng(V)
     x = (rng.standard_normal((70, V)) * scale).astype(np.float32)
     x[:, 0] += 1.5  # (some blank mass: beams that stay)
-    exp = _oracle_expected(orc, x.astype(np.float64), {"beam_width": 24})
+    exp = _oracle_expected(orc, _f64(x), {"beam_width": 24})
     got = dec.decode_beams(torch.from_numpy(x).cuda(), beam_width=24)
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="shape%d" % V, **_tol(x))
 
@@ -167,11 +183,11 @@ def test_hip_ragged_batch_and_edge_cases(lm):
     xs = [synth.d_words(2, u, T, synth.LIBRI_LABELS, False, lm.words, lm.sentences, 28, boost=6.0)
           for u, T in enumerate([1, 0, 37, 5, 64, 2])]
     texts = dec.decode_batch(None, xs)
-    assert texts == [orc.decode(x.astype(np.float64)) for x in xs]
+    assert texts == [orc.decode(_f64(x)) for x in xs]
     # beam_width=1 and max beam bucket
     for bw in (1, 200):
         got = dec.decode_beams(xs[4], beam_width=bw)
-        exp = _oracle_expected(orc, xs[4].astype(np.float64), {"beam_width": bw})
+        exp = _oracle_expected(orc, _f64(xs[4]), {"beam_width": bw})
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="bw%d" % bw, **_tol(xs[4]))
     with pytest.raises(NotImplementedError):
         dec.decode_beams(xs[4], beam_width=300)
@@ -224,7 +240,7 @@ def test_hip_oracle_one_full_length_utterance(lm, bpe):
     hot = lm.hotwords(6, 2)
     x = synth.d_words(4, 11, 1000, bpe, True, lm.words, lm.sentences, len(bpe), boost=6.0)
     got = dec.decode_beams(x, hotwords=hot, prune_history=True)
-    exp = _oracle_expected(orc, x.astype(np.float64), {"hotwords": hot, "prune_history": True})
+    exp = _oracle_expected(orc, _f64(x), {"hotwords": hot, "prune_history": True})
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="full", **_tol(x))
 
 
@@ -258,7 +274,7 @@ def test_hip_config2_full_size_char_nolm_stress():
     alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
     orc = build_oracle(alpha.labels, alpha.is_bpe)
     x = synth.d_flat(2, 999, 120, 29)
-    exp = _oracle_expected(orc, x.astype(np.float64), {})
+    exp = _oracle_expected(orc, _f64(x), {})
     got = dec.decode_beams(x)
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="cfg2", **_tol(x))
 
@@ -278,9 +294,9 @@ def test_hip_config3_hf_vocab_lm_full_length():
     xs = [synth.d_words(3, u, T, synth.HF_W2V2_LABELS, False, lm_u.words, lm_u.sentences, 0, boost=6.0,
                         space_label="|") for u, T in enumerate([1000, 130, 77])]
     got = dec.decode_batch(None, xs)
-    assert got == [orc.decode(x.astype(np.float64)) for x in xs]
+    assert got == [orc.decode(_f64(x)) for x in xs]
     beams = dec.decode_beams(xs[1])
-    exp = _oracle_expected(orc, xs[1].astype(np.float64), {})
+    exp = _oracle_expected(orc, _f64(xs[1]), {})
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in beams], exp, what="cfg3", **_tol(xs[1]))
 
 
@@ -341,7 +357,7 @@ def test_hip_config5_streaming_64_streams(lm, bpe):
         st = orc.get_starting_state()
         exp = None
         for k in range(n_chunks):
-            exp = orc.partial_decode_beams(xs[u][k * chunk:(k + 1) * chunk].astype(np.float64), st, k * chunk,
+            exp = orc.partial_decode_beams(_f64(xs[u][k * chunk:(k + 1) * chunk]), st, k * chunk,
                                            beam_width=200, is_end=(k == n_chunks - 1))
         assert [b.text for b in beams[u]] == [e.text for e in exp]
         assert [[tuple(f) for f in b.text_frames] for b in beams[u]] == [[tuple(f) for f in e.tframes] for e in exp]
@@ -370,7 +386,9 @@ def test_hip_half_precision_logits_in_place(lm, bpe):
         # through the per-row kernels under CTCDEC_PRUNE_EXP=f64, where the generic one (half types) and the
         # register-resident one (float32) sum the row in different orders: ~1e-11)
         assert [(o.text, o.text_frames) for o in a] == [(o.text, o.text_frames) for o in b]
-        bound = _tol(xh.to(torch.float32))["tol"]
+        # (the float32 copy is computed in the reference's float32 arithmetic by default, the 16-bit rows never are: the
+        #  float32 bound between the two unless everything is fp64)
+        bound = _tol(xh)["tol"]
         for o, q in zip(a, b):
             assert abs(o.logit_score - q.logit_score) <= bound
             assert abs(o.lm_score - q.lm_score) <= bound
@@ -378,7 +396,7 @@ def test_hip_half_precision_logits_in_place(lm, bpe):
         with np.errstate(all="ignore"):
             exp = orc.decode_beams(wide.astype(np.float64), prune_history=True)
         expd = [{"text": e[0], "frames": [[w, int(f0), int(f1)] for w, (f0, f1) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
-        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a], expd, what="half %s" % dt, **_tol(wide))
+        check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in a], expd, what="half %s" % dt, **_tol(xh))
 
 
 def test_hip_probability_rows_overflowing_the_survivor_bound():
@@ -429,7 +447,7 @@ def test_hip_multi_lm_vs_oracle_batch(lm, bpe):
     hot = lm.hotwords(4, 1)
     got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], prune_history=True, hotwords=hot)
     for u, x in enumerate(xs):
-        exp = _oracle_expected(orc, x.astype(np.float64), {"prune_history": True, "hotwords": hot})
+        exp = _oracle_expected(orc, _f64(x), {"prune_history": True, "hotwords": hot})
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="multi%d" % u, **_tol(x))
     texts = dec.decode_batch(None, torch.from_numpy(np.stack(xs)).cuda(), hotwords=hot)
     assert texts == [g[0].text for g in got]
@@ -458,7 +476,7 @@ def test_hip_non_finite_logits_follow_the_reference():
     masked = x.copy()
     masked[:, 10:20] = -np.inf
     with np.errstate(all="ignore"):
-        exp = _oracle_expected(orc, masked.astype(np.float64), {"beam_width": 20})
+        exp = _oracle_expected(orc, _f64(masked), {"beam_width": 20})
     got = dec.decode_beams(torch.from_numpy(masked).cuda(), beam_width=20)
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="masked", **_tol(masked))
     big = rng.standard_normal((30, 1024)).astype(np.float32)  # the register-resident prune kernel
@@ -478,7 +496,7 @@ def test_hip_non_finite_logits_follow_the_reference():
                 d.decode_beams(bad, beam_width=5)
             with pytest.raises(ValueError):
                 d.decode_batch(None, [base, bad])
-    assert dec.decode(x) == orc.decode(x.astype(np.float64))
+    assert dec.decode(x) == orc.decode(_f64(x))
     assert len(dec_big.decode(big)) > 0
 
 
@@ -594,7 +612,7 @@ def test_hip_workgroup_kernel_with_four_and_eight_waves(lm, bpe, threads, monkey
         got = dec.decode_beams_batch(None, xs, beam_width=bw, **kw)
         for x, g in zip(xs, got):
             with np.errstate(all="ignore"):
-                exp = orc.decode_beams(x.astype(np.float64), beam_width=bw, **kw)
+                exp = orc.decode_beams(_f64(x), beam_width=bw, **kw)
             expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
             check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in g], expd, what="threads " + threads, **_tol(x))
 
@@ -622,7 +640,7 @@ def test_hip_ragged_batch_is_dispatched_longest_first(lm, monkeypatch):
     alpha = Alphabet.build_alphabet(synth.LIBRI_LABELS)
     orc = build_oracle(alpha.labels, alpha.is_bpe, lm.path, None)
     for u in (0, 3, 10, 11, 350, 699):
-        assert got[u] == orc.decode(xs[u].astype(np.float64), beam_width=16), u
+        assert got[u] == orc.decode(_f64(xs[u]), beam_width=16), u
 
 
 def test_hip_device_binding_and_kernel_choice(lm, monkeypatch):
@@ -689,7 +707,7 @@ def test_hip_peaky_posteriors_single_label_runs(lm, bpe, monkeypatch):
         kw = {"hotwords": hot, "prune_history": True}
         got = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], **kw)
         for u, x in enumerate(xs):
-            exp = _oracle_expected(orc, x.astype(np.float64), kw)
+            exp = _oracle_expected(orc, _f64(x), kw)
             check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got[u]], exp, what="peaky%d" % u, **_tol(x))
         monkeypatch.setenv("CTCDEC_NO_LABEL_RUNS", "1")
         plain = dec.decode_beams_batch(None, [torch.from_numpy(x).cuda() for x in xs], **kw)
