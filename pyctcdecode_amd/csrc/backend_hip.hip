@@ -1157,6 +1157,53 @@ __device__ __forceinline__ float np_exp_nonpos_dev(float t) {
   const float v = ldexpf(num / den, (int)q);
   return t <= -103.97208404541015625f ? 0.0f : v;
 }
+// The same for the four labels of a lane's group, two at a time in packed float32 instructions (v_pk_mul / add / fma_f32: each
+// component rounds exactly like the scalar instruction; what has no packed form -- the maximum, the reciprocal, the scaling
+// and the select -- stays scalar). A wave issues one vector instruction every ~5 cycles whatever it is (tools/micro/
+// valu_rates.hip), so half the instructions is what counts. The division num / den is IEEE-exact in both forms:
+//   default: the compiler's division (v_div_scale / v_rcp / four fused steps / v_div_fmas / v_div_fixup);
+//   CTC_NP_SHORT_DIV: v_rcp + one Newton step + quotient + one fused correction -- den is in [0.8, 1.2] and num in [0.7, 1.5]
+//   here, nothing needs scaling or fixing up; correct rounding of that sequence on THIS chip's v_rcp_f32 is checked for every
+//   reduced argument by tools/micro/np_div_check.hip (round 6: 0 of 2.1e9 differ) before the macro may be set.
+__device__ __forceinline__ f32x2 np_exp_nonpos_pk(f32x2 t) {
+#pragma clang fp contract(off)
+  f32x2 tc;
+  tc.x = fmaxf(t.x, -104.0f);
+  tc.y = fmaxf(t.y, -104.0f);
+  const f32x2 magic = (f32x2)(12582912.0f);
+  f32x2 q = tc * (f32x2)(1.442695040888963407359924681001892137f);
+  q = q + magic;
+  q = q - magic;
+  f32x2 r = __builtin_elementwise_fma(q, (f32x2)(-6.93145752e-1f), tc);
+  r = __builtin_elementwise_fma(q, (f32x2)(-1.42860677e-6f), r);
+  f32x2 num = __builtin_elementwise_fma((f32x2)(5.082762527590693718096e-04f), r, (f32x2)(6.757896990527504603057e-03f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(5.114512081637298353406e-02f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(2.473615434895520810817e-01f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(7.257664613233124478488e-01f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(9.999999999980870924916e-01f));
+  f32x2 den = __builtin_elementwise_fma((f32x2)(2.159509375685829852307e-02f), r, (f32x2)(-2.742335390411667452936e-01f));
+  den = __builtin_elementwise_fma(den, r, (f32x2)(1.0f));
+  f32x2 p;
+#ifdef CTC_NP_SHORT_DIV
+  f32x2 y0;
+  y0.x = __builtin_amdgcn_rcpf(den.x);
+  y0.y = __builtin_amdgcn_rcpf(den.y);
+  const f32x2 e = __builtin_elementwise_fma(-den, y0, (f32x2)(1.0f));
+  const f32x2 y = __builtin_elementwise_fma(e, y0, y0);
+  const f32x2 q0 = num * y;
+  const f32x2 rem = __builtin_elementwise_fma(-den, q0, num);
+  p = __builtin_elementwise_fma(rem, y, q0);
+#else
+  p.x = num.x / den.x;
+  p.y = num.y / den.y;
+#endif
+  f32x2 v;
+  v.x = ldexpf(p.x, (int)q.x);
+  v.y = ldexpf(p.y, (int)q.y);
+  v.x = t.x <= -103.97208404541015625f ? 0.0f : v.x;
+  v.y = t.y <= -103.97208404541015625f ? 0.0f : v.y;
+  return v;
+}
 // index of element i of a row in the exchange buffer: eight floats of padding per 128 (the accumulator lanes of different
 // leaves then read different banks)
 __device__ __forceinline__ int np_pad(int i) { return i + ((i >> 7) << 3); }
@@ -1317,10 +1364,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
           float4 e;
+#ifdef CTC_NP_SCALAR
           e.x = np_exp_nonpos_dev(r[k].x - m);
           e.y = np_exp_nonpos_dev(r[k].y - m);
           e.z = np_exp_nonpos_dev(r[k].z - m);
           e.w = np_exp_nonpos_dev(r[k].w - m);
+#else
+          const f32x2 mm2 = (f32x2)(m);
+          const f32x2 e01 = np_exp_nonpos_pk((f32x2){r[k].x, r[k].y} - mm2), e23 = np_exp_nonpos_pk((f32x2){r[k].z, r[k].w} - mm2);
+          e = make_float4(e01.x, e01.y, e23.x, e23.y);
+#endif
           *(float4*)(np_rb + np_pad((k * 64 + lane) * 4)) = e;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
