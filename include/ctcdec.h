@@ -87,10 +87,21 @@ int ctcdec_lm_load_arpa(ctcdec_decoder* dec, const char* path, int32_t* order_ou
 
 /* The parsed model as one flat file (vocabulary, unigram array and the hashed n-gram table in upload
  * layout): what a kenlm binary is to an ARPA file (language_model.py:424 accepts .bin/.binary next to
- * .arpa) -- loading is a few reads instead of a parse.  kenlm's own binary formats are NOT readable
- * (out of scope); convert once from the ARPA file with ctcdec_lm_save_flat. */
+ * .arpa) -- loading is a few reads instead of a parse.  (kenlm's own probing binaries: ctcdec_lm_load_kenlm below.) */
 int ctcdec_lm_save_flat(const ctcdec_decoder* dec, const char* path);
 int ctcdec_lm_load_flat(ctcdec_decoder* dec, const char* path, int32_t* order_out);
+
+/* Replaces kenlm.Model("x.bin") (decoder.py:1074; language_model.py:424 accepts .bin / .binary): a kenlm PROBING binary
+ * (`build_binary probing`) -- header and sanity block, vocabulary strings checked against the vocabulary hash table, the
+ * unigram array and the per-order probing tables adopted entry by entry into the flat trie (which uses kenlm's own n-gram key
+ * chain for that reason).  Trie / quantised / array-compressed / rest-cost models are refused by name (CTCDEC_ERR_IO).
+ * FORMAT UNPINNED AGAINST REAL KENLM: restated from the published sources, pinned against ctcdec_arpa_to_kenlm_binary only
+ * (csrc/kenlm_binary.cpp).  ctcdec_is_kenlm_binary: 1 when the file starts with kenlm's magic bytes. */
+int ctcdec_lm_load_kenlm(ctcdec_decoder* dec, const char* path, int32_t* order_out);
+int ctcdec_is_kenlm_binary(const char* path);
+/* ARPA -> kenlm probing binary (what `build_binary probing x.arpa x.bin` writes, as far as kenlm's sources say): a converter
+ * and the reader's test vector.  probing_multiplier <= 1: kenlm's default 1.5. */
+int ctcdec_arpa_to_kenlm_binary(const char* arpa_path, const char* out_path, float probing_multiplier);
 
 /* Replaces LanguageModel.__init__'s unigram handling (language_model.py:257-265, :87-103):
  * unigrams given as a UTF-8 blob + offsets; has_unigrams=0 means "unigrams is None" (no trie).

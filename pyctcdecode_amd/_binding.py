@@ -92,6 +92,9 @@ _PROTOS = {
     "ctcdec_lm_load_arpa": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int32)]),
     "ctcdec_lm_save_flat": (C.c_int, [_VP, C.c_char_p]),
     "ctcdec_lm_load_flat": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int32)]),
+    "ctcdec_lm_load_kenlm": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int32)]),
+    "ctcdec_is_kenlm_binary": (C.c_int, [C.c_char_p]),
+    "ctcdec_arpa_to_kenlm_binary": (C.c_int, [C.c_char_p, C.c_char_p, C.c_float]),
     "ctcdec_lm_set_unigrams": (C.c_int, [_VP, C.c_int32, C.c_char_p, C.POINTER(C.c_int64), C.c_int64,
                                          C.POINTER(C.c_int64)]),
     "ctcdec_lm_share": (C.c_int, [_VP, _VP]),

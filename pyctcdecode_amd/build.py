@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libctcdec.so")
-SOURCES = ["api.cpp", "host_tables.cpp", "backend_hip.hip", "beam_wave_hip.hip", "beam_group_hip.hip"]
+SOURCES = ["api.cpp", "host_tables.cpp", "kenlm_binary.cpp", "backend_hip.hip", "beam_wave_hip.hip", "beam_group_hip.hip"]
 # The wave kernel is one loop over the frames with ~18 000 instructions in its body and a budget of 128 registers. LLVM's
 # machine-level loop-invariant code motion hoists every constant and address computation it finds out of that loop and
 # keeps them in registers across it: 105 registers spilled to scratch memory (and every reload of one waits for the
@@ -24,7 +24,7 @@ HIP_FLAGS = {"backend_hip.hip": _MAX_ILP,
              # (the workgroup kernel: 238 -> 195 registers, 255 -> 138 scalar registers spilled to vector lanes)
              "beam_group_hip.hip": ["-mllvm", "-disable-machine-licm"]}
 HEADERS = ["common.h", "beam_core.h", "beam_wave.h", "set_order.h", "set_order_small.h", "backend.h", "host_tables.h", "np_sum.h",
-           "wave_ops_hip.h", "text_wave.h"]
+           "np_f32.h", "wave_ops_hip.h", "text_wave.h"]
 
 
 def hipcc() -> str:

@@ -439,6 +439,26 @@ int ctcdec_lm_load_flat(ctcdec_decoder* dec, const char* path, int32_t* order_ou
   return CTCDEC_OK;
 }
 
+int ctcdec_lm_load_kenlm(ctcdec_decoder* dec, const char* path, int32_t* order_out) {
+  if (!dec || !path) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  if (dec->multi) return fail(CTCDEC_ERR_ARG, "decoder holds several language models");
+  std::string e = dec->lm_ref().load_kenlm_binary(path);
+  if (!e.empty()) return fail(CTCDEC_ERR_IO, e);
+  dec->has_lm = true;
+  dec->tables_dirty = true;
+  if (order_out) *order_out = dec->lm_ref().order;
+  return CTCDEC_OK;
+}
+
+int ctcdec_is_kenlm_binary(const char* path) { return path && looks_like_kenlm_binary(path) ? 1 : 0; }
+
+int ctcdec_arpa_to_kenlm_binary(const char* arpa_path, const char* out_path, float probing_multiplier) {
+  if (!arpa_path || !out_path) return fail(CTCDEC_ERR_ARG, "bad arguments");
+  std::string e = arpa_to_kenlm_binary(arpa_path, out_path, probing_multiplier);
+  if (!e.empty()) return fail(CTCDEC_ERR_IO, e);
+  return CTCDEC_OK;
+}
+
 int ctcdec_lm_set_unigrams(ctcdec_decoder* dec, int32_t has_unigrams, const char* blob, const int64_t* off,
                            int64_t n_unigrams, int64_t* n_kept_out) {
   if (!dec || !dec->has_lm) return fail(CTCDEC_ERR_ARG, "no language model loaded");

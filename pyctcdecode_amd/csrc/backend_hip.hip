@@ -1204,6 +1204,40 @@ __device__ __forceinline__ f32x2 np_exp_nonpos_pk(f32x2 t) {
   v.y = t.y <= -103.97208404541015625f ? 0.0f : v.y;
   return v;
 }
+// ... and for rows all of whose arguments are in (-87, 0] -- every row of ordinary logits; a row that reaches further down is
+// handed to the per-row kernel --: no clamp, no underflow select, and the scaling by 2^k as one integer add into the exponent
+// field (the result is a normal number there: exactly what ldexpf gives; k sits in the low mantissa bits of q + 1.5 * 2^23).
+__device__ __forceinline__ f32x2 np_exp_nonpos_pk_fast(f32x2 t) {
+#pragma clang fp contract(off)
+  const f32x2 magic = (f32x2)(12582912.0f);
+  f32x2 q = t * (f32x2)(1.442695040888963407359924681001892137f);
+  const f32x2 qm = q + magic;
+  q = qm - magic;
+  f32x2 r = __builtin_elementwise_fma(q, (f32x2)(-6.93145752e-1f), t);
+  r = __builtin_elementwise_fma(q, (f32x2)(-1.42860677e-6f), r);
+  f32x2 num = __builtin_elementwise_fma((f32x2)(5.082762527590693718096e-04f), r, (f32x2)(6.757896990527504603057e-03f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(5.114512081637298353406e-02f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(2.473615434895520810817e-01f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(7.257664613233124478488e-01f));
+  num = __builtin_elementwise_fma(num, r, (f32x2)(9.999999999980870924916e-01f));
+  f32x2 den = __builtin_elementwise_fma((f32x2)(2.159509375685829852307e-02f), r, (f32x2)(-2.742335390411667452936e-01f));
+  den = __builtin_elementwise_fma(den, r, (f32x2)(1.0f));
+  // num / den, IEEE-exact: v_rcp_f32 + one Newton step + quotient + one fused correction (den in [0.8, 1.2], num in [0.7, 1.5]:
+  // nothing to scale or fix up; checked against the compiler's division for every reduced argument on this chip:
+  // tools/micro/np_div_check.hip, profiles/r06_np_div_check.txt -- 0 of 2 104 533 978 differ)
+  f32x2 y0;
+  y0.x = __builtin_amdgcn_rcpf(den.x);
+  y0.y = __builtin_amdgcn_rcpf(den.y);
+  const f32x2 e = __builtin_elementwise_fma(-den, y0, (f32x2)(1.0f));
+  const f32x2 y = __builtin_elementwise_fma(e, y0, y0);
+  const f32x2 q0 = num * y;
+  const f32x2 rem = __builtin_elementwise_fma(-den, q0, num);
+  const f32x2 p = __builtin_elementwise_fma(rem, y, q0);
+  f32x2 v;
+  v.x = __uint_as_float(__float_as_uint(p.x) + (__float_as_uint(qm.x) << 23));
+  v.y = __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(qm.y) << 23));
+  return v;
+}
 // index of element i of a row in the exchange buffer: eight floats of padding per 128 (the accumulator lanes of different
 // leaves then read different banks)
 __device__ __forceinline__ int np_pad(int i) { return i + ((i >> 7) << 3); }
@@ -1358,7 +1392,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
     uint32_t cnt = 0xFFFFu;  // "not a clean row": the per-row kernel takes it
     int first = 0;
     double s = 1.0;
-    if (isfinite(m) && rs == rs) {
+    bool clean = isfinite(m) && rs == rs;
+    if constexpr (NP) {
+      // numpy-order sums: a row whose smallest logit is 87 or more below its maximum (exponentials that are denormal or zero in
+      // float32; -inf masks; labels past the row's end do not count) takes the per-row kernel, whose exponential has the
+      // underflow rules -- the 16 exponentials below then need neither a clamp nor a select, and scale by an integer add
+      float lo = INFINITY;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if constexpr (AL) {
+          if (n4 == NL * 64 || in_row(k)) lo = fminf(fminf(lo, fminf(r[k].x, r[k].y)), fminf(r[k].z, r[k].w));
+        } else {
+          const int e0 = (k * 64 + lane) * 4;
+          lo = fminf(lo, fminf(fminf(e0 < V ? r[k].x : lo, e0 + 1 < V ? r[k].y : lo), fminf(e0 + 2 < V ? r[k].z : lo, e0 + 3 < V ? r[k].w : lo)));
+        }
+      }
+      if (clean && __ballot(!(lo - m > -87.0f)) != 0ull) clean = false;
+    }
+    if (clean) {
       if constexpr (NP) {
         // numpy's float32 exp of every label, in place; through the exchange buffer; numpy's accumulators
 #pragma unroll
@@ -1371,7 +1422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
           e.w = np_exp_nonpos_dev(r[k].w - m);
 #else
           const f32x2 mm2 = (f32x2)(m);
-          const f32x2 e01 = np_exp_nonpos_pk((f32x2){r[k].x, r[k].y} - mm2), e23 = np_exp_nonpos_pk((f32x2){r[k].z, r[k].w} - mm2);
+          const f32x2 e01 = np_exp_nonpos_pk_fast((f32x2){r[k].x, r[k].y} - mm2), e23 = np_exp_nonpos_pk_fast((f32x2){r[k].z, r[k].w} - mm2);
           e = make_float4(e01.x, e01.y, e23.x, e23.y);
 #endif
           *(float4*)(np_rb + np_pad((k * 64 + lane) * 4)) = e;

@@ -96,13 +96,21 @@ CTC_HD uint32_t key_slot_hash(uint64_t text_h, uint64_t part_h, uint32_t ch) {
   return (uint32_t)(mix64(text_h * 0x9E3779B97F4A7C15ull + part_h * 0xC2B2AE3D27D4EB4Full + ch) >> 32);
 }
 
-// n-gram key: a chain over the word ids NEWEST FIRST (the scored word, then its context going back), so the
-// keys of all orders of one query share their prefix: key_n = end(push(...push(push(begin, w_n), w_{n-1})..., w_1), n)
-// costs one mix per order instead of one per word per order.  Never 0 (0 marks an empty slot).  The key is a
-// mixed value already: its low bits are the table slot. (Round 5: the per-word step is mix_step -- two 32-bit multiplies --
-// instead of a splitmix64 finaliser; the host checks every loaded model for colliding keys with an independent hash.)
-CTC_HD uint64_t ngram_key_begin() { return 0x243F6A8885A308D3ull; }
-CTC_HD uint64_t ngram_key_push(uint64_t k, uint32_t id) { return mix_step(k, id, rotl32(id, 16)); }
+// n-gram key: a chain over the word ids NEWEST FIRST (the scored word, then its context going back), so the keys of all
+// orders of one query share their prefix: key_n = end(push(...push(first(w_n), w_{n-1})..., w_1), n) costs one step per order
+// instead of one per word per order. Round 6: the chain IS kenlm's own -- lm/search_hashed.hh: a unigram's node is its word
+// index, every further (older) context word is folded in by CombineWordHash, (node * 8978948897894561157) ^ ((1 + word) *
+// 17894857484156487943) -- over kenlm's own word indices (<unk> = 0, the others in the order of the ARPA unigram section):
+// the middle / longest hash tables of a kenlm PROBING binary can then be adopted entry by entry, key and all, without the
+// n-grams' words (which such a file does not hold: host_tables.cpp, HostLM::load_kenlm_binary). The order goes into the top
+// byte (kenlm keeps one table per order, here all orders share one); never 0 (0 marks an empty slot); the slot is the key's
+// low bits (tools/hash_quality.py on the bench model: 849 152 n-grams + 18 M synthetic tuples without a collision, 1.126
+// probes per hit at load <= 1/4 -- the same as rounds 4 and 5's chains). Two 64-bit multiplies per step (~13 vector
+// instructions; round 5's mix_step: ~8) on a path that runs once per completed word.
+CTC_HD uint64_t ngram_key_first(uint32_t wid) { return (uint64_t)wid; }
+CTC_HD uint64_t ngram_key_push(uint64_t k, uint32_t id) {
+  return (k * 8978948897894561157ull) ^ ((uint64_t)(1u + id) * 17894857484156487943ull);
+}
 CTC_HD uint64_t ngram_key_end(uint64_t k, uint32_t n) {
   k ^= (uint64_t)n << 56;
   return k == 0 ? 1 : k;
@@ -406,7 +414,7 @@ CTC_HD void lm_probe_issue(const Tab& t, const LmState& in, uint32_t wid, LmProb
   p.s2 = p.s3 = p.s4 = p.s5 = p.s6 = 0;
   p.e2 = p.e3 = p.e4 = p.e5 = p.e6 = none;
   // one chain, newest word first: the key of order n extends the key of order n-1 by one word
-  uint64_t c = ngram_key_push(ngram_key_begin(), wid);
+  uint64_t c = ngram_key_first(wid);
   if (max_n >= 2) { c = ngram_key_push(c, in.words[0]); p.k2 = ngram_key_end(c, 2); p.s2 = p.k2 & t.ngram_mask; p.e2 = t.ngrams[p.s2]; }
   if (MAXORD >= 3 && max_n >= 3) { c = ngram_key_push(c, in.words[1]); p.k3 = ngram_key_end(c, 3); p.s3 = p.k3 & t.ngram_mask; p.e3 = t.ngrams[p.s3]; }
   if (MAXORD >= 4 && max_n >= 4) { c = ngram_key_push(c, in.words[2]); p.k4 = ngram_key_end(c, 4); p.s4 = p.k4 & t.ngram_mask; p.e4 = t.ngrams[p.s4]; }

@@ -139,6 +139,8 @@ std::string HostLM::load_arpa(const std::string& path) {
   words.clear();
   vocab.clear();
   unigrams.clear();
+  raw_ngrams.clear();
+  unk_listed = false;
   words.push_back("<unk>");
   vocab["<unk>"] = 0;
   unigrams.push_back(UnigramEntry{-100.0f, 0.0f});  // kenlm default when <unk> is missing
@@ -212,6 +214,7 @@ std::string HostLM::load_arpa(const std::string& path) {
       uint32_t id;
       if (w == "<unk>") {
         id = 0;
+        unk_listed = true;
       } else {
         auto it = vocab.find(w);
         if (it == vocab.end()) {
@@ -225,11 +228,17 @@ std::string HostLM::load_arpa(const std::string& path) {
       }
       unigrams[id] = UnigramEntry{prob, backoff};
     } else {
-      uint64_t k = ngram_key_begin(), chk = 0x6A09E667F3BCC909ull;  // newest word first (common.h)
+      uint64_t k = 0, chk = 0x6A09E667F3BCC909ull, k_suffix = 0;  // newest word first (common.h)
       for (int j = section - 1; j >= 0; --j) {
         const uint32_t id = index(toks[j]);
-        k = ngram_key_push(k, id);
+        if (j == 0) k_suffix = k;  // the chain over w2..wn
+        k = j == section - 1 ? ngram_key_first(id) : ngram_key_push(k, id);
         chk = mix64(chk ^ (uint64_t)id) + 0x13198A2E03707344ull;
+      }
+      if (keep_raw) {
+        uint64_t k_prefix = 0;  // the chain over w1..w(n-1)
+        for (int j = section - 2; j >= 0; --j) k_prefix = j == section - 2 ? ngram_key_first(index(toks[j])) : ngram_key_push(k_prefix, index(toks[j]));
+        raw_ngrams.push_back(RawNgram{section, k, k_suffix, k_prefix, prob, backoff});
       }
       raw.push_back(RawGram{ngram_key_end(k, (uint32_t)section), chk ^ (uint64_t)section, prob, backoff});
     }
@@ -264,7 +273,7 @@ std::string HostLM::load_arpa(const std::string& path) {
 
 // ---- flat model file: "CTCDLM01" | order, n_words, bos, eos (u32) | n_ngrams, table_size, blob_bytes (u64)
 //      | word end offsets u64[n_words] | word bytes | UnigramEntry[n_words] | NgramEntry[table_size] | "CTCDEND1"
-static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '3'};  // 03: n-gram keys by mix_step (02: splitmix chain), newest-first, slot = key & mask
+static const char kCacheMagic[8] = {'C', 'T', 'C', 'D', 'L', 'M', '0', '4'};  // 04: n-gram keys by kenlm's CombineWordHash chain (03: mix_step, 02: splitmix), newest-first, slot = key & mask
 static const char kCacheEnd[8] = {'C', 'T', 'C', 'D', 'E', 'N', 'D', '1'};
 
 std::string HostLM::save_cache(const std::string& path) const {

@@ -52,8 +52,20 @@ struct HostLM {
   uint64_t prefix_mask = 0;
   size_t n_ngrams = 0;
 
+  // ARPA -> kenlm binary writer only (kenlm_binary.cpp): the n-grams as listed, with the keys of their two (n-1)-gram halves
+  struct RawNgram {
+    int order;
+    uint64_t key, suffix_key, prefix_key;  // kenlm's chain over w1..wn / w2..wn / w1..w(n-1) (before ngram_key_end)
+    float prob, backoff;
+  };
+  bool keep_raw = false;
+  bool unk_listed = false;  // the ARPA file lists <unk> itself
+  std::vector<RawNgram> raw_ngrams;
+
   // returns "" on success, else an error message
   std::string load_arpa(const std::string& path);
+  // a kenlm PROBING binary (build_binary probing): kenlm_binary.cpp -- format unpinned against real kenlm, see there
+  std::string load_kenlm_binary(const std::string& path);
   // The parsed model as one flat file (vocabulary, unigram array, hashed n-gram table exactly as they
   // are uploaded): loading it is a few freads instead of an ARPA parse.  Same return convention.
   std::string save_cache(const std::string& path) const;
@@ -65,6 +77,10 @@ struct HostLM {
   void start_state(bool begin_sentence, LmState* out) const;
   void tables(DeviceTables* t) const;  // host pointers (for the host-side query)
 };
+
+bool looks_like_kenlm_binary(const std::string& path);  // by its magic bytes
+// ARPA -> kenlm probing binary, as far as kenlm's sources say (test infrastructure for the reader + a converter)
+std::string arpa_to_kenlm_binary(const std::string& arpa_path, const std::string& out_path, float probing_multiplier);
 
 // TokInfo.start_* of every label, looked up in a vocabulary prefix table
 void fill_token_starts_from(const std::vector<PrefixEntry>& table, uint64_t mask, HostAlphabet* alpha);

@@ -175,9 +175,11 @@ class _Batch:
         else:
             arrs = [x.detach().cpu().numpy() if _is_device_tensor(x) else np.asarray(x) for x in logits_list]
             # float32 / float16 matrices go over in their own dtype: the reference decides "probabilities or logits?" on
-            # the input dtype (decoder.py:760), and so does the library. Everything else (float64, integers, mixed
-            # batches) is widened to float64 first.
-            kinds = {a.dtype for a in arrs}
+            # the input dtype (decoder.py:760) and computes a float32 matrix's log-softmax in float32 (decoder.py:180-197), and so
+            # does the library. Everything else (float64, integers, batches that mix float32 with float64 / integer matrices --
+            # those are computed in float64 altogether, a documented deviation of <= 1e-6 for their float32 members) is widened to
+            # float64 first. Matrices without frames have no say.
+            kinds = {a.dtype for a in arrs if a.shape[0] > 0}
             target, self.dtype = np.float64, 1
             if kinds == {np.dtype(np.float32)}:
                 target, self.dtype = np.float32, 0

@@ -11,6 +11,7 @@ from __future__ import annotations
 import abc
 import ctypes as C
 import logging
+import os
 import re
 from typing import Any, Collection, Dict, Iterable, List, Optional, Sequence, Set, Tuple
 
@@ -90,9 +91,15 @@ class MultiLanguageModelState(AbstractLMState):
 
 class NgramModel:
     """The n-gram model inside libctcdec: what ``kenlm.Model(path)`` is to the reference
-    (decoder.py:1074).  Reads ARPA text and its own flat model files (``*.ctcdec``, written by
-    :meth:`save_flat`: the ARPA file parsed once, loading is a few reads -- the role a kenlm binary plays
-    for the reference); kenlm's binary formats themselves are not readable."""
+    (decoder.py:1074).  Reads ARPA text, kenlm PROBING binaries (``build_binary probing``; the format is restated from
+    kenlm's published sources and pinned only against this library's own writer: csrc/kenlm_binary.cpp) and its own flat model
+    files (``*.ctcdec``, written by :meth:`save_flat`: the ARPA file parsed once, loading is a few reads)."""
+
+    @staticmethod
+    def arpa_to_kenlm_binary(arpa_path: str, out_path: str, probing_multiplier: float = 1.5) -> None:
+        """ARPA -> kenlm probing binary (the layout ``build_binary probing`` writes, as far as kenlm's sources say)."""
+        lib = B.get_library()
+        lib.check(lib.dll.ctcdec_arpa_to_kenlm_binary(arpa_path.encode("utf-8"), out_path.encode("utf-8"), float(probing_multiplier)))
 
     FLAT_SUFFIX = ".ctcdec"
 
@@ -110,10 +117,13 @@ class NgramModel:
             self.order = _clone_of.order
             return
         flat = path.endswith(self.FLAT_SUFFIX)
-        if not flat and not path.endswith(".arpa"):
+        # a kenlm binary (decoder.py:1074 hands any path to kenlm.Model; language_model.py:424 accepts .bin / .binary): told by
+        # its magic bytes, whatever it is called. Only the PROBING format is read (the library refuses the others by name).
+        kenlm_bin = not flat and os.path.isfile(path) and bool(lib.dll.ctcdec_is_kenlm_binary(self.path))
+        if not flat and not kenlm_bin and not path.endswith(".arpa"):
             raise NotImplementedError(
-                "only ARPA text models (and their %s conversions) are supported by the device trie builder; "
-                "got %r (kenlm binary formats are not readable)" % (self.FLAT_SUFFIX, path)
+                "language model files are read as ARPA text (.arpa), as kenlm probing binaries (told by their magic bytes) or as "
+                "this package's flat files (%s); got %r" % (self.FLAT_SUFFIX, path)
             )
         blob, off = B.pack_strings([""])
         handle = C.c_void_p()
@@ -121,7 +131,7 @@ class NgramModel:
         self._handle = handle
         order = C.c_int32()
         try:
-            load = lib.dll.ctcdec_lm_load_flat if flat else lib.dll.ctcdec_lm_load_arpa
+            load = lib.dll.ctcdec_lm_load_flat if flat else (lib.dll.ctcdec_lm_load_kenlm if kenlm_bin else lib.dll.ctcdec_lm_load_arpa)
             lib.check(load(handle, self.path, C.byref(order)))
         except Exception:
             lib.dll.ctcdec_destroy(handle)

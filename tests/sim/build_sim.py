@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 SRC = os.path.join(ROOT, "pyctcdecode_amd", "csrc")
 OUT_DIR = os.path.join(ROOT, "tests", "_build")
 OUT = os.path.join(OUT_DIR, "libctcdec_sim.so")
-SOURCES = [os.path.join(SRC, "api.cpp"), os.path.join(SRC, "host_tables.cpp"),
+SOURCES = [os.path.join(SRC, "api.cpp"), os.path.join(SRC, "host_tables.cpp"), os.path.join(SRC, "kenlm_binary.cpp"),
            os.path.join(ROOT, "tests", "sim", "backend_sim.cpp")]
 DEPS = SOURCES + [os.path.join(SRC, h) for h in ("common.h", "beam_core.h", "beam_wave.h", "text_wave.h", "set_order.h",
-                                                  "np_sum.h", "backend.h", "host_tables.h")] + [os.path.join(ROOT, "tests", "sim", "wave_fibers.h"), os.path.join(ROOT, "tests", "sim", "group_fibers.h")] + [os.path.join(ROOT, "include", "ctcdec.h")]
+                                                  "np_sum.h", "np_f32.h", "backend.h", "host_tables.h")] + [os.path.join(ROOT, "tests", "sim", "wave_fibers.h"), os.path.join(ROOT, "tests", "sim", "group_fibers.h")] + [os.path.join(ROOT, "include", "ctcdec.h")]
 
 
 def build(force: bool = False) -> str:

@@ -419,14 +419,14 @@ def test_lazy_text_frames_and_memo_entries_behave_like_the_plain_objects():
             self.text = text
 
     memo = _LazyMemo({("", False): (0.0, 0.0, "START")})
-    memo._note([_B("a"), _B("a b"), _B("")], [-1.0, -2.0, -9.0], store, 0)
+    memo._note([_B("a"), _B("a b"), _B("")], [-1.0, -2.0, -9.0], store)
     assert memo._pending and dict.__len__(memo) == 1  # nothing filed yet
     assert ("a b", False) in memo and not memo._pending and len(memo) == 3
     assert memo[("a", False)][0] == -1.0 and memo.get(("a b", False))[1] == -2.0
     assert memo[("", False)] == (0.0, 0.0, "START")  # (an entry that is already there is not replaced)
-    memo._note([_B("c")], [-3.0], store, 2)
+    memo._note([_B("c")], [-3.0], store)
     memo[("c", False)] = (1.0, 1.0, "MINE")  # a caller's own entry wins over a pending note
     assert memo[("c", False)] == (1.0, 1.0, "MINE") and sorted(k[0] for k in memo) == ["", "a", "a b", "c"]
-    memo._note([_B("d")], [-4.0], store, 0)
+    memo._note([_B("d")], [-4.0], store)
     plain = pickle.loads(pickle.dumps(memo))
     assert type(plain) is dict and ("d", False) in plain and len(plain) == 5

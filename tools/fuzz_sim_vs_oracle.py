@@ -209,10 +209,11 @@ def run_case(rng, execute=True):
     # float32 matrix itself) -- except PROBABILITY input, whose scores the reference accumulates in float32 altogether
     with np.errstate(all="ignore"):
         f32_prob = x.dtype == np.float32 and x.shape[0] > 0 and math.isclose(x.sum(axis=1).mean(), 1)
-    f32_loose = x.dtype == np.float32 and (f32_prob or (_prune_mode() == "p" and x.shape[1] <= 4095))
-    f32_path = TOL_F32 is not None and (f32_loose or
-                                        (x.dtype == np.float16 and x.shape[1] % 8 == 0 and x.shape[1] <= 1024))
+    f32_poly = x.dtype == np.float32 and _prune_mode() == "p" and x.shape[1] <= 4095
+    f32_path = TOL_F32 is not None and (f32_poly or (x.dtype == np.float16 and x.shape[1] % 8 == 0 and x.shape[1] <= 1024))
     tkw = {"tol": TOL_F32, "tie_tol": 4e-5} if f32_path else {"tol": TOL, "tie_tol": 1e-9}
+    if f32_prob:  # (every backend: the reference's float32 score accumulation is not restated)
+        tkw = {"tol": 1e-4, "tie_tol": 4e-5}
     expd = [{"text": e[0], "frames": [[w, int(a), int(b)] for w, (a, b) in e[2]], "logit": e[3], "lm": e[4]} for e in exp]
     try:
         check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], expd, what="whole", **tkw)

@@ -36,7 +36,19 @@ def push_new(k, ids):
     return mix_step(k, ids, (ids << np.uint32(16)) | (ids >> np.uint32(16)))
 
 
+def keys_kenlm(tuples):
+    """kenlm's own chain (CombineWordHash): the scored word's index, then every context word going back; order in the top byte"""
+    A, B = np.uint64(8978948897894561157), np.uint64(17894857484156487943)
+    k = tuples[:, -1].astype(np.uint64)
+    for j in range(tuples.shape[1] - 2, -1, -1):
+        k = (k * A) ^ ((tuples[:, j].astype(np.uint64) + np.uint64(1)) * B)
+    k ^= np.uint64(tuples.shape[1]) << np.uint64(56)
+    return k
+
+
 def keys(tuples, push):
+    if push is None:
+        return keys_kenlm(tuples)
     """tuples: [n, order] word ids, oldest first; key chain newest first"""
     k = np.full(len(tuples), 0x243F6A8885A308D3, dtype=np.uint64)
     for j in range(tuples.shape[1] - 1, -1, -1):
@@ -90,7 +102,8 @@ def main():
                 by_order.setdefault(section, []).append([vocab.get(t, 0) for t in toks])
     print("%s: %d words, n-grams per order %s" % (path, len(vocab), {k: len(v) for k, v in by_order.items()}))
     rng = np.random.default_rng(1)
-    for name, push in (("old (splitmix64 per word)", push_old), ("new (mix_step per word)", push_new)):
+    for name, push in (("old (splitmix64 per word)", push_old), ("round 5 (mix_step per word)", push_new),
+                       ("round 6 (kenlm's CombineWordHash)", None)):
         ks = [keys(np.array(v, dtype=np.int64), push) for _, v in sorted(by_order.items())]
         allk = np.concatenate(ks)
         uniq = len(np.unique(allk))

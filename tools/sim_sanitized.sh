@@ -6,7 +6,7 @@ set -eu
 out=tests/_build/libctcdec_sim_asan.so
 mkdir -p tests/_build
 g++ -std=c++17 -O1 -g -fPIC -shared -pthread -DCTC_SIM -DCTC_TEXT_WIN=48 -DCTC_TEXT_LIST=16 -fsanitize=address,undefined \
-    -fno-omit-frame-pointer -Wno-unused-function -o $out pyctcdecode_amd/csrc/api.cpp pyctcdecode_amd/csrc/host_tables.cpp \
+    -fno-omit-frame-pointer -Wno-unused-function -o $out pyctcdecode_amd/csrc/api.cpp pyctcdecode_amd/csrc/host_tables.cpp pyctcdecode_amd/csrc/kenlm_binary.cpp \
     tests/sim/backend_sim.cpp
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:abort_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
