@@ -197,7 +197,8 @@ struct ctcdec_decoder {
   // per-call workspace (grow only)
   DevBuf w_logits, w_ptrs, w_row0, w_rowsum, w_isprob, w_scnt, w_sid, w_slp, w_flags, w_text, w_emit, w_toff,
       w_eoff, w_start, w_out, w_nout, w_status, w_tok, w_head, w_prof, w_imp, w_impoff, w_ff, w_cold, w_pay, w_tscr, w_tsoff, w_tpool,
-      d_toktext, d_tokbytes, w_slow, w_order;
+      d_toktext, d_tokbytes, w_slow, w_order, w_side;
+  bool slicing = false;  // a time-sliced host ingest is under way (decode_host_sliced): the prune stage notes each slice's side of 1
   uint32_t max_label_bytes = 1;
   bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
   HostBuf h_tok, h_out, h_small;
@@ -207,7 +208,7 @@ struct ctcdec_decoder {
     DevBuf* all[] = {&d_tok,  &d_tok_hot, &d_uni,  &d_pref,  &d_hot,  &w_logits, &w_ptrs, &w_row0,
                      &w_rowsum, &w_isprob, &w_scnt, &w_sid,  &w_slp,   &w_flags, &w_text,   &w_emit, &w_toff,
                      &w_eoff,  &w_start,  &w_out,  &w_nout, &w_status, &w_tok,  &w_head, &w_prof, &w_imp, &w_impoff, &w_ff, &w_cold, &w_pay,
-                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow, &w_order};
+                     &w_tscr,  &w_tsoff, &w_tpool, &d_toktext, &d_tokbytes, &w_slow, &w_order, &w_side};
     for (DevBuf* b : all) b->drop();
     for (int k = 0; k < MAX_LMS - 1; ++k) {
       d_xuni[k].drop();
@@ -664,13 +665,30 @@ static void fill_result(const OutBeam& ob, const LmState* xs, int K, BeamResult*
   r->raw_lm = ob.raw_lm;
 }
 
+// after_launch: called once the kernels of this call are queued and before the host waits for them (time-sliced host ingest:
+// the next slice's copy runs under this slice's kernels)
+typedef std::function<int(std::string*)> AfterLaunch;
 static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
                        int32_t dtype, int32_t is_device, const ctcdec_params* p, const ctcdec_lm_state* start_states,
-                       const StreamIn* stream, ctcdec_result** out, ctcdec_stream* rs = nullptr, bool want_result = true);
+                       const StreamIn* stream, ctcdec_result** out, ctcdec_stream* rs = nullptr, bool want_result = true,
+                       const AfterLaunch* after_launch = nullptr);
+static int decode_host_sliced(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
+                              int32_t dtype, const ctcdec_params* p, const ctcdec_lm_state* start_states, int n_slices,
+                              ctcdec_result** out);
+static int host_slices_wanted(const ctcdec_decoder* dec, const int32_t* utt_frames, int32_t n_utts, int32_t dtype);
 
 int ctcdec_decode_batch(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames,
                         int32_t n_utts, int32_t dtype, int32_t is_device, const ctcdec_params* p,
                         const ctcdec_lm_state* start_states, ctcdec_result** out) {
+  // Large HOST batches (the reference's own calling convention: numpy in) go over in time slices, the copy of slice k + 1
+  // under the kernels of slice k (decode_host_sliced); 1 = "decode it in one piece after all" (probability-like rows)
+  if (dec && p && out && !is_device && n_utts > 0 && utt_logits && utt_frames && dtype >= CTCDEC_F32 && dtype <= CTCDEC_BF16) {
+    const int n_slices = host_slices_wanted(dec, utt_frames, n_utts, dtype);
+    if (n_slices >= 2) {
+      const int rc = decode_host_sliced(dec, utt_logits, utt_frames, n_utts, dtype, p, start_states, n_slices, out);
+      if (rc != 1) return rc;
+    }
+  }
   return decode_impl(dec, utt_logits, utt_frames, n_utts, dtype, is_device, p, start_states, nullptr, out);
 }
 
@@ -780,7 +798,8 @@ static std::string build_import(const ctcdec_decoder* dec, const StreamIn& st, i
 // caller's beams for the replay); want_result: materialise beams at all
 static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
                        int32_t dtype, int32_t is_device, const ctcdec_params* p, const ctcdec_lm_state* start_states,
-                       const StreamIn* stream, ctcdec_result** out, ctcdec_stream* rs, bool want_result) {
+                       const StreamIn* stream, ctcdec_result** out, ctcdec_stream* rs, bool want_result,
+                       const AfterLaunch* after_launch) {
   if (!dec || !p || !out || n_utts < 0 || (n_utts > 0 && (!utt_logits || !utt_frames)))
     return fail(CTCDEC_ERR_ARG, "bad arguments");
   if (dtype < CTCDEC_F32 || dtype > CTCDEC_BF16) return fail(CTCDEC_ERR_ARG, "dtype must be f32, f64, f16 or bf16");
@@ -1111,6 +1130,8 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     pa.pass = 0;
     pa.row_base = 0;
     pa.slow_rows = (uint32_t*)dec->w_slow.p;
+    pa.utt_side = dec->slicing ? (uint32_t*)dec->w_side.p : nullptr;
+    pa.utt_sum = dec->slicing ? (double*)((char*)dec->w_side.p + (((size_t)n_utts * 4 + 15) & ~(size_t)15)) : nullptr;
     pa.rows_aligned16 = 1;
     pa.rows_aligned4 = 1;
     for (const void* q : ptrs) {
@@ -1169,6 +1190,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     max_surv = V;  // un-normalised probability rows can exceed the bound: redo at full width
   }
 
+  if (after_launch && *after_launch && (*after_launch)(&err)) return fail(CTCDEC_ERR_DEVICE, err);
   // results back (page-locked staging: the token pool is a few MB per batch)
   const bool host_timing = getenv("CTCDEC_HOST_TIMING") != nullptr;
   auto t_launch = std::chrono::steady_clock::now();
@@ -1425,6 +1447,135 @@ int ctcdec_stream_import(ctcdec_stream* st, const ctcdec_beam_in* beams, const i
   return CTCDEC_OK;
 }
 
+// ---- time-sliced ingest of host batches --------------------------------------------------------------------------------
+// The reference is called with numpy matrices (decoder.py:730-775). Copying a large host batch takes longer than decoding it
+// (2.1 GB: 37 ms over PCIe, 13 ms of kernels), and an utterance's beam search is ~11 us x T of latency whatever the batch size,
+// so overlapping per-utterance chunks would still end with one full-length decode after the last copy. TIME slices do not:
+// the batch goes through the device-resident stream machinery (ctcdec_stream_*: the beams stay on the device between
+// slices), slice k + 1 is copied -- hipMemcpy2D of [utterances x slice bytes] with the batch's pitch, as fast from pageable
+// memory as one big copy: tools/h2d_2d_probe.py -- while slice k's kernels run, and only the last slice's kernels are exposed.
+// Chunked == unchunked for logits (what partial_decode_beams guarantees and the suites check); the one thing that is a property
+// of the WHOLE utterance is the probability sniff (decoder.py:760): whenever any slice of any utterance is within reach of
+// "mean row sum = 1", or an utterance has slices on both sides of 1, the batch is decoded again in one piece (return 1).
+static int host_slices_wanted(const ctcdec_decoder* dec, const int32_t* utt_frames, int32_t n_utts, int32_t dtype) {
+  const char* env = getenv("CTCDEC_HOST_SLICES");  // 0: never; n >= 2: always, in n slices (tests); unset: by size
+  if (env && atoi(env) < 2) return 0;
+  const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
+  int64_t rows = 0, tmax = 0;
+  for (int32_t u = 0; u < n_utts; ++u) {
+    if (utt_frames[u] < 0) return 0;
+    rows += utt_frames[u];
+    tmax = std::max<int64_t>(tmax, utt_frames[u]);
+  }
+  const double bytes = (double)rows * (double)dec->alpha.labels.size() * (double)esz;
+  int n = env ? atoi(env) : (bytes >= 512e6 ? (int)std::min(16.0, std::max(4.0, bytes / 256e6)) : 0);
+  if (n > tmax / 2) n = (int)(tmax / 2);
+  return n >= 2 ? n : 0;
+}
+
+static int decode_host_sliced(ctcdec_decoder* dec, const void* const* utt_logits, const int32_t* utt_frames, int32_t n_utts,
+                              int32_t dtype, const ctcdec_params* p, const ctcdec_lm_state* start_states, int n_slices,
+                              ctcdec_result** out) {
+  if (p->beam_width < 1 || p->beam_width > CTCDEC_MAX_BEAM_WIDTH) return 1;  // (the one-piece path words the refusal)
+  const size_t V = dec->alpha.labels.size();
+  const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
+  int64_t tmax = 0;
+  for (int32_t u = 0; u < n_utts; ++u) tmax = std::max<int64_t>(tmax, utt_frames[u]);
+  const int64_t C = (tmax + n_slices - 1) / n_slices;  // frames per slice
+  const size_t row_bytes = V * esz, slot = (size_t)C * row_bytes;
+  std::string err;
+  ctcdec_stream* st = nullptr;
+  int rc = ctcdec_stream_open(dec, n_utts, start_states, &st);
+  if (rc != CTCDEC_OK) return rc;
+  // per utterance: "a slice was read as probabilities" (u32), then the sum of all row sums seen so far (f64)
+  const size_t side_off = ((size_t)n_utts * 4 + 15) & ~(size_t)15, side_bytes = side_off + (size_t)n_utts * 8;
+  struct Closer {
+    ctcdec_stream* s;
+    ctcdec_decoder* d;
+    ~Closer() {
+      d->slicing = false;
+      ctcdec_stream_close(s);
+    }
+  } closer{st, dec};
+  {
+    std::lock_guard<std::mutex> device_lock(g_device_mu);
+    if (be::bind_thread(&err) || dec->w_logits.ensure(2 * (size_t)n_utts * slot, &err) || dec->w_side.ensure(side_bytes, &err) ||
+        be::zero(dec->w_side.p, side_bytes, &err) || be::sync(&err))
+      return fail(CTCDEC_ERR_DEVICE, err);
+  }
+  dec->slicing = true;
+  std::vector<int32_t> frames((size_t)n_utts);
+  std::vector<const void*> ptrs((size_t)n_utts);
+  auto slice_frames = [&](int k, int32_t u) { return (int32_t)std::max<int64_t>(0, std::min<int64_t>(C, (int64_t)utt_frames[u] - (int64_t)k * C)); };
+  // slice k of every utterance -> half (k & 1) of the staging buffer, utterance u at u * slot: runs of utterances that follow
+  // each other in host memory with one length (a [B, T, V] array) go over in ONE two-dimensional copy
+  auto copy_slice = [&](int k, std::string* e) -> int {
+    char* half = (char*)dec->w_logits.p + (size_t)(k & 1) * (size_t)n_utts * slot;
+    for (int32_t u = 0; u < n_utts;) {
+      const int32_t f = slice_frames(k, u);
+      int32_t v = u + 1;
+      const size_t pitch = (size_t)utt_frames[u] * row_bytes;
+      while (v < n_utts && utt_frames[v] == utt_frames[u] && (const char*)utt_logits[v] == (const char*)utt_logits[u] + (size_t)(v - u) * pitch) ++v;
+      if (f > 0 && be::h2d_2d_overlapped(half + (size_t)u * slot, slot, (const char*)utt_logits[u] + (size_t)k * slot, pitch,
+                                         (size_t)f * row_bytes, (size_t)(v - u), e))
+        return -1;
+      u = v;
+    }
+    return 0;
+  };
+  const bool trace = getenv("CTCDEC_SLICE_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[ctcdec host] time-sliced ingest: %d utterances, %d slices of %lld frames\n", n_utts, n_slices, (long long)C);
+  if (copy_slice(0, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  ctcdec_result* res = nullptr;
+  for (int k = 0; k < n_slices; ++k) {
+    const bool last = k == n_slices - 1;
+    char* half = (char*)dec->w_logits.p + (size_t)(k & 1) * (size_t)n_utts * slot;
+    for (int32_t u = 0; u < n_utts; ++u) {
+      frames[(size_t)u] = slice_frames(k, u);
+      ptrs[(size_t)u] = half + (size_t)u * slot;
+    }
+    std::vector<int32_t> ff((size_t)n_utts);
+    for (int32_t u = 0; u < n_utts; ++u) ff[(size_t)u] = (int32_t)st->frames[(size_t)u];
+    StreamIn sin;
+    sin.first_frame = ff.data();
+    sin.beams = nullptr;
+    sin.beam_off = st->imp_off.data();
+    sin.text_blob = st->imp_blob.data();
+    sin.fold = last ? 1 : 0;
+    sin.eos = last ? 1 : 0;
+    const AfterLaunch next = [&, k](std::string* e) -> int { return copy_slice(k + 1, e); };
+    res = nullptr;
+    rc = decode_impl(dec, ptrs.data(), frames.data(), n_utts, dtype, /*is_device=*/1, p,
+                     st->start_states.empty() ? nullptr : st->start_states.data(), &sin, &res, st, /*want_result=*/last,
+                     last ? nullptr : &next);
+    if (rc != CTCDEC_OK) return rc;
+    if (!last) ctcdec_result_free(res);
+  }
+  // The probability test (decoder.py:760) is about the whole utterance: the sliced decode stands when no slice was read as
+  // probabilities AND the utterance's own mean row sum is safely not 1 (the slices' sums carry float32 noise of < 1e-2 per row:
+  // 0.05 is far outside it and far inside what logits give) -- else the batch is decoded again in one piece.
+  std::vector<unsigned char> side(side_bytes, 0);
+  {
+    std::lock_guard<std::mutex> device_lock(g_device_mu);
+    if (be::bind_thread(&err) || be::d2h(side.data(), dec->w_side.p, side_bytes, &err)) {
+      ctcdec_result_free(res);
+      return fail(CTCDEC_ERR_DEVICE, err);
+    }
+  }
+  const uint32_t* seen = (const uint32_t*)side.data();
+  const double* sums = (const double*)(side.data() + side_off);
+  for (int32_t u = 0; u < n_utts; ++u) {
+    const double mean = utt_frames[u] > 0 ? sums[u] / (double)utt_frames[u] : NAN;
+    if (seen[u] == 3u || (std::isfinite(mean) && fabs(mean - 1.0) <= 0.05)) {
+      if (trace) fprintf(stderr, "[ctcdec host] time-sliced ingest: probability-like rows, decoding in one piece\n");
+      ctcdec_result_free(res);
+      return 1;
+    }
+  }
+  *out = res;
+  return CTCDEC_OK;
+}
+
 int ctcdec_stream_frames(const ctcdec_stream* st, int64_t* frames_out) {
   if (!st || !frames_out) return fail(CTCDEC_ERR_ARG, "bad arguments");
   for (int32_t u = 0; u < st->n; ++u) frames_out[u] = st->frames[(size_t)u];
@@ -1487,6 +1638,8 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   pa.row_base = 0;
   pa.pass = 0;
   pa.slow_rows = (uint32_t*)dec->w_slow.p;
+  pa.utt_side = nullptr;
+  pa.utt_sum = nullptr;
   pa.rows_aligned16 = (((uintptr_t)ptrs[0]) & 15u) == 0 ? 1 : 0;
   pa.rows_aligned4 = (((uintptr_t)ptrs[0]) & 3u) == 0 ? 1 : 0;
   if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);

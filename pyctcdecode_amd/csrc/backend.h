@@ -26,6 +26,9 @@ int d2h(void* dst, const void* src, size_t bytes, std::string* err);
 int d2d(void* dst, const void* src, size_t bytes, std::string* err);
 int zero(void* dst, size_t bytes, std::string* err);
 int sync(std::string* err);
+// `height` rows of `width` bytes, host (pitch spitch) -> device (pitch dpitch), on the COPY stream (its own non-blocking stream:
+// the kernels queued on the decode stream keep running while the host waits here). Returns when the copy has landed.
+int h2d_2d_overlapped(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, std::string* err);
 // streams and events for the chunked pipeline of large batches (api.cpp: decode_pipelined). Every call above and the
 // launches below act on the current stream; stream 0 is the default.
 void use_stream(int idx);
@@ -65,6 +68,9 @@ struct PruneArgs {
   int64_t row_base;      // first row of this launch (utt_row0 and the row-indexed arrays are absolute); n_rows rows follow
   uint32_t* slow_rows;   // [n_rows] scratch, or nullptr: rows (relative to row_base) the 64-rows-per-wave kernel hands to the
                          // per-row one; their count is kept in overflow[3]
+  uint32_t* utt_side;    // [n_utts] or nullptr (time-sliced host ingest, api.cpp): set to 3 when this launch's rows of the utterance
+                         // were classified as probabilities
+  double* utt_sum;       // [n_utts] or nullptr (likewise): the row sums of this launch's rows are added to it
   // set by launch_prune itself:
   int32_t f32_np;        // float32 rows in the reference's own float32 arithmetic (np_f32.h + numpy's summation order): the default;
                          // 0 under CTCDEC_PRUNE_EXP=pk (round 5's packed polynomial, fp64 from there on) / =f64

@@ -124,6 +124,14 @@ int h2d(void* d, const void* s, size_t n, std::string* err) {
   HIP_TRY(hipStreamSynchronize(g_stream));  // the source is caller memory that may be reused
   return 0;
 }
+int h2d_2d_overlapped(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, std::string* err) {
+  hipStream_t copy = g_streams[N_STREAMS - 1];
+  if (height == 0 || width == 0) return 0;
+  if (height == 1 || (dpitch == width && spitch == width)) HIP_TRY(hipMemcpyAsync(d, s, width * height, hipMemcpyHostToDevice, copy));
+  else HIP_TRY(hipMemcpy2DAsync(d, dpitch, s, spitch, width, height, hipMemcpyHostToDevice, copy));
+  HIP_TRY(hipStreamSynchronize(copy));
+  return 0;
+}
 int d2h(void* d, const void* s, size_t n, std::string* err) {
   HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
   HIP_TRY(hipStreamSynchronize(g_stream));
@@ -239,6 +247,8 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
     // (an infinite mean -- rows masked with -inf -- is never close: math.isclose(+-inf, 1) is False.) The window:
     // float32 pairwise sums of rows of ordinary logits are off by < 1e-2; float64 ones by < 1e-12.
     const bool amb = isfinite(mean) && fabs(mean - 1.0) <= (a.dtype == 1 ? 1e-6 : 0.5);
+    // (time-sliced ingest: the reference tests the WHOLE utterance's mean row sum -- the slices' sums are added up for the caller)
+    if (a.utt_sum && r1 > r0) atomicAdd(&a.utt_sum[u], s);
     a.utt_is_prob[u] = amb ? 2u : 0u;
     if (amb) a.overflow[2] = 1u;  // flags[2]: some utterance needs the exact test
   }
@@ -266,6 +276,7 @@ __global__ __launch_bounds__(256) void utt_sniff_exact(PruneArgs a) {
   if (threadIdx.x == 0) {
     const bool is_prob = T > 0 && np_mean_is_one(np_mean_of_sums(a.row_sum + r0, a.dtype, T));
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
+    if (is_prob && a.utt_side) a.utt_side[u] = 3u;  // (time-sliced ingest: a slice was read as probabilities)
     if (is_prob) a.overflow[1] = 1u;  // flags[1]: some utterance needs the probability pass
   }
 }

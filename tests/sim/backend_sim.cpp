@@ -60,6 +60,10 @@ int h2d(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); retur
 int d2h(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int d2d(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int zero(void* d, size_t n, std::string*) { memset(d, 0, n); return 0; }
+int h2d_2d_overlapped(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, std::string*) {
+  for (size_t r = 0; r < height; ++r) memcpy((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+  return 0;
+}
 int sync(std::string*) { return 0; }
 void use_stream(int) {}
 int n_events() { return 80; }
@@ -105,6 +109,9 @@ int launch_prune(const PruneArgs& a, std::string*) {
     const double mean = T > 0 ? np_mean_of_sums(a.row_sum + r0, a.dtype, T) : NAN;
     bool is_prob = np_mean_is_one(mean);
     a.utt_is_prob[u] = is_prob ? 1u : 0u;
+    if (a.utt_side && is_prob) a.utt_side[u] = 3u;
+    if (a.utt_sum)
+      for (int64_t t = 0; t < T; ++t) a.utt_sum[u] += a.row_sum[r0 + t];
     // float32 rows: the reference's arithmetic stays float32 (decoder.py:180-197, 762 on a float32 array: numpy's float32
     // exp / log -- its SIMD kernels, restated in np_f32.h --, a float32 pairwise sum, float32 subtractions) and only the clip
     // against ln(1e-15) widens the result: restated step by step, so that a frame's log-probabilities are the reference's bits.
