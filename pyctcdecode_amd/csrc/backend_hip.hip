@@ -1088,6 +1088,11 @@ __device__ __forceinline__ float dpp_f32(float ident, float v) {
 // v_max3_f32 / v_max_f32_dpp by hand: fmaxf() makes the compiler quiet each operand first (v_max_f32 x, x, x), which doubles
 // the instructions of a maximum over loaded values. NaNs need no care here: a row that holds one is recognised by its sum
 // and handed to the per-row kernel.
+__device__ __forceinline__ float min3_raw(float a, float b, float c) {
+  float o;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+  return o;
+}
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
   float o;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
@@ -1233,17 +1238,16 @@ __device__ __forceinline__ f32x2 np_exp_nonpos_pk_fast(f32x2 t) {
   num = __builtin_elementwise_fma(num, r, (f32x2)(9.999999999980870924916e-01f));
   f32x2 den = __builtin_elementwise_fma((f32x2)(2.159509375685829852307e-02f), r, (f32x2)(-2.742335390411667452936e-01f));
   den = __builtin_elementwise_fma(den, r, (f32x2)(1.0f));
-  // num / den, IEEE-exact: v_rcp_f32 + one Newton step + quotient + one fused correction (den in [0.8, 1.2], num in [0.7, 1.5]:
-  // nothing to scale or fix up; checked against the compiler's division for every reduced argument on this chip:
-  // tools/micro/np_div_check.hip, profiles/r06_np_div_check.txt -- 0 of 2 104 533 978 differ)
+  // num / den, IEEE-exact: v_rcp_f32, quotient, one fused correction (den in [0.8, 1.2], num in [0.7, 1.5]: nothing to scale or
+  // fix up, and the reciprocal's 1 ulp is enough for the correction term). Checked against the compiler's division for EVERY
+  // reduced argument on this chip: tools/micro/np_div_check.hip, profiles/r06_np_div_check.txt -- 0 of 2 104 533 978 differ
+  // (with and without a Newton step on the reciprocal).
   f32x2 y0;
   y0.x = __builtin_amdgcn_rcpf(den.x);
   y0.y = __builtin_amdgcn_rcpf(den.y);
-  const f32x2 e = __builtin_elementwise_fma(-den, y0, (f32x2)(1.0f));
-  const f32x2 y = __builtin_elementwise_fma(e, y0, y0);
-  const f32x2 q0 = num * y;
+  const f32x2 q0 = num * y0;
   const f32x2 rem = __builtin_elementwise_fma(-den, q0, num);
-  const f32x2 p = __builtin_elementwise_fma(rem, y, q0);
+  const f32x2 p = __builtin_elementwise_fma(rem, y0, q0);
   f32x2 v;
   v.x = __uint_as_float(__float_as_uint(p.x) + (__float_as_uint(qm.x) << 23));
   v.y = __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(qm.y) << 23));
@@ -1375,6 +1379,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
   int my_first = 0;
   uint32_t my_cnt = 0;
 
+  // numpy's accumulators over the exchange buffer of row i (NP): lane (leaf, j) adds the elements accumulator j of that leaf
+  // adds, in numpy's order; the leaf sums go to LDS for phase B. The leaves of the first sweep are fetched once per block.
+  int np_off0 = 0, np_len0 = 0;
+  if constexpr (NP) {
+    const int leaf = lane >> 3;
+    if (leaf < a.np_n_leaf) {
+      np_off0 = a.np_leaf[2 * leaf];
+      np_len0 = a.np_leaf[2 * leaf + 1];
+    }
+  }
+  auto np_accumulate = [&](int i) {
+#ifdef CTC_NP_DIAG_NOEXCH
+    if (lane < a.np_n_leaf) np_ls[lane * PF_ROWS + i] = 1.0f;
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int g = lane >> 3, j = lane & 7;
+    const int nl = a.np_n_leaf;
+    for (int base = 0; base < nl; base += 8) {
+      const int leaf = base + g;
+      const bool mine = leaf < nl;
+      int off = np_off0, len = np_len0;
+      if (base > 0) {
+        off = len = 0;
+        if (mine) {
+          off = a.np_leaf[2 * leaf];
+          len = a.np_leaf[2 * leaf + 1];
+        }
+      }
+      float res = 0.f;
+      if (len == 128 && (off & 127) == 0) {  // (the usual leaf: sixteen terms per accumulator, constant offsets from one address)
+        const float* q = np_rb + np_pad(off) + j;
+        float t0 = q[0], t1 = q[8], t2 = q[16], t3 = q[24], t4 = q[32], t5 = q[40], t6 = q[48], t7 = q[56];
+        float t8 = q[64], t9 = q[72], t10 = q[80], t11 = q[88], t12 = q[96], t13 = q[104], t14 = q[112], t15 = q[120];
+        float rr = t0 + t1;
+        rr = rr + t2; rr = rr + t3; rr = rr + t4; rr = rr + t5; rr = rr + t6; rr = rr + t7; rr = rr + t8;
+        rr = rr + t9; rr = rr + t10; rr = rr + t11; rr = rr + t12; rr = rr + t13; rr = rr + t14; rr = rr + t15;
+        res = rr;
+      } else if (len >= 8) {
+        const int body = len - (len & 7);
+        float rr = np_rb[np_pad(off + j)];
+        for (int t = 8; t < body; t += 8) rr = rr + np_rb[np_pad(off + t + j)];
+        res = rr;
+      }
+      // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) inside the group of eight lanes: additions commute, an xor butterfly is that tree
+      res = res + dpp_f32<0xB1, 0xf>(0.f, res);   // quad_perm [1, 0, 3, 2]
+      res = res + dpp_f32<0x4E, 0xf>(0.f, res);   // quad_perm [2, 3, 0, 1]
+      res = res + dpp_f32<0x141, 0xf>(0.f, res);  // row_half_mirror (both quads hold their sums in every lane by now)
+      if ((len & 7) != 0 || len < 8) {  // leftovers (and leaves shorter than eight: a plain loop from 0), one by one
+        const int body = len >= 8 ? len - (len & 7) : 0;
+        if (len < 8) res = 0.f;
+        for (int t = body; t < len; ++t) res = res + np_rb[np_pad(off + t)];
+      }
+      if (mine && j == 0) np_ls[leaf * PF_ROWS + i] = res;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the next row's exponentials go to the same buffer)
+  };
+
   auto phase_a = [&](int i, const Raw(&raw)[NL]) -> uint32_t {
     float4 r[NC];
     widen(raw, r);
@@ -1412,7 +1476,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
         if constexpr (AL) {
-          if (n4 == NL * 64 || in_row(k)) lo = fminf(fminf(lo, fminf(r[k].x, r[k].y)), fminf(r[k].z, r[k].w));
+          if (n4 == NL * 64 || in_row(k)) lo = min3_raw(min3_raw(lo, r[k].x, r[k].y), r[k].z, r[k].w);
         } else {
           const int e0 = (k * 64 + lane) * 4;
           lo = fminf(lo, fminf(fminf(e0 < V ? r[k].x : lo, e0 + 1 < V ? r[k].y : lo), fminf(e0 + 2 < V ? r[k].z : lo, e0 + 3 < V ? r[k].w : lo)));
@@ -1422,67 +1486,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
     }
     if (clean) {
       if constexpr (NP) {
-        // numpy's float32 exp of every label, in place; through the exchange buffer; numpy's accumulators
+        // numpy's float32 exp of every label, in place, into the exchange buffer; their sum in any order for the screen (the
+        // exact one -- numpy's accumulators, np_accumulate below -- is taken AFTER the screen: the wave issues in order, so the
+        // screen's work stands between the LDS writes here and the reads there instead of a wait)
+        f32x2 approx = (f32x2)(0.f);
+        const f32x2 mm2 = (f32x2)(m);
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-          float4 e;
-#ifdef CTC_NP_SCALAR
-          e.x = np_exp_nonpos_dev(r[k].x - m);
-          e.y = np_exp_nonpos_dev(r[k].y - m);
-          e.z = np_exp_nonpos_dev(r[k].z - m);
-          e.w = np_exp_nonpos_dev(r[k].w - m);
+#ifdef CTC_NP_DIAG_PKEXP  // diagnostics only (what the exact exponentials cost): round 5's polynomial in their place
+          const f32x2 e01 = exp_nonpos_f32x2m((f32x2){r[k].x, r[k].y} - mm2), e23 = exp_nonpos_f32x2m((f32x2){r[k].z, r[k].w} - mm2);
 #else
-          const f32x2 mm2 = (f32x2)(m);
           const f32x2 e01 = np_exp_nonpos_pk_fast((f32x2){r[k].x, r[k].y} - mm2), e23 = np_exp_nonpos_pk_fast((f32x2){r[k].z, r[k].w} - mm2);
-          e = make_float4(e01.x, e01.y, e23.x, e23.y);
 #endif
-          *(float4*)(np_rb + np_pad((k * 64 + lane) * 4)) = e;
+          bool inside = true;  // (labels past the row's end hold -inf: garbage here, never read by the leaves, kept out of the screen's sum)
+          if constexpr (AL) inside = n4 == NL * 64 || in_row(k);
+          else inside = (k * 64 + lane) * 4 + 3 < V;
+          if (inside) approx += e01 + e23;
+#ifndef CTC_NP_DIAG_NOEXCH
+          *(float4*)(np_rb + np_pad((k * 64 + lane) * 4)) = make_float4(e01.x, e01.y, e23.x, e23.y);
+#endif
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int g = lane >> 3, j = lane & 7;
-        const int nl = a.np_n_leaf;
-        float part = 0.f;
-        for (int base = 0; base < nl; base += 8) {
-          const int leaf = base + g;
-          const bool mine = leaf < nl;
-          int off = 0, len = 0;
-          if (mine) {
-            off = a.np_leaf[2 * leaf];
-            len = a.np_leaf[2 * leaf + 1];
-          }
-          float res = 0.f;
-          if (len == 128 && (off & 127) == 0) {  // (the usual leaf: sixteen terms per accumulator, constant offsets from one address)
-            const float* q = np_rb + np_pad(off) + j;
-            float t0 = q[0], t1 = q[8], t2 = q[16], t3 = q[24], t4 = q[32], t5 = q[40], t6 = q[48], t7 = q[56];
-            float t8 = q[64], t9 = q[72], t10 = q[80], t11 = q[88], t12 = q[96], t13 = q[104], t14 = q[112], t15 = q[120];
-            float rr = t0 + t1;
-            rr = rr + t2; rr = rr + t3; rr = rr + t4; rr = rr + t5; rr = rr + t6; rr = rr + t7; rr = rr + t8;
-            rr = rr + t9; rr = rr + t10; rr = rr + t11; rr = rr + t12; rr = rr + t13; rr = rr + t14; rr = rr + t15;
-            res = rr;
-          } else if (len >= 8) {
-            const int body = len - (len & 7);
-            float rr = np_rb[np_pad(off + j)];
-            for (int i = 8; i < body; i += 8) rr = rr + np_rb[np_pad(off + i + j)];
-            res = rr;
-          }
-          // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) inside the group of eight lanes: additions commute, an xor butterfly is that tree
-          res = res + dpp_f32<0xB1, 0xf>(0.f, res);   // quad_perm [1, 0, 3, 2]
-          res = res + dpp_f32<0x4E, 0xf>(0.f, res);   // quad_perm [2, 3, 0, 1]
-          res = res + dpp_f32<0x141, 0xf>(0.f, res);  // row_half_mirror (both quads hold their sums in every lane by now)
-          if ((len & 7) != 0 || len < 8) {  // leftovers (and leaves shorter than eight: a plain loop from 0), one by one
-            const int body = len >= 8 ? len - (len & 7) : 0;
-            if (len < 8) res = 0.f;
-            for (int i = body; i < len; ++i) res = res + np_rb[np_pad(off + i)];
-          }
-          if (mine && j == 0) {
-            np_ls[leaf * PF_ROWS + i] = res;
-            part += res;
-          }
-        }
-        s = (double)wave_sum_f32(part);  // (any order: only the screen below looks at it; phase B combines the leaves exactly)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        s = (double)wave_sum_f32(approx.x + approx.y);
       } else {
       // sum of exponentials: float32 per lane (16 terms), fp64 across the lanes
       f32x2 acc = (f32x2)(0.f);
@@ -1545,6 +1569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
           }
         }
       }
+      if constexpr (NP) np_accumulate(i);
     }
     if (lane == i) {
       my_m = m;
