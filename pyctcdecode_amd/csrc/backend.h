@@ -77,6 +77,7 @@ struct PruneArgs {
   const uint8_t* np_prog;  // frame_prune_fast, f32_np: the pairwise tree over the leaf sums of one row as (dst, src) pairs
   const uint16_t* np_leaf; // ... and the leaves as (offset, length) pairs; np_n_leaf of them
   int32_t np_n_leaf;
+  int32_t np_uniform8;     // 1, 2, 4 or 8 leaves of 128 labels each (V = 128 .. 1024 in powers of two): the tree is walked in registers
 };
 int launch_prune(const PruneArgs& a, std::string* err);
 // decoder.py:760 in the input dtype and numpy's summation order for the utterances pass 0 marked ambiguous

@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
   uint16_t* tabs = (uint16_t*)(smem + PF_LDS_IDS + PF_LDS_X);  // [SMALL_SET_SLOTS][64 rows]
   static_assert(!NP || DT == 0, "numpy-order sums: float32 rows");
   float* np_ls = (float*)(smem + PF_LDS);        // NP: [n_leaf][64 rows] leaf sums
-  float* np_rb = pf_np_rowbuf_bytes(NC) <= PF_TABS_BYTES ? (float*)tabs : (float*)(smem + PF_LDS + (size_t)a.np_n_leaf * PF_ROWS * 4);
+  float* np_rb = pf_np_rowbuf_bytes(NC) <= PF_TABS_BYTES ? (float*)tabs : (float*)(smem + PF_LDS + (a.np_uniform8 ? 0 : (size_t)a.np_n_leaf * PF_ROWS * 4));
   constexpr bool WIDE = DT == 0;                 // float32 rows
   constexpr int NL = WIDE ? NC : NC / 2;         // 16-byte loads per lane and row
   constexpr int PER = WIDE ? 4 : 8;              // labels per load
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
   };
 
   // what phase A leaves for row i, in lane i
-  float my_m = 0.f, my_rs = 0.f;
+  float my_m = 0.f, my_rs = 0.f, my_s32 = 1.0f;
   double my_s = 1.0;
   int my_first = 0;
   uint32_t my_cnt = 0;
@@ -1433,7 +1433,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
         if (len < 8) res = 0.f;
         for (int t = body; t < len; ++t) res = res + np_rb[np_pad(off + t)];
       }
-      if (mine && j == 0) np_ls[leaf * PF_ROWS + i] = res;
+      if (a.np_uniform8) {
+        // up to eight leaves of 128, one per group of eight lanes (every lane of a group holds its leaf's sum; groups without a
+        // leaf hold 0): numpy's tree ((S0+S1)+(S2+S3)) + ((S4+S5)+(S6+S7)) by three cross-lane additions -- partners 8 lanes
+        // apart inside a row of sixteen, then rows 0 -> 1 and 2 -> 3, then row 1 -> row 3 (additions commute) -- and the row's
+        // sum lands in lane i's register: no leaf sums in LDS, which buys the block's two further waves per CU back
+        float t = res + dpp_f32<0x128, 0xf>(0.f, res);  // row_ror:8
+        t = t + dpp_f32<0x142, 0xa>(0.f, t);              // row_bcast:15 into rows 1 and 3
+        t = t + dpp_f32<0x143, 0xc>(0.f, t);              // row_bcast:31 into rows 2 and 3
+        const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 63));
+        if (lane == i) my_s32 = total;
+      } else if (mine && j == 0) {
+        np_ls[leaf * PF_ROWS + i] = res;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();  // (the next row's exponentials go to the same buffer)
@@ -1643,11 +1655,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
       float l32 = 0.f;
       if constexpr (NP) {
         // this row's leaf sums, combined along numpy's recursion (every lane walks the same (dst, src) list on its own column)
-        for (int q = 0; q + 1 < a.np_n_leaf; ++q) {
-          const int dst = a.np_prog[2 * q], src = a.np_prog[2 * q + 1];
-          np_ls[dst * PF_ROWS + lane] = np_ls[dst * PF_ROWS + lane] + np_ls[src * PF_ROWS + lane];
+        float s32 = my_s32;  // (up to eight leaves of 128: combined in registers by phase A)
+        if (!a.np_uniform8) {
+          for (int q = 0; q + 1 < a.np_n_leaf; ++q) {
+            const int dst = a.np_prog[2 * q], src = a.np_prog[2 * q + 1];
+            np_ls[dst * PF_ROWS + lane] = np_ls[dst * PF_ROWS + lane] + np_ls[src * PF_ROWS + lane];
+          }
+          s32 = np_ls[lane];
         }
-        l32 = np_log_f32(np_ls[lane]);
+        l32 = np_log_f32(s32);
       } else {
         lse = log_ge1(s);
       }
@@ -1709,7 +1725,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
 // numpy's pairwise recursion over a row of V elements (np_sum.h): its leaves (offset, length) left to right and the additions
 // that combine their sums, as (dst, src) leaf indices -- the result of a node lives where its leftmost leaf's did
 struct NpPlan {
-  int V = -1, n_leaf = 0;
+  int V = -1, n_leaf = 0, uniform8 = 0;
   uint16_t* d_leaf = nullptr;
   uint8_t* d_prog = nullptr;
 };
@@ -1752,6 +1768,9 @@ static int np_plan_for(int V, NpPlan** out, std::string* err) {
   HIP_TRY(hipMemcpy(p.d_leaf, leaf.data(), leaf.size() * 2, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(p.d_prog, prog.data(), prog.size(), hipMemcpyHostToDevice));
   p.n_leaf = (int)leaf.size() / 2;
+  p.uniform8 = (p.n_leaf == 1 || p.n_leaf == 2 || p.n_leaf == 4 || p.n_leaf == 8) ? 1 : 0;
+  for (size_t k = 0; k < leaf.size(); k += 2)
+    if (leaf[k + 1] != 128 || (leaf[k] & 127) != 0) p.uniform8 = 0;
   p.V = V;
   *out = &p;
   return 0;
@@ -1766,6 +1785,7 @@ int launch_prune(const PruneArgs& a_in, std::string* err) {
     a.np_prog = nullptr;
     a.np_leaf = nullptr;
     a.np_n_leaf = 0;
+    a.np_uniform8 = 0;
   }
   if (a.pass == 0) {
     g_timing_valid = false;
@@ -1814,7 +1834,8 @@ int launch_prune(const PruneArgs& a_in, std::string* err) {
         a.np_leaf = plan->d_leaf;
         a.np_prog = plan->d_prog;
         a.np_n_leaf = plan->n_leaf;
-        flds += pf_np_extra_lds(nc <= 8 ? nc : (nc <= 12 ? 12 : 16), plan->n_leaf);
+        a.np_uniform8 = plan->uniform8;
+        flds += pf_np_extra_lds(nc <= 8 ? nc : (nc <= 12 ? 12 : 16), plan->uniform8 ? 0 : plan->n_leaf);
       }
       // rows the fast kernel hands over: the per-row float4 kernel where it applies (<= 1024 aligned labels), else the generic one
 #define CTC_LAUNCH_FAST_K(KERN)                                                                                           \

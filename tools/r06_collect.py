@@ -51,6 +51,14 @@ def main():
     out["batch_4096"] = d
     with open(os.path.join(SRC, "library.sha256")) as fh:
         out["binary_sha16"] = fh.read().split()[0][:16]  # of pyctcdecode_amd/libctcdec.so on the box that measured
+    # ... and the hash of what that library was built from (sources, headers, command lines, compiler versions): a rebuild of the same
+    # tree under another root is the same kernels in another file (run this script on the tree that was measured)
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from pyctcdecode_amd import build as _b
+
+    out["source_sha16"] = _b.source_tag()[:16]
     with open(os.path.join(DST, "r06_pmc_hbm_traffic.json"), "w") as fo:
         json.dump(out, fo, indent=1)
     sq, sq2 = load("sq1_4096.json"), load("sq2_4096.json")
