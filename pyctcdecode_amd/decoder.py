@@ -1050,11 +1050,15 @@ class BeamSearchDecoderCTC:
         hotwords: Optional[Iterable[str]] = None,
         hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
     ) -> List[str]:
-        """decoder.py:895-945. ``pool`` is ignored (one device launch decodes the whole batch)."""
+        """decoder.py:895-945. One device launch decodes the whole batch: a multiprocessing pool is ignored. A
+        `pyctcdecode_amd.parallel.DevicePool` -- one worker process per GPU -- shards the batch over its devices."""
         if getattr(logits_list, "ndim", 0) != 3:
             logits_list = list(logits_list)
         if len(logits_list) == 0:
             return []
+        if type(pool).__name__ == "DevicePool":
+            return pool.decode_batch(logits_list, beam_width=beam_width, beam_prune_logp=beam_prune_logp,
+                                     token_min_logp=token_min_logp, hotwords=hotwords, hotword_weight=hotword_weight)
         params = self._params(beam_width, beam_prune_logp, token_min_logp, True, hotword_weight, 1)
         params.texts_only = 1  # (the kernels write the texts themselves: no emission lists to copy back and replay)
         res = self._run(logits_list, params, hotwords)
@@ -1095,12 +1099,16 @@ class BeamSearchDecoderCTC:
         hotwords: Optional[Iterable[str]] = None,
         hotword_weight: float = DEFAULT_HOTWORD_WEIGHT,
     ) -> List[List[OutputBeam]]:
-        """decoder.py:801-857. Beams carry ``last_lm_state=None`` like the reference's mp-safe beams."""
+        """decoder.py:801-857. Beams carry ``last_lm_state=None`` like the reference's mp-safe beams. ``pool``: see decode_batch."""
         logits_list = list(logits_list)
         for logits in logits_list:
             self._check_logits_dimension(logits)
         if len(logits_list) == 0:
             return []
+        if type(pool).__name__ == "DevicePool":
+            return pool.decode_beams_batch(logits_list, beam_width=beam_width, beam_prune_logp=beam_prune_logp,
+                                           token_min_logp=token_min_logp, prune_history=prune_history, hotwords=hotwords,
+                                           hotword_weight=hotword_weight)
         params = self._params(beam_width, beam_prune_logp, token_min_logp, prune_history, hotword_weight, 0)
         res = self._run(logits_list, params, hotwords)
         try:

@@ -153,3 +153,144 @@ def decode_beams_batch_sharded(decoder, logits_list, group=None, **kwargs) -> Li
     lo, hi = shard_bounds_by_frames(_frames_of(logits_list), world, rank)
     local = decoder.decode_beams_batch(None, logits_list[lo:hi], **kwargs)
     return gather_objects(local, group=group)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DevicePool: what `pool` is to the reference's decode_batch(pool, ...) -- ONE caller process, several devices
+# ---------------------------------------------------------------------------------------------------------------------
+def _device_worker(conn, device: int, decoder_dir: str, library: Optional[str]) -> None:
+    """One worker process = one GPU (the native library binds one device per process): loads the saved decoder on its device and
+    serves (method, logits, kwargs) requests until it is told to stop."""
+    import os
+    import traceback
+
+    os.environ["CTCDEC_DEVICE"] = str(device)
+    try:
+        from pyctcdecode_amd import _binding as B
+
+        if library:  # (tests: the CPU simulator build of the device code)
+            B._LIB = B.Library(library)
+        from pyctcdecode_amd.decoder import BeamSearchDecoderCTC
+
+        dec = BeamSearchDecoderCTC.load_from_dir(decoder_dir)
+        conn.send(("ready", device))
+    except Exception:  # the parent raises what went wrong
+        conn.send(("error", traceback.format_exc()))
+        return
+    while True:
+        msg = conn.recv()
+        if msg is None:
+            return
+        method, logits, kwargs = msg
+        try:
+            if method == "decode_batch":
+                conn.send(("ok", dec.decode_batch(None, logits, **kwargs)))
+            else:
+                beams = dec.decode_beams_batch(None, logits, **kwargs)
+                conn.send(("ok", [[(b.text, list(b.text_frames), b.logit_score, b.lm_score) for b in bs] for bs in beams]))
+        except Exception as e:  # noqa: BLE001 (sent back as the exception the direct call would have raised)
+            conn.send(("raise", e if isinstance(e, (ValueError, NotImplementedError, TypeError)) else RuntimeError(traceback.format_exc())))
+
+
+class DevicePool:
+    """`pool` for `decode_batch(pool, logits_list, ...)` / `decode_beams_batch(pool, ...)` on a node with several GPUs
+    (decoder.py:895-945, 801-857: the reference scales inside ONE process by handing a multiprocessing pool in). The native
+    library binds one device per process, so a DevicePool is one spawned worker process per device, each holding a replica of
+    the decoder (saved with save_to_dir, loaded in the worker); a call shards the batch over the workers by frames (contiguous
+    slices: results come back in input order), each worker decodes its slice in one launch on its own GPU, and the parent
+    collects the results -- no exchange between devices during the decode. The matrices travel to the workers as host arrays
+    through pipes: this is the convenience form for callers that hold numpy logits; a pipeline that already has its logits on
+    the GPUs runs one process per GPU and `decode_batch_sharded` (above).
+
+        pool = DevicePool(decoder, devices=[0, 1, 2, 3])
+        texts = decoder.decode_batch(pool, logits_list)
+        pool.close()
+    """
+
+    def __init__(self, decoder, devices: Optional[Sequence[int]] = None, library: Optional[str] = None, start_timeout: float = 300.0):
+        import multiprocessing as mp
+        import tempfile
+
+        if devices is None:
+            import torch
+
+            devices = list(range(max(1, torch.cuda.device_count())))
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("a DevicePool needs at least one device")
+        self._dir = tempfile.TemporaryDirectory(prefix="ctcdec_pool_")
+        decoder.save_to_dir(self._dir.name)
+        ctx = mp.get_context("spawn")  # (never fork a process that holds a HIP context)
+        self._workers = []
+        for d in self.devices:
+            parent, child = ctx.Pipe()
+            p = ctx.Process(target=_device_worker, args=(child, d, self._dir.name, library), daemon=True)
+            p.start()
+            child.close()
+            self._workers.append((p, parent))
+        for p, conn in self._workers:
+            if not conn.poll(start_timeout):
+                self.close()
+                raise RuntimeError("a DevicePool worker did not come up within %.0f s" % start_timeout)
+            kind, what = conn.recv()
+            if kind != "ready":
+                self.close()
+                raise RuntimeError("a DevicePool worker failed to start:\n%s" % what)
+
+    def _map(self, method: str, logits_list, kwargs):
+        logits_list = [np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x) for x in logits_list]
+        n, world = len(logits_list), len(self._workers)
+        spans = [shard_bounds_by_frames(_frames_of(logits_list), world, r) for r in range(world)]
+        busy = []
+        for (lo, hi), (_p, conn) in zip(spans, self._workers):
+            if hi > lo:
+                conn.send((method, logits_list[lo:hi], kwargs))
+                busy.append(conn)
+        out: List[Any] = []
+        err = None
+        for conn in busy:  # (every answer is collected before anything is raised: the workers stay in step)
+            kind, what = conn.recv()
+            if kind == "ok":
+                out.extend(what)
+            elif err is None:
+                err = what
+        if err is not None:
+            raise err
+        assert len(out) == n
+        return out
+
+    def decode_batch(self, logits_list, **kwargs) -> List[str]:
+        return self._map("decode_batch", logits_list, kwargs)
+
+    def decode_beams_batch(self, logits_list, **kwargs):
+        from pyctcdecode_amd.decoder import OutputBeam
+
+        return [[OutputBeam(t, None, f, lg, lm) for t, f, lg, lm in beams] for beams in self._map("decode_beams_batch", logits_list, kwargs)]
+
+    def close(self) -> None:
+        for p, conn in getattr(self, "_workers", []):
+            try:
+                conn.send(None)
+            except (OSError, BrokenPipeError):
+                pass
+        for p, conn in getattr(self, "_workers", []):
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+            conn.close()
+        self._workers = []
+        if getattr(self, "_dir", None) is not None:
+            self._dir.cleanup()
+            self._dir = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
