@@ -141,10 +141,13 @@ struct BeamArgs {
                                // its wave (100 MHz real-time counter), HW_ID | XCC_ID << 32, frames}
   int32_t prio_mode;           // issue priority of a wave among the waves of its SIMD (beam_wave_hip.hip, WaveGpuCtx::frame_done):
                                // 0 left alone; 1 + k: rotated every 2^k frames; 32: by the frames it still has to decode against
-                               // the launch's average (`progress`)
+                               // the launch's average (`progress`); 33: likewise, each remaining frame weighed by what a frame of
+                               // this utterance is expected to cost (`block_weight`: survivors per frame against the launch's mean)
   unsigned long long* progress;  // [1] frames decoded so far by all waves of the launch (prio_mode 32; zeroed by launch_beam)
   unsigned long long total_frames;
   float inv_n_utts;
+  const float* block_weight;   // [n_utts] (prio_mode 33) expected cost of a frame of the utterance workgroup b decodes, relative to
+                               // the launch's mean (utt_weigh / utt_place, backend_hip.hip); the same kernels write `order`
 };
 int launch_beam(const BeamArgs& a, std::string* err);
 // Will launch_beam run the wave kernel on these arguments (given payload lines)? THE kernel-selection rule, shared by the

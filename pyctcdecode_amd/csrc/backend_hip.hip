@@ -234,15 +234,26 @@ __global__ __launch_bounds__(64) void utt_sniff(PruneArgs a) {
   const int lane = threadIdx.x;
   const int64_t r0 = a.utt_row0[u], r1 = a.utt_row0[u + 1];
   double s = 0.0, c = 0.0;
-  for (int64_t r = r0 + lane; r < r1; r += 64) {
-    s += a.row_sum[r];
-    c += (double)a.surv_cnt[r];
+  {  // four rows per lane and trip: the loads of a trip are in flight together (one row per trip: 58 us of load latency for 4096 x 1000 rows)
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int64_t r = r0 + lane; r < r1; r += 256) {
+      const bool h1 = r + 64 < r1, h2 = r + 128 < r1, h3 = r + 192 < r1;
+      const double x0 = a.row_sum[r], x1 = h1 ? a.row_sum[r + 64] : 0.0, x2 = h2 ? a.row_sum[r + 128] : 0.0, x3 = h3 ? a.row_sum[r + 192] : 0.0;
+      const uint32_t n0 = a.surv_cnt[r], n1 = h1 ? a.surv_cnt[r + 64] : 0u, n2 = h2 ? a.surv_cnt[r + 128] : 0u, n3 = h3 ? a.surv_cnt[r + 192] : 0u;
+      s += x0; s1 += x1; s2 += x2; s3 += x3;
+      c0 += n0; c1 += n1; c2 += n2; c3 += n3;
+    }
+    s = (s + s1) + (s2 + s3);
+    c = (double)c0 + (double)c1 + (double)c2 + (double)c3;
   }
   s = wave_sum(s);
   c = wave_sum(c);
   if (lane == 0) {
     // (the survivors of all rows, summed: what a small batch's beam kernel is chosen by; saturating, only read for small batches)
-    if (a.pass == 0) atomicAdd(&a.overflow[4], (uint32_t)fmin(c, 1.0e9));
+    // (only small batches read it, and 4096 atomics on one address are 40 us of a 55-us kernel: launches of more than 1024
+    //  utterances leave it alone)
+    if (a.pass == 0 && a.n_utts <= 1024) atomicAdd(&a.overflow[4], (uint32_t)fmin(c, 1.0e9));
     double mean = r1 > r0 ? s / (double)(r1 - r0) : NAN;
     // (an infinite mean -- rows masked with -inf -- is never close: math.isclose(+-inf, 1) is False.) The window:
     // float32 pairwise sums of rows of ordinary logits are off by < 1e-2; float64 ones by < 1e-12.
@@ -1253,6 +1264,41 @@ __device__ __forceinline__ f32x2 np_exp_nonpos_pk_fast(f32x2 t) {
   v.y = __uint_as_float(__float_as_uint(p.y) + (__float_as_uint(qm.y) << 23));
   return v;
 }
+// The same for N pairs at once, stage by stage. Why: on gfx950 a vector instruction that reads the result of the packed-float32
+// instruction right before it costs a wait state, and the compiler -- which schedules one exponential's chain after the other --
+// pays it with an `s_nop` between nearly every two instructions of the sixteen chains of a row (round 6: 102 of the 340
+// instructions of a row's exponentials were s_nop, and a wave issues one instruction per ~5 cycles whatever it is). Written
+// stage-major with the scheduler fenced between stages, consecutive instructions belong to different chains and nothing waits.
+// Same operations per element, in the same order: the values are np_exp_nonpos_pk_fast's bit for bit.
+template <int N>
+__device__ __forceinline__ void np_exp_nonpos_pk_fast_n(const f32x2 (&t)[N], f32x2 (&v)[N]) {
+#pragma clang fp contract(off)
+  const f32x2 magic = (f32x2)(12582912.0f);
+  f32x2 q[N], qm[N], r[N], num[N], den[N], y0[N], q0[N];
+#define CTC_STAGE(expr)                      \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) { expr; } \
+  __builtin_amdgcn_sched_barrier(0);
+  CTC_STAGE(q[i] = t[i] * (f32x2)(1.442695040888963407359924681001892137f))
+  CTC_STAGE(qm[i] = q[i] + magic)
+  CTC_STAGE(q[i] = qm[i] - magic)
+  CTC_STAGE(r[i] = __builtin_elementwise_fma(q[i], (f32x2)(-6.93145752e-1f), t[i]))
+  CTC_STAGE(r[i] = __builtin_elementwise_fma(q[i], (f32x2)(-1.42860677e-6f), r[i]))
+  CTC_STAGE(num[i] = __builtin_elementwise_fma((f32x2)(5.082762527590693718096e-04f), r[i], (f32x2)(6.757896990527504603057e-03f));
+            den[i] = __builtin_elementwise_fma((f32x2)(2.159509375685829852307e-02f), r[i], (f32x2)(-2.742335390411667452936e-01f)))
+  CTC_STAGE(num[i] = __builtin_elementwise_fma(num[i], r[i], (f32x2)(5.114512081637298353406e-02f));
+            den[i] = __builtin_elementwise_fma(den[i], r[i], (f32x2)(1.0f)))
+  CTC_STAGE(num[i] = __builtin_elementwise_fma(num[i], r[i], (f32x2)(2.473615434895520810817e-01f));
+            y0[i].x = __builtin_amdgcn_rcpf(den[i].x))
+  CTC_STAGE(num[i] = __builtin_elementwise_fma(num[i], r[i], (f32x2)(7.257664613233124478488e-01f));
+            y0[i].y = __builtin_amdgcn_rcpf(den[i].y))
+  CTC_STAGE(num[i] = __builtin_elementwise_fma(num[i], r[i], (f32x2)(9.999999999980870924916e-01f)))
+  CTC_STAGE(q0[i] = num[i] * y0[i])
+  CTC_STAGE(num[i] = __builtin_elementwise_fma(-den[i], q0[i], num[i]))  // (the remainder)
+  CTC_STAGE(q0[i] = __builtin_elementwise_fma(num[i], y0[i], q0[i]))
+  CTC_STAGE(v[i].x = __uint_as_float(__float_as_uint(q0[i].x) + (__float_as_uint(qm[i].x) << 23));
+            v[i].y = __uint_as_float(__float_as_uint(q0[i].y) + (__float_as_uint(qm[i].y) << 23)))
+#undef CTC_STAGE
+}
 // index of element i of a row in the exchange buffer: eight floats of padding per 128 (the accumulator lanes of different
 // leaves then read different banks)
 __device__ __forceinline__ int np_pad(int i) { return i + ((i >> 7) << 3); }
@@ -1503,12 +1549,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 
         // screen's work stands between the LDS writes here and the reads there instead of a wait)
         f32x2 approx = (f32x2)(0.f);
         const f32x2 mm2 = (f32x2)(m);
+#if !defined(CTC_NP_DIAG_PKEXP) && !defined(CTC_NP_CHAINWISE)
+        // (the exponentials of CTC_NP_IL groups of four labels at a time, stage by stage: np_exp_nonpos_pk_fast_n)
+#ifndef CTC_NP_IL
+#define CTC_NP_IL 2
+#endif
+        constexpr int IL = NC % CTC_NP_IL == 0 ? CTC_NP_IL : 1;
+        f32x2 ex[NC][2];
+#pragma unroll
+        for (int k0 = 0; k0 < NC; k0 += IL) {
+          f32x2 tin[2 * IL], tout[2 * IL];
+#pragma unroll
+          for (int j = 0; j < IL; ++j) {
+            tin[2 * j] = (f32x2){r[k0 + j].x, r[k0 + j].y} - mm2;
+            tin[2 * j + 1] = (f32x2){r[k0 + j].z, r[k0 + j].w} - mm2;
+          }
+          np_exp_nonpos_pk_fast_n<2 * IL>(tin, tout);
+#pragma unroll
+          for (int j = 0; j < IL; ++j) {
+            ex[k0 + j][0] = tout[2 * j];
+            ex[k0 + j][1] = tout[2 * j + 1];
+          }
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
 #ifdef CTC_NP_DIAG_PKEXP  // diagnostics only (what the exact exponentials cost): round 5's polynomial in their place
           const f32x2 e01 = exp_nonpos_f32x2m((f32x2){r[k].x, r[k].y} - mm2), e23 = exp_nonpos_f32x2m((f32x2){r[k].z, r[k].w} - mm2);
-#else
+#elif defined(CTC_NP_CHAINWISE)
           const f32x2 e01 = np_exp_nonpos_pk_fast((f32x2){r[k].x, r[k].y} - mm2), e23 = np_exp_nonpos_pk_fast((f32x2){r[k].z, r[k].w} - mm2);
+#else
+          const f32x2 e01 = ex[k][0], e23 = ex[k][1];
 #endif
           bool inside = true;  // (labels past the row's end hold -inf: garbage here, never read by the leaves, kept out of the screen's sum)
           if constexpr (AL) inside = n4 == NL * 64 || in_row(k);
@@ -2009,6 +2080,100 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
   for (uint32_t k = (uint32_t)lane; k < len; k += 64u) a.text_pool[base + k] = scratch[pos + k];
 }
 
+// ---- what a frame of each utterance will cost, before the wave kernel decodes it (round 6) -------------------------------------
+// The wave kernel's launch lasts as long as its slowest wave, and the slowest waves are the utterances with the most survivors
+// per frame (more candidate passes per frame: CTCDEC_WAVE_TIMES, profiles/r06_wave_times.txt). The prune stage has just counted
+// them, so the beam launch can know its heavy utterances BEFORE it starts instead of noticing them fall behind:
+//   utt_weigh  (one wave per utterance): cost per frame = WEIGH_C0 + survivors per frame (a frame costs about the same again as
+//              its ~5 survivors' passes whatever they are: the phase tables), and the utterance's total;
+//   utt_place  (one workgroup): ranks the totals by counting and deals the utterances out -- heaviest first, so that they are the
+//              oldest waves of their SIMDs (the arbiter's tie-break), and in a snake over the SIMD count, so that each SIMD's four
+//              waves add up to about the same work -- and leaves every workgroup the relative weight of its utterance
+//              (BeamArgs::block_weight), by which WaveGpuCtx::frame_done scales the frames it still has to decode.
+// Which utterance a workgroup decodes never changes what it computes (tests/test_full_occupancy.py runs both orders).
+constexpr float WEIGH_C0 = 4.0f;
+constexpr int PLACE_MAX = 8192;  // utterances utt_place ranks (LDS: 4 bytes each); larger launches keep their order
+struct WeighArgs {
+  const int64_t* utt_row0;
+  const uint32_t* surv_cnt;
+  int32_t n_utts;
+  float* total;        // [n_utts] WEIGH_C0 * frames + survivors
+  float* per_frame;    // [n_utts]
+  float* sum;          // [1] of per_frame (zeroed by the caller)
+  const int32_t* given_order;  // or nullptr: utt_place decides
+  int32_t* order;      // [n_utts] out (given_order == nullptr)
+  float* block_weight; // [n_utts] out
+  int32_t simds;
+};
+__global__ __launch_bounds__(64) void utt_weigh(WeighArgs a) {
+  const int u = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int64_t r0 = a.utt_row0[u], r1 = a.utt_row0[u + 1];
+  double c = 0.0;
+  {
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;  // (four loads in flight per trip)
+    for (int64_t r = r0 + lane; r < r1; r += 256) {
+      const uint32_t n0 = a.surv_cnt[r], n1 = r + 64 < r1 ? a.surv_cnt[r + 64] : 0u, n2 = r + 128 < r1 ? a.surv_cnt[r + 128] : 0u,
+                     n3 = r + 192 < r1 ? a.surv_cnt[r + 192] : 0u;
+      c0 += n0; c1 += n1; c2 += n2; c3 += n3;
+    }
+    c = (double)c0 + (double)c1 + (double)c2 + (double)c3;
+  }
+  c = wave_sum(c);
+  if (lane == 0) {
+    const float T = (float)(r1 - r0);
+    const float tot = WEIGH_C0 * T + (float)c;
+    const float pf = T > 0.f ? tot / T : WEIGH_C0;
+    a.total[u] = tot;
+    a.per_frame[u] = pf;  // (their sum is taken by utt_place's workgroups themselves: thousands of atomics on one address cost 40 us)
+  }
+}
+// 16 utterances per workgroup of 256 threads: sixteen lanes share the count of one utterance's rank (a single workgroup ranking
+// 4096 totals took 0.7 ms -- most of what the placement saved)
+constexpr int PLACE_PER_BLOCK = 16;
+__global__ __launch_bounds__(256) void utt_place(WeighArgs a) {
+  __shared__ float w[PLACE_MAX];
+  __shared__ float part_sum[4];
+  const int n = a.n_utts;
+  {  // the launch's mean cost per frame (every workgroup adds the per-utterance values up itself)
+    float acc = 0.f;
+    for (int v = threadIdx.x; v < n; v += blockDim.x) acc += a.per_frame[v];
+    acc = (float)wave_sum((double)acc);
+    if ((threadIdx.x & 63) == 0) part_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+  }
+  const float scale = (float)n / ((part_sum[0] + part_sum[1]) + (part_sum[2] + part_sum[3]));
+  const int u = blockIdx.x * PLACE_PER_BLOCK + (threadIdx.x >> 4), part = threadIdx.x & 15;
+  if (a.given_order || n > PLACE_MAX || a.simds < 0) {  // weights only
+    if (part == 0 && u < n) {
+      const int v = a.given_order ? a.given_order[u] : u;
+      a.block_weight[u] = a.per_frame[v] * scale;
+    }
+    return;
+  }
+  for (int v = threadIdx.x; v < n; v += blockDim.x) w[v] = a.total[v];
+  __syncthreads();
+  const int uu = u < n ? u : 0;
+  const float mine = w[uu];
+  int rank = 0;
+  for (int v = part; v < n; v += 16) {
+    const float x = w[v];
+    rank += (x > mine || (x == mine && v < uu)) ? 1 : 0;
+  }
+  rank += __shfl_xor(rank, 1, 64);
+  rank += __shfl_xor(rank, 2, 64);
+  rank += __shfl_xor(rank, 4, 64);
+  rank += __shfl_xor(rank, 8, 64);
+  if (part == 0 && u < n) {
+    const int S = a.simds;
+    const int g = rank / S, k = rank - g * S;
+    const int len = n - g * S < S ? n - g * S : S;
+    const int b = g * S + ((g & 1) ? len - 1 - k : k);
+    a.order[b] = u;
+    a.block_weight[b] = a.per_frame[u] * scale;
+  }
+}
+
 static int g_last_kernel = 0;  // 1: wave kernel, 2: workgroup kernel
 int last_beam_kernel() { return g_last_kernel; }
 
@@ -2050,20 +2215,55 @@ int launch_beam(const BeamArgs& a, std::string* err) {
     // waves of a launch end 12.3 .. 16.1 ms (5th .. 95th percentile) apart without it, 13.6 .. 15.2 ms with it; batches of one
     // wave per SIMD or fewer are unaffected).
     const char* pr = getenv("CTCDEC_WAVE_PRIO");
-    wa.prio_mode = 32;
+    // (round 6, second half) "weigh" = dyn with every remaining frame weighed by the utterance's survivors per frame, and the
+    // heavy utterances dispatched first / dealt out evenly over the SIMDs (utt_weigh, utt_place): the default for launches of
+    // more than one wave per SIMD
+    wa.prio_mode = a.n_utts > 4 * g_cus ? 33 : 32;
     if (pr && pr[0] == 'n') wa.prio_mode = 0;
     if (pr && pr[0] == 'r') wa.prio_mode = 1 + (pr[1] && pr[2] && pr[3] ? atoi(pr + 3) & 15 : 5);
+    if (pr && pr[0] == 'd') wa.prio_mode = 32;
+    if (pr && pr[0] == 'w') wa.prio_mode = 33;
     wa.progress = nullptr;
     wa.total_frames = 0;
     wa.inv_n_utts = 0.f;
-    if (wa.prio_mode == 32) {
+    wa.block_weight = nullptr;
+    const bool dump_times = getenv("CTCDEC_WAVE_TIMES") != nullptr;
+    if (wa.prio_mode >= 32 || dump_times) {
       static unsigned long long* g_progress = nullptr;
-      if (!g_progress) HIP_TRY(hipMalloc((void**)&g_progress, 8));
-      HIP_TRY(hipMemsetAsync(g_progress, 0, 8, g_stream));
+      if (!g_progress) HIP_TRY(hipMalloc((void**)&g_progress, 16));
+      HIP_TRY(hipMemsetAsync(g_progress, 0, 16, g_stream));
       wa.progress = g_progress;
       wa.total_frames = (unsigned long long)a.total_rows;
       wa.inv_n_utts = 1.0f / (float)a.n_utts;
       if (a.total_rows >= (1ll << 32)) wa.prio_mode = 0;
+      if (wa.prio_mode == 33 || dump_times) {  // (a dump carries the weights along)
+        static float* g_weigh = nullptr;  // total | per_frame | block_weight | order
+        static int g_weigh_cap = 0;
+        if (a.n_utts > g_weigh_cap) {
+          if (g_weigh) HIP_TRY(hipFree(g_weigh));
+          g_weigh = nullptr;
+          g_weigh_cap = 0;
+          HIP_TRY(hipMalloc((void**)&g_weigh, (size_t)a.n_utts * 16));
+          g_weigh_cap = a.n_utts;
+        }
+        WeighArgs w;
+        w.utt_row0 = a.utt_row0;
+        w.surv_cnt = a.surv_cnt;
+        w.n_utts = a.n_utts;
+        w.total = g_weigh;
+        w.per_frame = g_weigh + (size_t)a.n_utts;
+        w.block_weight = g_weigh + (size_t)a.n_utts * 2;
+        w.order = (int32_t*)(g_weigh + (size_t)a.n_utts * 3);
+        w.sum = (float*)(g_progress + 1);
+        const bool keep_order = a.order != nullptr || getenv("CTCDEC_NO_PLACE") != nullptr || a.n_utts > PLACE_MAX || wa.prio_mode != 33;
+        w.given_order = a.order;               // (a ragged multi-round launch keeps its longest-first order)
+        w.simds = keep_order ? -1 : 4 * g_cus;  // -1: weights only
+        hipLaunchKernelGGL(utt_weigh, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, w);
+        hipLaunchKernelGGL(utt_place, dim3((unsigned)((a.n_utts + PLACE_PER_BLOCK - 1) / PLACE_PER_BLOCK)), dim3(256), 0, g_stream, w);
+        HIP_TRY(hipGetLastError());
+        wa.block_weight = w.block_weight;
+        if (!keep_order) wa.order = w.order;
+      }
     }
     // diagnostics: when and where each wave ran -> CTCDEC_WAVE_TIMES=<file> (n_utts x 4 uint64; synchronous)
     const char* wt = getenv("CTCDEC_WAVE_TIMES");
@@ -2080,6 +2280,14 @@ int launch_beam(const BeamArgs& a, std::string* err) {
       if (FILE* f = fopen(wt, "wb")) {
         fwrite(h.data(), 8, h.size(), f);
         fclose(f);
+      }
+      if (wa.block_weight) {  // <file>.w: the relative weight of every workgroup's utterance (float32)
+        std::vector<float> bw((size_t)a.n_utts);
+        HIP_TRY(hipMemcpy(bw.data(), wa.block_weight, bw.size() * 4, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen((std::string(wt) + ".w").c_str(), "wb")) {
+          fwrite(bw.data(), 4, bw.size(), f);
+          fclose(f);
+        }
       }
     }
     g_last_kernel = 1;

@@ -67,7 +67,16 @@ struct WaveGpuCtx {
     if (lane == 0) old = atomicAdd(k->progress, (unsigned long long)units);
     const uint32_t done = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old) + units;  // (launches of < 2^32 frames)
     const float avg_left = (float)((uint32_t)k->total_frames - done) * k->inv_n_utts;
-    const float d = (float)(T - t2) - avg_left;  // > 0: behind the launch's average
+    // (mode 33: a frame of this utterance costs `weight` average frames -- its survivors per frame, counted by the prune stage)
+    const float weight = mode == 33 ? k->block_weight[blockIdx.x] : 1.f;
+    const float d = (float)(T - t2) * weight - avg_left;  // > 0: behind the launch's average
+    set_prio(d > 24.f ? 3u : d > 0.f ? 2u : d > -24.f ? 1u : 0u);
+  }
+  // mode 33: the heavy utterances run at the top level from their first frame on (they are known before the launch)
+  __device__ __forceinline__ void start_prio(int T) {
+    const KernArgs k = fresh();
+    if (k->prio_mode != 33) return;
+    const float d = (float)T * k->block_weight[blockIdx.x] - (float)(uint32_t)k->total_frames * k->inv_n_utts;
     set_prio(d > 24.f ? 3u : d > 0.f ? 2u : d > -24.f ? 1u : 0u);
   }
   // launch constants, re-read where they are used (scalar loads; see WaveDecoder::tab)
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BW <= 100 ? 
     rec[0] = wall_clock64();
     rec[3] = (unsigned long long)io.T | ((unsigned long long)(uint32_t)u << 32);
   }
+  ctx.start_prio(io.T);
   WaveDecoder<WaveGpuCtx, BW, ORD, PROF> dec(ctx, view, io);
   dec.run();
   if (rec && threadIdx.x == 0) {

@@ -39,6 +39,23 @@ def summarise(path):
         sel = order[idx_in == r]
         print("    %d. wave of its SIMD to finish: mean end %.2f ms, mean slot %.2f" % (r + 1, end[sel].mean() / 1e3, wave_id[sel].mean()))
     blk = np.arange(n)
+    import os
+    if os.path.exists(path + ".w"):  # the weights utt_weigh gave the workgroups' utterances (relative cost of a frame)
+        w = np.fromfile(path + ".w", dtype=np.float32)[:n].astype(np.float64)
+        print("  weights: min %.3f  p5 %.3f  median %.3f  p95 %.3f  max %.3f" % tuple(np.percentile(w, [0, 5, 50, 95, 100])))
+        for s_ in sorted(set(wave_id.tolist())):
+            m = wave_id == s_
+            if m.sum() > 8:
+                c = np.corrcoef(w[m], dur[m])[0, 1]
+                k, b0 = np.polyfit(w[m], dur[m] / 1e3, 1)
+                print("    slot %d: corr(weight, lifetime) %.3f; lifetime = %.2f ms + %.2f ms x weight  => cost at weight 0 / cost at the mean weight = %.2f" % (s_, c, b0, k, b0 / (b0 + k)))
+        top = np.argsort(-end)[:12]
+        print("  the last 12 waves to end: end ms / weight / slot / block: " + "  ".join("%.2f/%.3f/%d/%d" % (end[i] / 1e3, w[i], wave_id[i], i) for i in top))
+        # do block b and block b + 1024 share a SIMD?
+        S = 1024
+        if n >= 2 * S:
+            same = (grp[:S] == grp[S:2 * S]).mean()
+            print("  blocks b and b + %d on the same SIMD: %.1f %%" % (S, 100 * same))
     print("  by dispatch order (block index / 1024): " + "  ".join("%d: end %.2f ms, slot %.2f" % (k, end[(blk >> 10) == k].mean() / 1e3, wave_id[(blk >> 10) == k].mean()) for k in range((n + 1023) >> 10)))
 
 
