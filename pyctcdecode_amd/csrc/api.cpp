@@ -1103,6 +1103,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   ba.total_rows = R;
   // Small batches choose their beam kernel by the input (backend: wave_kernel_chosen): their beam stage is launched when the
   // prune stage has reported -- like a resident stream's --, one small read-back between the two stages.
+  auto t_setup = t_begin, t_queued = t_begin, t_flags = t_begin;  // (CTCDEC_HOST_TIMING: where the host side of a call goes)
   const bool by_input = !rs && be::beam_kernel_depends_on_input(ba);
   const bool late_beam = rs != nullptr || by_input;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1161,9 +1162,12 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     // (a resident stream's beam kernel advances persistent state: it is launched once, when the prune stage has
     // reported -- and so is a small batch's, whose kernel is chosen by what the prune stage counted; everything else
     // launches it right behind the first prune pass and redoes it in the two rare cases)
+    t_setup = std::chrono::steady_clock::now();
     if (be::launch_prune(pa, &err) || (!late_beam && run_beam())) return fail(CTCDEC_ERR_DEVICE, err);
+    t_queued = std::chrono::steady_clock::now();
     uint32_t flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (be::d2h(flags, dec->w_flags.p, 32, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    t_flags = std::chrono::steady_clock::now();
     uint32_t surv_total = flags[4];  // (pass 0 counted every row as logits)
     if (flags[2]) {  // rows that sum to about 1: the reference's test in its own dtype and summation order (decoder.py:760)
       if (be::launch_sniff_exact(pa, &err) || be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
@@ -1267,9 +1271,14 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     res->beam_kernel = be::last_beam_kernel();
     if (dec->profile && be::d2h(dec->prof, dec->w_prof.p, N_PROF * 8, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     res->ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (host_timing)
-      fprintf(stderr, "[ctcdec host] texts from the device: %llu bytes, native call %.3f ms (kernels %.3f + %.3f)\n", heads[1], res->ms[2],
-              res->ms[0], res->ms[1]);
+    if (host_timing) {
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+      };
+      fprintf(stderr, "[ctcdec host] texts from the device: %llu bytes, native call %.3f ms (kernels %.3f + %.3f): setup %.3f, launches %.3f, "
+                      "wait for the kernels %.3f, counters back %.3f, records + texts back %.3f\n", heads[1], res->ms[2], res->ms[0], res->ms[1],
+              ms(t_begin, t_setup), ms(t_setup, t_queued), ms(t_queued, t_flags), ms(t_flags, t_kernel), ms(t_kernel, std::chrono::steady_clock::now()));
+    }
     *out = res.release();
     return CTCDEC_OK;
   }

@@ -1320,7 +1320,10 @@ __host__ __device__ inline size_t pf_np_extra_lds(int nc, int n_leaf) {
 // where every lane combines its row's along the recursion's tree (a.np_prog). A frame's log-probabilities are then the
 // reference's bits, and the decode of float32 logits equals the reference's to the last bit of every score.
 template <int NC, int DT, bool AL = true, bool NP = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? 3 : 1, NC <= 4 ? 3 : 8))) void frame_prune_fast(PruneArgs a) {
+#ifndef CTC_PF_WAVES
+#define CTC_PF_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NC <= 4 ? CTC_PF_WAVES : 1, NC <= 4 ? CTC_PF_WAVES : 8))) void frame_prune_fast(PruneArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int64_t row_lo = a.row_base + (int64_t)blockIdx.x * PF_ROWS;
@@ -2092,6 +2095,7 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
 //              (BeamArgs::block_weight), by which WaveGpuCtx::frame_done scales the frames it still has to decode.
 // Which utterance a workgroup decodes never changes what it computes (tests/test_full_occupancy.py runs both orders).
 constexpr float WEIGH_C0 = 4.0f;
+constexpr float WEIGH_GAIN = 4.0f;  // (the regression of a wave's natural lifetime on this weight has slope ~3: profiles/r06_weigh_*.txt)
 constexpr int PLACE_MAX = 8192;  // utterances utt_place ranks (LDS: 4 bytes each); larger launches keep their order
 struct WeighArgs {
   const int64_t* utt_row0;
@@ -2104,6 +2108,8 @@ struct WeighArgs {
   int32_t* order;      // [n_utts] out (given_order == nullptr)
   float* block_weight; // [n_utts] out
   int32_t simds;
+  float gain;          // block_weight = 1 + gain * (relative cost per frame - 1)
+  int32_t snake;       // odd generations dealt out in reverse
 };
 __global__ __launch_bounds__(64) void utt_weigh(WeighArgs a) {
   const int u = blockIdx.x;
@@ -2147,7 +2153,7 @@ __global__ __launch_bounds__(256) void utt_place(WeighArgs a) {
   if (a.given_order || n > PLACE_MAX || a.simds < 0) {  // weights only
     if (part == 0 && u < n) {
       const int v = a.given_order ? a.given_order[u] : u;
-      a.block_weight[u] = a.per_frame[v] * scale;
+      a.block_weight[u] = 1.f + a.gain * (a.per_frame[v] * scale - 1.f);
     }
     return;
   }
@@ -2168,9 +2174,10 @@ __global__ __launch_bounds__(256) void utt_place(WeighArgs a) {
     const int S = a.simds;
     const int g = rank / S, k = rank - g * S;
     const int len = n - g * S < S ? n - g * S : S;
-    const int b = g * S + ((g & 1) ? len - 1 - k : k);
+    int b = g * S + (((g & 1) && a.snake == 1) ? len - 1 - k : k);
+    if (a.snake == 2) b = n - 1 - rank;  // (diagnostics: lightest first)
     a.order[b] = u;
-    a.block_weight[b] = a.per_frame[u] * scale;
+    a.block_weight[b] = 1.f + a.gain * (a.per_frame[u] * scale - 1.f);
   }
 }
 
@@ -2258,6 +2265,8 @@ int launch_beam(const BeamArgs& a, std::string* err) {
         const bool keep_order = a.order != nullptr || getenv("CTCDEC_NO_PLACE") != nullptr || a.n_utts > PLACE_MAX || wa.prio_mode != 33;
         w.given_order = a.order;               // (a ragged multi-round launch keeps its longest-first order)
         w.simds = keep_order ? -1 : 4 * g_cus;  // -1: weights only
+        w.gain = getenv("CTCDEC_WEIGH_GAIN") ? (float)atof(getenv("CTCDEC_WEIGH_GAIN")) : WEIGH_GAIN;
+        w.snake = getenv("CTCDEC_PLACE_SNAKE") ? atoi(getenv("CTCDEC_PLACE_SNAKE")) : 1;
         hipLaunchKernelGGL(utt_weigh, dim3((unsigned)a.n_utts), dim3(64), 0, g_stream, w);
         hipLaunchKernelGGL(utt_place, dim3((unsigned)((a.n_utts + PLACE_PER_BLOCK - 1) / PLACE_PER_BLOCK)), dim3(256), 0, g_stream, w);
         HIP_TRY(hipGetLastError());

@@ -138,3 +138,38 @@ def test_sim_batch_bookkeeping_of_the_occupancy_test(assets, sim_library, monkey
     picked, n_beams = _run_group(dec, key, cases, assets, fillers, 24, lambda x: x, monkeypatch, n_sample=4)
     assert picked == 1 and n_beams >= 24
     assert len(set(_places(8, 2144))) == 8 and _places(3, 24)[:2] == [0, 23]
+
+
+@pytest.mark.gpu
+def test_hip_placement_by_weight_keeps_every_result(assets, filler_host, monkeypatch):  # noqa: F811
+    """Round 6: a launch of more than one wave per SIMD weighs its utterances (survivors per frame), dispatches the heavy ones
+    first in a snake over the SIMDs and runs them at a higher issue priority (utt_weigh / utt_place, backend_hip.hip). Which
+    workgroup decodes an utterance and at which priority must not show in any beam: an equal-length batch (ragged ones keep their
+    longest-first order) under the default, under CTCDEC_WAVE_PRIO=dyn (no weights, no placement), with the weights but without
+    the placement, and dealt out lightest first."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    lm, labels, hot = assets
+    n = 4 * 256 + 70  # (> one wave per SIMD: the placement is on)
+    dev = torch.from_numpy(filler_host[:, :90]).cuda()  # [N_DISTINCT, 90, V]
+    batch = torch.stack([dev[(7 * u) % N_DISTINCT].roll(u % 5, 0) for u in range(n)])  # (distinct survivor counts per utterance)
+    dec = build_ctcdecoder(labels, lm.path)
+    monkeypatch.setenv("CTCDEC_BEAM_KERNEL", "wave")
+    kw = dict(beam_width=100, hotwords=hot)
+    kw_beams = dict(kw, prune_history=True)  # (what decode_batch decodes with: decoder.py:944 -> decode())
+    runs = {}
+    for name, env in (("default", {}), ("dyn", {"CTCDEC_WAVE_PRIO": "dyn"}), ("noplace", {"CTCDEC_NO_PLACE": "1"}),
+                      ("lightest first", {"CTCDEC_PLACE_SNAKE": "2", "CTCDEC_WEIGH_GAIN": "8"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        runs[name] = [_as_tuples(b) for b in dec.decode_beams_batch(None, batch, **kw_beams)]
+        assert dec.last_beam_kernel == 1
+        for k in env:
+            monkeypatch.delenv(k)
+    texts = dec.decode_batch(None, batch, **kw)
+    assert texts == [b[0][0] for b in runs["default"]]
+    for name, got in runs.items():
+        differ = [u for u in range(n) if got[u] != runs["default"][u]]
+        assert not differ, "%s: %d utterances differ from the default launch, first %d" % (name, len(differ), differ[0])

@@ -1,0 +1,28 @@
+"""Diagnostics (GPU box): the host side of the bench step -- decode_batch on the resident headline batch, wall time against the
+native call and its kernels (CTCDEC_HOST_TIMING breaks the native call down).   python tools/host_step.py [batch]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from pyctcdecode_amd import build_ctcdecoder  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+lm, labels, hot = bench.build_assets(os.path.join(ROOT, "bench_cache"), 20000, 60000)
+xs = bench.make_batch(lm, labels, 0, n, 1000, 6.0, 32)
+dec = build_ctcdecoder(labels, lm.path)
+dev = torch.from_numpy(xs).cuda()
+torch.cuda.synchronize()
+os.environ["CTCDEC_HOST_TIMING"] = "1"
+for it in range(5):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    texts = dec.decode_batch(None, dev, beam_width=bench.BEAM, hotwords=hot)
+    t1 = time.perf_counter()
+    ms = dec.last_timing_ms
+    print("step %d: wall %.3f ms, native %.3f ms, kernels %.3f + %.3f = %.3f ms; python outside the native call %.3f ms" % (
+        it, 1e3 * (t1 - t0), ms[2], ms[0], ms[1], ms[0] + ms[1], 1e3 * (t1 - t0) - ms[2]), flush=True)
