@@ -80,7 +80,7 @@ def main():
                  ("np_div_check.txt", "r06_np_div_check.txt"), ("wave_times.txt", "r06_wave_times.txt"),
                  ("bench.json", "r06_bench.json"), ("bench.log", "r06_bench.log"), ("pytest_gpu.log", "r06_pytest_gpu.log"),
                  ("phases512.log", "r06_phases_512.log"), ("phases4096.log", "r06_phases_4096.log"),
-                 ("fuzz_hip.log", "r06_fuzz_hip.log")):
+                 ("fuzz_hip.log", "r06_fuzz_hip.log"), ("host_step.log", "r06_host_step.log")):
         if os.path.exists(os.path.join(SRC, a)):
             shutil.copy(os.path.join(SRC, a), os.path.join(DST, b))
     print(open(os.path.join(DST, "r06_kernel_stats.txt")).read())

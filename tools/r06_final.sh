@@ -36,11 +36,12 @@ ls -la $out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rates tools/micro/valu_rates.hip 2>/dev/null && timeout 300 /tmp/valu_rates > $out/micro_valu_rates.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/mem_latency tools/micro/mem_latency.hip 2>/dev/null && timeout 120 /tmp/mem_latency > $out/micro_mem_latency.txt 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/np_div_check tools/micro/np_div_check.hip 2>/dev/null && timeout 300 /tmp/np_div_check > $out/np_div_check.txt 2>&1
-for p in none dyn; do
+for p in none dyn weigh; do
   CTCDEC_WAVE_PRIO=$p CTCDEC_WAVE_TIMES=$out/wt_$p.bin timeout 300 python bench.py $B --steps 2 --warmup 1 > /dev/null 2> $out/wt_$p.log
 done
-python tools/wave_times.py $out/wt_none.bin $out/wt_dyn.bin > $out/wave_times.txt 2>&1
-rm -f $out/wt_none.bin $out/wt_dyn.bin
+python tools/wave_times.py $out/wt_none.bin $out/wt_dyn.bin $out/wt_weigh.bin > $out/wave_times.txt 2>&1
+rm -f $out/wt_none.bin* $out/wt_dyn.bin* $out/wt_weigh.bin*
+timeout 300 python tools/host_step.py 2>&1 | grep -E "^step|ctcdec host" > $out/host_step.log
 tail -3 $out/np_div_check.txt
 # the memory paths of the CU (texture addresser / L1 / L2 request counters), one group per pass
 timeout 400 bash tools/pmc_run.sh $out ta_4096 "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum GRBM_GUI_ACTIVE" --no-shard --no-peaky --no-extras
