@@ -202,6 +202,8 @@ struct ctcdec_decoder {
   uint32_t max_label_bytes = 1;
   bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
   HostBuf h_tok, h_out, h_small;
+  HostBuf h_stage;          // page-locked staging of a call's small uploads (upload_staged): they go over without the host waiting
+  size_t stage_used = 0;
   bool profile = false;
   unsigned long long prof[N_PROF] = {0};
   ~ctcdec_decoder() {
@@ -220,8 +222,25 @@ struct ctcdec_decoder {
     h_tok.drop();
     h_out.drop();
     h_small.drop();
+    h_stage.drop();
   }
 };
+
+// A call's small per-utterance tables (pointers, row offsets, arena offsets, start states): copied into the decoder's page-locked
+// staging block and sent on the decode stream WITHOUT waiting -- the kernels that read them are queued behind them on the same
+// stream. (upload() waits for every copy: six round trips of ~20 us in front of the first kernel of a call.) The block is reused
+// from the start by the next call, which begins after this one's last synchronisation. Falls back to upload() when it is full.
+template <class T>
+static int upload_staged(ctcdec_decoder* dec, DevBuf& b, const std::vector<T>& v, std::string* err) {
+  const size_t bytes = sizeof(T) * v.size();
+  const size_t room = dec->h_stage.p ? dec->h_stage.cap - dec->stage_used : 0;
+  if (bytes == 0 || bytes > room) return upload(b, v, err);
+  if (b.ensure(std::max<size_t>(bytes, 16), err)) return -1;
+  char* src = (char*)dec->h_stage.p + dec->stage_used;
+  memcpy(src, v.data(), bytes);
+  dec->stage_used += (bytes + 63) & ~(size_t)63;
+  return be::h2d_async(b.p, src, bytes, err);
+}
 
 struct ctcdec_result {
   std::vector<std::vector<BeamResult>> utts;
@@ -820,6 +839,9 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   if (sync_tables(dec, &err)) return fail(CTCDEC_ERR_DEVICE, err);
   const int V = (int)dec->alpha.labels.size();
   const size_t esz = dtype == CTCDEC_F32 ? 4 : dtype == CTCDEC_F64 ? 8 : 2;
+  // staging for this call's small uploads (every earlier call has synchronised: nothing is in flight from the block)
+  dec->stage_used = 0;
+  if (dec->h_stage.ensure((size_t)n_utts * (64 + sizeof(LmState) * (size_t)K) + 4096, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
   std::vector<int64_t> row0((size_t)n_utts + 1, 0);
   for (int32_t u = 0; u < n_utts; ++u) {
@@ -850,7 +872,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       u = v;
     }
   }
-  if (upload(dec->w_ptrs, ptrs, &err) || upload(dec->w_row0, row0, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+  if (upload_staged(dec, dec->w_ptrs, ptrs, &err) || upload_staged(dec, dec->w_row0, row0, &err)) return fail(CTCDEC_ERR_DEVICE, err);
 
   // survivor bound: rows are normalised log-probabilities, so at most floor(e^-min) labels pass
   int max_surv = V;
@@ -955,8 +977,8 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     }
   }
   if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
-      (!rs && (dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_eoff, eoff, &err))) ||
-      upload(dec->w_toff, toff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
+      (!rs && (dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload_staged(dec, dec->w_eoff, eoff, &err))) ||
+      upload_staged(dec, dec->w_toff, toff, &err) || dec->w_out.ensure((size_t)n_utts * n_best * sizeof(OutBeam), &err) ||
       dec->w_nout.ensure((size_t)n_utts * 4, &err) || dec->w_status.ensure((size_t)n_utts * 4, &err) ||
       dec->w_tok.ensure((size_t)std::max<unsigned long long>(tok_cap, 1) * sizeof(EmitNode), &err) ||
       dec->w_head.ensure(16, &err) || dec->w_cold.ensure((size_t)n_utts * 2 * COLD_STRIDE * sizeof(ColdRec), &err))
@@ -987,7 +1009,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
         }
       }
     }
-    if (upload(dec->w_start, st, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    if (upload_staged(dec, dec->w_start, st, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     d_start = (const LmState*)dec->w_start.p;
   }
   const size_t xstate_bytes = K > 1 ? (size_t)n_utts * n_best * (size_t)(K - 1) * sizeof(LmState) : 0;
@@ -1051,7 +1073,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     for (int32_t u = 0; u < n_utts; ++u)
       soff[(size_t)u + 1] = soff[(size_t)u] + (((uint64_t)utt_frames[u] + 2) * (uint64_t)(dec->max_label_bytes + 1) + 15) / 16 * 16;
     if (dec->w_tscr.ensure((size_t)soff[(size_t)n_utts] + 16, &err) || dec->w_tpool.ensure((size_t)soff[(size_t)n_utts] + 16, &err) ||
-        upload(dec->w_tsoff, soff, &err))
+        upload_staged(dec, dec->w_tsoff, soff, &err))
       return fail(CTCDEC_ERR_DEVICE, err);
     ba.text_scratch = (uint8_t*)dec->w_tscr.p;
     ba.text_soff = (const uint64_t*)dec->w_tsoff.p;
@@ -1204,9 +1226,14 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
   uint32_t* n_out = (uint32_t*)dec->h_small.p;
   uint32_t* status = n_out + n_utts;
   unsigned long long head = 0;
-  if (be::d2h(n_out, dec->w_nout.p, (size_t)n_utts * 4, &err) ||
-      be::d2h(status, dec->w_status.p, (size_t)n_utts * 4, &err) || be::d2h(&head, dec->w_head.p, 8, &err))
+  // (one wait for the three: the targets are page-locked, `heads` rides in the spare 16 bytes behind the status words)
+  unsigned long long* heads_pinned = (unsigned long long*)(status + n_utts);
+  if (be::d2h_async(n_out, dec->w_nout.p, (size_t)n_utts * 4, &err) ||
+      be::d2h_async(status, dec->w_status.p, (size_t)n_utts * 4, &err) || be::d2h_async(heads_pinned, dec->w_head.p, 16, &err) ||
+      be::sync(&err))
     return fail(CTCDEC_ERR_DEVICE, err);
+  head = heads_pinned[0];
+  bool outgrown_redone = false;
   if (!arenas_full) {
     bool outgrown = false;
     for (int32_t u = 0; u < n_utts; ++u) outgrown = outgrown || (status[u] & (ST_TEXT_OVERFLOW | ST_EMIT_OVERFLOW)) != 0;
@@ -1215,6 +1242,7 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
       if (getenv("CTCDEC_ARENA_TRACE")) fprintf(stderr, "[ctcdec host] node arenas outgrown: beam stage redone with the worst case\n");
       dec->arenas_worst_case = true;
       arenas_full = true;
+      outgrown_redone = true;
       size_arenas(true);
       if (dec->w_text.ensure(toff[(size_t)n_utts] * sizeof(TextNode), &err) ||
           dec->w_emit.ensure(eoff[(size_t)n_utts] * sizeof(EmitNode), &err) || upload(dec->w_toff, toff, &err) ||
@@ -1255,8 +1283,8 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     if (status[u]) return fail(CTCDEC_ERR_INTERNAL, "beam kernel status " + std::to_string(status[u]) +
                                                         " for utterance " + std::to_string(u));
   if (device_texts) {  // one block of text per utterance, written by the kernels
-    unsigned long long heads[2] = {0, 0};
-    if (be::d2h(heads, dec->w_head.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
+    unsigned long long heads[2] = {heads_pinned[0], heads_pinned[1]};  // (read back with the counters above)
+    if (outgrown_redone && be::d2h(heads, dec->w_head.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     res->device_texts = true;
     res->dev_out.resize((size_t)n_utts);
     res->dev_texts.resize((size_t)heads[1]);

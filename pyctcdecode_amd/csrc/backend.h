@@ -38,6 +38,8 @@ int ev_wait(int id, std::string* err);
 int ev_sync(int id, std::string* err);
 double ev_elapsed_ms(int a, int b);
 int d2h_async(void* dst, const void* src, size_t bytes, std::string* err);
+// host -> device on the current stream WITHOUT waiting: `src` is page-locked memory the caller leaves alone until the stream has passed it
+int h2d_async(void* dst, const void* src, size_t bytes, std::string* err);
 int sync_all(std::string* err);
 int cus();  // compute units of the device
 void set_last_timing(double prune_ms, double beam_ms);

@@ -172,6 +172,10 @@ int d2h_async(void* d, const void* s, size_t n, std::string* err) {
   HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, g_stream));
   return 0;
 }
+int h2d_async(void* d, const void* s, size_t n, std::string* err) {
+  HIP_TRY(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, g_stream));
+  return 0;
+}
 int sync_all(std::string* err) {
   for (int k = 0; k < N_STREAMS; ++k) HIP_TRY(hipStreamSynchronize(g_streams[k]));
   return 0;

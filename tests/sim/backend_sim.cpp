@@ -72,6 +72,7 @@ int ev_wait(int, std::string*) { return 0; }
 int ev_sync(int, std::string*) { return 0; }
 double ev_elapsed_ms(int, int) { return 0.0; }
 int d2h_async(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
+int h2d_async(void* d, const void* s, size_t n, std::string*) { memcpy(d, s, n); return 0; }
 int sync_all(std::string*) { return 0; }
 int cus() { return 4; }  // small on purpose: the chunked pipeline is exercised by a few dozen utterances
 void set_last_timing(double, double) {}
