@@ -202,6 +202,7 @@ struct ctcdec_decoder {
   uint32_t max_label_bytes = 1;
   bool arenas_worst_case = false;  // a call has outgrown the usual reservation of the node arenas: reserve the worst case from now on
   HostBuf h_tok, h_out, h_small;
+  int dense_calls = 0;      // calls left that skip the 64-rows-per-wave prune kernel (most rows of a recent call overflowed it)
   HostBuf h_stage;          // page-locked staging of a call's small uploads (upload_staged): they go over without the host waiting
   size_t stage_used = 0;
   bool profile = false;
@@ -1155,6 +1156,11 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     pa.slow_rows = (uint32_t*)dec->w_slow.p;
     pa.utt_side = dec->slicing ? (uint32_t*)dec->w_side.p : nullptr;
     pa.utt_sum = dec->slicing ? (double*)((char*)dec->w_side.p + (((size_t)n_utts * 4 + 15) & ~(size_t)15)) : nullptr;
+    pa.dense_hint = 0;
+    if (dec->dense_calls > 0 && !rs) {
+      pa.dense_hint = 1;
+      if (attempt == 0) --dec->dense_calls;
+    }
     pa.rows_aligned16 = 1;
     pa.rows_aligned4 = 1;
     for (const void* q : ptrs) {
@@ -1191,6 +1197,9 @@ static int decode_impl(ctcdec_decoder* dec, const void* const* utt_logits, const
     if (be::d2h(flags, dec->w_flags.p, 32, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     t_flags = std::chrono::steady_clock::now();
     uint32_t surv_total = flags[4];  // (pass 0 counted every row as logits)
+    // small vocabularies fed flat logits: nearly every row overflows the 64-rows-per-wave kernel's sixteen candidates and is done
+    // again by the per-row kernel -- the next sixteen calls go there directly (then the fast kernel is tried again)
+    if (V <= 128 && R >= 1024 && (uint64_t)flags[3] * 2 > (uint64_t)R) dec->dense_calls = 16;
     if (flags[2]) {  // rows that sum to about 1: the reference's test in its own dtype and summation order (decoder.py:760)
       if (be::launch_sniff_exact(pa, &err) || be::d2h(flags, dec->w_flags.p, 16, &err)) return fail(CTCDEC_ERR_DEVICE, err);
     }
@@ -1677,6 +1686,7 @@ int ctcdec_frame_survivors(ctcdec_decoder* dec, const void* logits, int32_t n_fr
   pa.slow_rows = (uint32_t*)dec->w_slow.p;
   pa.utt_side = nullptr;
   pa.utt_sum = nullptr;
+  pa.dense_hint = 0;
   pa.rows_aligned16 = (((uintptr_t)ptrs[0]) & 15u) == 0 ? 1 : 0;
   pa.rows_aligned4 = (((uintptr_t)ptrs[0]) & 3u) == 0 ? 1 : 0;
   if (be::launch_prune(pa, &err)) return fail(CTCDEC_ERR_DEVICE, err);

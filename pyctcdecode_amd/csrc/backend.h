@@ -73,6 +73,8 @@ struct PruneArgs {
   uint32_t* utt_side;    // [n_utts] or nullptr (time-sliced host ingest, api.cpp): set to 3 when this launch's rows of the utterance
                          // were classified as probabilities
   double* utt_sum;       // [n_utts] or nullptr (likewise): the row sums of this launch's rows are added to it
+  int32_t dense_hint;    // 1: the caller has seen most rows of such input overflow the 64-rows-per-wave kernel (small vocabulary, flat
+                         // logits: every label survives) -- go straight to one wave per row
   // set by launch_prune itself:
   int32_t f32_np;        // float32 rows in the reference's own float32 arithmetic (np_f32.h + numpy's summation order): the default;
                          // 0 under CTCDEC_PRUNE_EXP=pk (round 5's packed polynomial, fp64 from there on) / =f64

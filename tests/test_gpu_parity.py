@@ -279,6 +279,38 @@ def test_hip_config2_full_size_char_nolm_stress():
     check_beams([(o.text, o.text_frames, o.logit_score, o.lm_score) for o in got], exp, what="cfg2", **_tol(x))
 
 
+def test_hip_dense_small_vocabulary_calls_skip_the_rows64_prune_kernel(monkeypatch):
+    """Round 6: a small vocabulary fed flat logits overflows the 64-rows-per-wave prune kernel in nearly every row (every label
+    survives); the caller notices and sends the decoder's next calls straight to one wave per row (PruneArgs::dense_hint). Same
+    survivors either way: the first call (fast kernel + listed rows), the following calls (hinted), a call under
+    CTCDEC_PRUNE_KERNEL=row and one of real-posterior-like rows in between agree beam for beam with what they gave before."""
+    import torch
+
+    from pyctcdecode_amd import build_ctcdecoder
+
+    if _mode() != "n":
+        pytest.skip("the hint is honoured only where both prune kernels give the same bits (the default float32 arithmetic)")
+    dec = build_ctcdecoder(synth.LIBRI_LABELS)
+    flat = [torch.from_numpy(synth.d_flat(2, 300 + u, 160, 29)).cuda() for u in range(8)]  # 1 280 rows, ~25 survivors each
+    tup = lambda out: [[(b.text, tuple(b.text_frames), b.logit_score, b.lm_score) for b in beams] for beams in out]  # noqa: E731
+    first = tup(dec.decode_beams_batch(None, flat, beam_width=32))
+    hinted = tup(dec.decode_beams_batch(None, flat, beam_width=32))
+    assert hinted == first
+    monkeypatch.setenv("CTCDEC_PRUNE_KERNEL", "row")
+    rows = tup(dec.decode_beams_batch(None, flat, beam_width=32))
+    monkeypatch.delenv("CTCDEC_PRUNE_KERNEL")
+    assert rows == first
+    fresh = build_ctcdecoder(synth.LIBRI_LABELS)  # (no hint yet)
+    rng = np.random.default_rng(5)
+    peaky = []
+    for u in range(8):  # rows with one or two survivors: what the fast kernel is for
+        x = rng.normal(size=(200, 29)).astype(np.float32)
+        x[np.arange(200), rng.integers(0, 29, size=200)] += 14.0
+        peaky.append(torch.from_numpy(x).cuda())
+    assert tup(fresh.decode_beams_batch(None, peaky, beam_width=32)) == tup(dec.decode_beams_batch(None, peaky, beam_width=32))
+    assert tup(dec.decode_beams_batch(None, flat, beam_width=32)) == first
+
+
 def test_hip_config3_hf_vocab_lm_full_length():
     """BASELINE config 3 shape (HF Wav2Vec2 char vocab V=32, 4-gram, alpha 0.5 beta 1.0, beam 100):
     a ragged batch incl. one T=1000 utterance against the oracle."""
