@@ -141,7 +141,9 @@ def test_sim_batch_bookkeeping_of_the_occupancy_test(assets, sim_library, monkey
 
 
 @pytest.mark.gpu
-def test_hip_placement_by_weight_keeps_every_result(assets, filler_host, monkeypatch):  # noqa: F811
+@pytest.mark.parametrize("n,frames", [(4 * 256 + 70, 90), (5000, 24), (8192 + 40, 16)],
+                         ids=["one_round", "more_than_one_round", "more_than_the_ranking_holds"])
+def test_hip_placement_by_weight_keeps_every_result(assets, filler_host, monkeypatch, n, frames):  # noqa: F811
     """Round 6: a launch of more than one wave per SIMD weighs its utterances (survivors per frame), dispatches the heavy ones
     first in a snake over the SIMDs and runs them at a higher issue priority (utt_weigh / utt_place, backend_hip.hip). Which
     workgroup decodes an utterance and at which priority must not show in any beam: an equal-length batch (ragged ones keep their
@@ -152,8 +154,9 @@ def test_hip_placement_by_weight_keeps_every_result(assets, filler_host, monkeyp
     from pyctcdecode_amd import build_ctcdecoder
 
     lm, labels, hot = assets
-    n = 4 * 256 + 70  # (> one wave per SIMD: the placement is on)
-    dev = torch.from_numpy(filler_host[:, :90]).cuda()  # [N_DISTINCT, 90, V]
+    # (more than one wave per SIMD: the placement is on; 5 000: more utterances than wave slots; 8 232: more than utt_place ranks --
+    #  weights only, the order stays)
+    dev = torch.from_numpy(filler_host[:, :frames]).cuda()  # [N_DISTINCT, frames, V]
     batch = torch.stack([dev[(7 * u) % N_DISTINCT].roll(u % 5, 0) for u in range(n)])  # (distinct survivor counts per utterance)
     dec = build_ctcdecoder(labels, lm.path)
     monkeypatch.setenv("CTCDEC_BEAM_KERNEL", "wave")
