@@ -2090,16 +2090,19 @@ __global__ __launch_bounds__(64) void assemble_texts(BeamArgs a) {
 }
 
 // ---- what a frame of each utterance will cost, before the wave kernel decodes it (round 6) -------------------------------------
-// The wave kernel's launch lasts as long as its slowest wave, and the slowest waves are the utterances with the most survivors
-// per frame (more candidate passes per frame: CTCDEC_WAVE_TIMES, profiles/r06_wave_times.txt). The prune stage has just counted
-// them, so the beam launch can know its heavy utterances BEFORE it starts instead of noticing them fall behind:
-//   utt_weigh  (one wave per utterance): cost per frame = WEIGH_C0 + survivors per frame (a frame costs about the same again as
-//              its ~5 survivors' passes whatever they are: the phase tables), and the utterance's total;
-//   utt_place  (one workgroup): ranks the totals by counting and deals the utterances out -- heaviest first, so that they are the
-//              oldest waves of their SIMDs (the arbiter's tie-break), and in a snake over the SIMD count, so that each SIMD's four
-//              waves add up to about the same work -- and leaves every workgroup the relative weight of its utterance
-//              (BeamArgs::block_weight), by which WaveGpuCtx::frame_done scales the frames it still has to decode.
-// Which utterance a workgroup decodes never changes what it computes (tests/test_full_occupancy.py runs both orders).
+// The wave kernel's launch lasts as long as its slowest wave. What makes a wave slow is its utterance's candidates per frame
+// (live beams x surviving labels: r = 0.97 with a wave's natural lifetime, profiles/r06_weigh_predictors.txt). The live beams are
+// known only once the utterance is decoded, but the surviving labels are what the prune stage has just counted, and they explain
+// a fifth of it (r = 0.47) -- enough to let the launch know its probably-heavy utterances BEFORE it starts:
+//   utt_weigh  (one wave per utterance): cost per frame = WEIGH_C0 + survivors per frame, and the utterance's total;
+//   utt_place  (sixteen utterances per workgroup): ranks the totals by counting and deals the utterances out -- heaviest first: workgroup
+//              b of a launch lands in slot b / 1024 of SIMD b mod 1024, so the first 1024 are the oldest waves of their SIMDs, and
+//              age is the arbiter's tie-break -- in a snake over the SIMD count, so that each SIMD's four waves add up to about the
+//              same predicted work; every workgroup is left the relative weight of its utterance (BeamArgs::block_weight), by which
+//              WaveGpuCtx::frame_done scales the frames it still has to decode.
+// Measured (profiles/r06_ab_weigh_place.log, r06_ab_weigh_gain_snake.log): the dispatch order is worth 1.0 ms of the 17-ms launch
+// (lightest first: +1.3 ms), the snake 0.2 ms, the weights in the priority rule 0.1 ms.
+// Which utterance a workgroup decodes never changes what it computes (tests/test_full_occupancy.py: placement test).
 constexpr float WEIGH_C0 = 4.0f;
 constexpr float WEIGH_GAIN = 4.0f;  // (the regression of a wave's natural lifetime on this weight has slope ~3: profiles/r06_weigh_*.txt)
 constexpr int PLACE_MAX = 8192;  // utterances utt_place ranks (LDS: 4 bytes each); larger launches keep their order
@@ -2109,7 +2112,6 @@ struct WeighArgs {
   int32_t n_utts;
   float* total;        // [n_utts] WEIGH_C0 * frames + survivors
   float* per_frame;    // [n_utts]
-  float* sum;          // [1] of per_frame (zeroed by the caller)
   const int32_t* given_order;  // or nullptr: utt_place decides
   int32_t* order;      // [n_utts] out (given_order == nullptr)
   float* block_weight; // [n_utts] out
@@ -2267,7 +2269,6 @@ int launch_beam(const BeamArgs& a, std::string* err) {
         w.per_frame = g_weigh + (size_t)a.n_utts;
         w.block_weight = g_weigh + (size_t)a.n_utts * 2;
         w.order = (int32_t*)(g_weigh + (size_t)a.n_utts * 3);
-        w.sum = (float*)(g_progress + 1);
         const bool keep_order = a.order != nullptr || getenv("CTCDEC_NO_PLACE") != nullptr || a.n_utts > PLACE_MAX || wa.prio_mode != 33;
         w.given_order = a.order;               // (a ragged multi-round launch keeps its longest-first order)
         w.simds = keep_order ? -1 : 4 * g_cus;  // -1: weights only
